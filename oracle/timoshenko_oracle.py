@@ -1,0 +1,312 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) — numpy/scipy restatement of pyLatticeDSO's beam FEM.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module; the product path (``pylatticedso_amd``) never does.
+
+Parity status: PINNED by the reference's committed dolfinx outputs
+``data/outputs/schur_complement/Schur_complement_{BCC,Hybrid1,Hybrid4}.npz`` (subset under
+``tests/golden/schur_*.npz``) — see ``tests/test_oracle_golden.py``.  The reference FEM path itself
+(dolfinx 0.9.0 / PETSc / gmsh, pyproject.toml:22-30) is not installable here, so what is restated is
+the weak form the reference hands to dolfinx plus gmsh's 1-D subdivision rule.
+
+What each function follows (paths relative to the reference repo):
+
+* ``section_constants``      src/pyLatticeSim/material_definition.py:44-45,122-156  (kappa=0.9, G=E/2(1+nu))
+* ``local_frame``            src/pyLatticeSim/beam_model.py:197-216
+* ``sub_element_stiffness``  src/pyLatticeSim/simulation_base.py:141-156 (strains), :190-197 (shear terms use
+                             quadrature_degree 1 = mid-point rule), :220-225 (bilinear form)
+* ``gmsh_subdivisions``      src/pyLatticeSim/lattice_generation.py:50-64 (h = 0.05*cell_size_x) + gmsh 1-D mesher
+* ``assemble_submeshed``     src/pyLatticeSim/lattice_generation.py:134-175, simulation_base.py:465-476
+* ``schur_complement``       src/pyLatticeSim/schur_complement.py:75-147
+* ``solve_dirichlet``        src/pyLatticeSim/simulation_base.py:465-514 (assemble with bcs, lifting, point loads, LU)
+* ``reference_cg``           src/pyLatticeSim/conjugate_gradient_solver.py:15-122
+* ``condensed_beam`` / ``beam_matrix``  closed-form static condensation of the above (derivation in DESIGN.md §3)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+KAPPA = 0.9          # material_definition.py:45
+PENALIZATION = 1.5   # beam.py:71 / lattice_sim.py:112
+MESH_FRACTION = 0.05  # lattice_generation.py:50 (mesh_element_lenght)
+
+
+# --------------------------------------------------------------------------------------------
+# element
+# --------------------------------------------------------------------------------------------
+def section_constants(radius, E, nu, kappa=KAPPA):
+    """C = [ES, kGS, kGS, GJ, EI, EI] for a circular section (material_definition.py:113,142-156)."""
+    G = E / (2.0 * (1.0 + nu))
+    S = math.pi * radius ** 2
+    I = math.pi * radius ** 4 / 4.0
+    J = 2.0 * I
+    return np.array([E * S, G * kappa * S, G * kappa * S, G * J, E * I, E * I])
+
+
+def local_frame(t):
+    """(t, a1, a2) exactly as beam_model.py:197-216 builds them from the element tangent."""
+    t = np.asarray(t, dtype=float)
+    t = t / np.linalg.norm(t)
+    ex, ey, ez = np.eye(3)
+    e1 = ey if abs(t[1]) < abs(t[0]) else ex
+    te1 = float(t @ e1)
+    e2 = ez if abs(t[2]) < abs(te1) else e1
+    a1 = np.cross(t, e2)
+    a1 /= np.linalg.norm(a1)
+    a2 = np.cross(t, a1)
+    a2 /= np.linalg.norm(a2)
+    return t, a1, a2
+
+
+def sub_element_stiffness(xa, xb, C):
+    """12x12 stiffness of ONE P1xP1 line element A->B; DOF order [wA(3), thA(3), wB(3), thB(3)].
+
+    strains (simulation_base.py:141-156), with w' = (wB-wA)/l, th' = (thB-thA)/l and th_m = (thA+thB)/2
+    for the two shear rows (integrated with the mid-point rule, simulation_base.py:193-195):
+        e0 = w'.t   e1 = w'.a1 - th_m.a2   e2 = w'.a2 + th_m.a1   e3 = th'.t   e4 = th'.a1   e5 = th'.a2
+    K_e = l * sum_i C_i b_i b_i^T
+    """
+    xa = np.asarray(xa, float)
+    xb = np.asarray(xb, float)
+    d = xb - xa
+    l = float(np.linalg.norm(d))
+    t, a1, a2 = local_frame(d)
+    Bm = np.zeros((6, 12))
+    # w' rows
+    Bm[0, 0:3], Bm[0, 6:9] = -t / l, t / l
+    Bm[1, 0:3], Bm[1, 6:9] = -a1 / l, a1 / l
+    Bm[2, 0:3], Bm[2, 6:9] = -a2 / l, a2 / l
+    # mid-point rotations in the shear rows
+    Bm[1, 3:6], Bm[1, 9:12] = -0.5 * a2, -0.5 * a2
+    Bm[2, 3:6], Bm[2, 9:12] = 0.5 * a1, 0.5 * a1
+    # th' rows
+    Bm[3, 3:6], Bm[3, 9:12] = -t / l, t / l
+    Bm[4, 3:6], Bm[4, 9:12] = -a1 / l, a1 / l
+    Bm[5, 3:6], Bm[5, 9:12] = -a2 / l, a2 / l
+    return l * (Bm.T * C) @ Bm
+
+
+def gmsh_subdivisions(length, h):
+    """Number of equal P1 elements gmsh puts on a straight line of ``length`` with uniform size ``h``.
+
+    gmsh's 1-D mesher integrates 1/h along the curve (a = length/h for a uniform field) and uses
+    N_points = int(a + 1.99), i.e. n_elements = int(a + 0.99) (>= 1).  ``ceil(a)`` agrees except for
+    frac(a) in (0, 0.01].  Pinned by tests/golden/schur_*.npz (round/floor miss by 1e-5..1e-4).
+    """
+    a = length / h
+    return max(1, int(a + 0.99))
+
+
+# --------------------------------------------------------------------------------------------
+# reference-faithful sub-meshed assembly
+# --------------------------------------------------------------------------------------------
+def assemble_submeshed(node_xyz, seg_conn, seg_radius, E, nu, h, kappa=KAPPA):
+    """Global K (CSR, 6 DOF/vertex) on the gmsh-like sub-mesh of every segment.
+
+    ``seg_conn``/``seg_radius`` are the lattice's (already penalised) segments with their ACTUAL radius
+    (penalised segments carry 1.5 r, beam.py:405-411).  Vertices 0..N-1 are the lattice nodes, the
+    interior sub-nodes of each segment follow.  Returns (K, n_vertices).
+    """
+    node_xyz = np.asarray(node_xyz, float)
+    N = len(node_xyz)
+    rows, cols, vals = [], [], []
+    nv = N
+    for (ia, ib), r in zip(np.asarray(seg_conn), np.asarray(seg_radius)):
+        xa, xb = node_xyz[ia], node_xyz[ib]
+        L = float(np.linalg.norm(xb - xa))
+        n = gmsh_subdivisions(L, h)
+        C = section_constants(r, E, nu, kappa)
+        ids = [ia] + list(range(nv, nv + n - 1)) + [ib]
+        nv += n - 1
+        Ke = sub_element_stiffness(xa, xa + (xb - xa) / n, C)  # identical for every sub-element of the line
+        for e in range(n):
+            dofs = np.r_[6 * ids[e] + np.arange(6), 6 * ids[e + 1] + np.arange(6)]
+            rows.append(np.repeat(dofs, 12))
+            cols.append(np.tile(dofs, 12))
+            vals.append(Ke.ravel())
+    K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(6 * nv, 6 * nv)).tocsr()
+    return K, nv
+
+
+def schur_complement(K, boundary_dofs):
+    """S = K_BB - K_BI K_II^-1 K_IB (schur_complement.py:75-147), dense."""
+    n = K.shape[0]
+    bd = np.asarray(boundary_dofs)
+    mask = np.ones(n, bool)
+    mask[bd] = False
+    it = np.flatnonzero(mask)
+    K = K.tocsc()
+    Kii = K[it][:, it].tocsc()
+    Kib = K[it][:, bd]
+    Kbb = K[bd][:, bd].toarray()
+    lu = spla.splu(Kii)
+    U = lu.solve(Kib.toarray())
+    return Kbb - Kib.T @ U
+
+
+def solve_dirichlet(K, fixed_mask, ubar, f):
+    """Direct solve with dolfinx semantics (simulation_base.py:465-514): constrained rows/cols -> identity,
+    RHS lifted by -K[:,c] ubar_c, b_c = ubar_c, then point loads added (also on constrained dofs).
+    Returns the full displacement vector."""
+    fixed_mask = np.asarray(fixed_mask, bool).ravel()
+    ubar = np.asarray(ubar, float).ravel()
+    f = np.asarray(f, float).ravel()
+    free = np.flatnonzero(~fixed_mask)
+    fix = np.flatnonzero(fixed_mask)
+    K = K.tocsr()
+    b = -(K[free][:, fix] @ ubar[fix]) + f[free]
+    u = np.zeros(K.shape[0])
+    u[fix] = ubar[fix] + f[fix]          # b.setValues(ADD) after set_bc (simulation_base.py:494-498)
+    u[free] = spla.splu(K[free][:, free].tocsc()).solve(b)
+    return u
+
+
+# --------------------------------------------------------------------------------------------
+# closed-form condensation: one 2-node element per lattice beam
+# --------------------------------------------------------------------------------------------
+def segment_flexibility(length, n, radius, E, nu, kappa=KAPPA):
+    """Tip flexibility of a clamped chain of ``n`` identical sub-elements (total ``length``).
+
+    returns (f_axial, f_torsion, f11, f12, f22) with the bending-plane block [[f11, f12], [f12, f22]]
+    acting on (transverse force, bending moment) -> (deflection, rotation):
+        f11 = L/(kGS) + L^3/(3EI) (1 - 1/(4 n^2)),  f12 = L^2/(2EI),  f22 = L/(EI)
+    """
+    ES, GS, _, GJ, EI, _ = section_constants(radius, E, nu, kappa)
+    L = length
+    return (L / ES, L / GJ,
+            L / GS + L ** 3 / (3.0 * EI) * (1.0 - 1.0 / (4.0 * n * n)),
+            L ** 2 / (2.0 * EI), L / EI)
+
+
+def condensed_beam(radius, seg_len, seg_n, E, nu, kappa=KAPPA, pen=PENALIZATION):
+    """5 stiffness scalars (ka, kt, a, b, c) of the lattice beam A->B made of up to three colinear
+    segments [pen(L1) | mid | pen(L2)] in series (zero-length segments are skipped).
+
+    (a, b, c) is the inverse of the summed, tip-transported bending flexibility at end B:
+        F = sum_i T_i^T F_i T_i,  T_i = [[1, 0], [d_i, 1]],  d_i = distance from segment end to B
+        [[a, -b], [-b, c]] = F^-1
+    """
+    radii = (pen * radius, radius, pen * radius)
+    L = float(sum(seg_len))
+    fa = ft = f11 = f12 = f22 = 0.0
+    s = 0.0
+    for l, n, r in zip(seg_len, seg_n, radii):
+        if l <= 0.0:
+            continue
+        ga, gt, g11, g12, g22 = segment_flexibility(l, n, r, E, nu, kappa)
+        d = L - (s + l)
+        fa += ga
+        ft += gt
+        f11 += g11 + 2.0 * d * g12 + d * d * g22
+        f12 += g12 + d * g22
+        f22 += g22
+        s += l
+    det = f11 * f22 - f12 * f12
+    return 1.0 / fa, 1.0 / ft, f22 / det, f12 / det, f11 / det
+
+
+def _skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def beam_matrix(scalars, d):
+    """12x12 stiffness of the condensed beam with end-to-end vector d = xB - xA.
+
+    End-B forces from the relative deformation (du = uB - uA + d x thA ... see DESIGN.md §3):
+        F_B = ka (du.t) t + a du_perp + b t x dth
+        M_B = kt (dth.t) t + c dth_perp - b t x du
+    and F_A = -F_B, M_A = -M_B - d x F_B (equilibrium).
+    """
+    ka, kt, a, b, c = scalars
+    d = np.asarray(d, float)
+    L = np.linalg.norm(d)
+    t = d / L
+    P = np.eye(3) - np.outer(t, t)
+    T = np.outer(t, t)
+    Tx = _skew(t)
+    Kbb = np.block([[ka * T + a * P, b * Tx], [-b * Tx, kt * T + c * P]])
+    # e = q_B - R q_A ; R = [[I, -[d]x], [0, I]]   (uB_rigid = uA + thA x d = uA - d x thA)
+    R = np.block([[np.eye(3), -_skew(d)], [np.zeros((3, 3)), np.eye(3)]])
+    K = np.zeros((12, 12))
+    K[6:, 6:] = Kbb
+    K[:6, 6:] = -R.T @ Kbb
+    K[6:, :6] = -Kbb @ R
+    K[:6, :6] = R.T @ Kbb @ R
+    return K
+
+
+def assemble_condensed(node_xyz, conn, scalars):
+    """Global K (CSR) with one condensed 2-node element per beam; scalars[B,5]."""
+    rows, cols, vals = [], [], []
+    node_xyz = np.asarray(node_xyz, float)
+    for (ia, ib), sc in zip(np.asarray(conn), np.asarray(scalars)):
+        Ke = beam_matrix(sc, node_xyz[ib] - node_xyz[ia])
+        dofs = np.r_[6 * ia + np.arange(6), 6 * ib + np.arange(6)]
+        rows.append(np.repeat(dofs, 12))
+        cols.append(np.tile(dofs, 12))
+        vals.append(Ke.ravel())
+    n = 6 * len(node_xyz)
+    return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+
+
+def beam_apply(scalars, d, xa, xb):
+    """Matrix-free product of one condensed beam: returns (fA[6], fB[6]) for end vectors xa, xb (each [u,th])."""
+    ka, kt, a, b, c = scalars
+    d = np.asarray(d, float)
+    L = np.linalg.norm(d)
+    t = d / L
+    du = xb[:3] - xa[:3] + np.cross(d, xa[3:])
+    dth = xb[3:] - xa[3:]
+    dut = du @ t
+    dtt = dth @ t
+    FB = (ka - a) * dut * t + a * du + b * np.cross(t, dth)
+    MB = (kt - c) * dtt * t + c * dth - b * np.cross(t, du)
+    FA = -FB
+    MA = -MB - np.cross(d, FB)
+    return np.r_[FA, MA], np.r_[FB, MB]
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's hand-written CG
+# --------------------------------------------------------------------------------------------
+def reference_cg(A, b, M=None, maxiter=100, tol=1e-5, mintol=1e-5, restart_every=1000, alpha_max=0.1,
+                 callback=None):
+    """Restatement of conjugate_gradient_solver.py:15-122 (x0 = 0, alpha clamp, restart, three stop tests)."""
+    matvec = (lambda v: A @ v)
+    prec = (lambda v: M @ v) if M is not None else (lambda v: v)
+    x = np.zeros(b.shape[0])
+    r = b - matvec(x)
+    # NB: without a preconditioner the reference sets ``z = r`` (an alias, not a copy) and then updates r in
+    # place, so a restart (p = z.copy()) picks up the CURRENT residual; with M it picks up the previous z.
+    z = prec(r) if M is not None else r
+    p = z.copy()
+    rz_old = r @ z
+    norm_b = np.linalg.norm(b)
+    info = 1
+    for k in range(maxiter):
+        Ap = matvec(p)
+        alpha = min(rz_old / (p @ Ap), alpha_max)
+        x += alpha * p
+        r -= alpha * Ap
+        if callback is not None:
+            callback(x)
+        if k % restart_every == 0 and k > 0:
+            p = z.copy()
+        if np.linalg.norm(r) <= tol * norm_b:
+            info = 0
+            break
+        if np.linalg.norm(p) < mintol * (np.linalg.norm(x) + 1e-12):
+            info = 0
+            break
+        if alpha < 1e-6:
+            info = 2
+        z = prec(r) if M is not None else r
+        rz_new = r @ z
+        p = z + (rz_new / rz_old) * p
+        rz_old = rz_new
+    return x, info
