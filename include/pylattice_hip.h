@@ -1,0 +1,158 @@
+/*
+ * pylattice_hip.h — C ABI of libpylattice_hip.so (MI355X / gfx950).
+ *
+ * The reference (Tcadart/pyLatticeDSO, 100 % Python) has no FFI of its own; the seam this library sits behind is
+ * the dolfinx/PETSc work done inside
+ *     solve_FEM_FenicsX            src/pyLatticeSim/utils_simulation.py:21-56
+ *     SimulationBase.solve_problem src/pyLatticeSim/simulation_base.py:465-514   (assemble K, lifting, LU solve)
+ *     get_schur_complement         src/pyLatticeSim/utils_schur.py:22-53
+ *     LatticeOpti.calculate_gradient src/pyLatticeOpti/lattice_opti.py:735-907   (u^T dK/dr u, adjoint form)
+ * Each entry point below cites the reference code it replaces.  All pointers are caller-owned HOST buffers
+ * (C-contiguous) unless the name ends in _dev; device state is owned by the handle.  Every function returns
+ * 0 on success or a negative pl_status; pl_last_error() gives the message.  No C++ exceptions cross the ABI.
+ * Handles are not thread-safe; distinct handles are independent.
+ *
+ * Unknown ordering everywhere: node-major, 6 values per node [ux, uy, uz, thx, thy, thz]
+ * (mixed P1xP1 space of simulation_base.py:201-213).
+ */
+#ifndef PYLATTICE_HIP_H
+#define PYLATTICE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pl_context *pl_handle;
+
+typedef enum {
+  PL_OK = 0,
+  PL_ERR_ARG = -1,       /* bad argument (null pointer, negative size, index out of range) */
+  PL_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+  PL_ERR_STATE = -3,     /* call order violated (e.g. solve before set_bc) */
+  PL_ERR_NOCONV = -4,    /* PCG hit max iterations (solution and stats are still written) */
+  PL_ERR_NAN = -5,       /* NaN/Inf detected in the residual */
+  PL_ERR_NODEVICE = -6   /* no HIP device visible */
+} pl_status;
+
+/* The lattice the FEM mesh is built from.  One entry per DESIGN strut (before joint penalisation); the
+ * penalised end segments (LatticeSim.set_penalized_beams, lattice_sim.py:245-308) and the gmsh sub-mesh
+ * (latticeGeneration.mesh_lattice_cells, lattice_generation.py:64-101) are described per strut by seg_len/seg_nsub
+ * and condensed in closed form on the device. */
+typedef struct {
+  int64_t n_nodes;
+  int64_t n_beams;
+  const double *node_xyz;     /* [3*n_nodes] */
+  const int32_t *beam_conn;   /* [2*n_beams] point1, point2 */
+  const double *beam_radius;  /* [n_beams]   un-penalised radius r (end segments use pen_coef*r) */
+  const double *seg_len;      /* [3*n_beams] geometric length of [pen@point1, middle, pen@point2], 0 = absent */
+  const int32_t *seg_nsub;    /* [3*n_beams] number of equal P1 sub-elements per segment (>=1 where len>0) */
+} pl_mesh_t;
+
+typedef struct {
+  double young;          /* E   (materials/<name>.json Young_modulus) */
+  double poisson;        /* nu */
+  double kappa;          /* shear correction, 0.9 in material_definition.py:45 */
+  double pen_coef;       /* radius multiplier of penalised segments, 1.5 (beam.py:71) */
+  int32_t device;        /* HIP device ordinal */
+  int32_t spmv_kernel;   /* 0 = auto, 1 = per-strut + f64 atomics, 2 = per-node gather (sliced ELL), 3 = LDS tiles */
+  int32_t precond;       /* 0 = none, 1 = Jacobi (diagonal), 2 = 6x6 block Jacobi */
+  int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
+  int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
+  int32_t reserved[7];
+} pl_opts_t;
+
+typedef struct {
+  int32_t iterations;
+  int32_t converged;       /* 1 if ||r|| <= rtol*||b|| */
+  double rel_residual;     /* ||r||/||b|| of the recurrence at exit */
+  double b_norm;
+  double ms_assembly;      /* last pl_assemble (+ pl_assemble_bsr) on the device, HIP events */
+  double ms_solve;         /* last pl_solve, HIP events around the PCG loop */
+  double ms_spmv_avg;      /* average K*x kernel time inside the last pl_solve (HIP events, sampled) */
+  double reserved[8];
+} pl_stats_t;
+
+void pl_default_opts(pl_opts_t *o);
+const char *pl_last_error(void);
+const char *pl_version(void);
+
+/* Upload topology + geometry; builds the node->strut incidence.  Replaces BeamModel.__init__ /
+ * latticeGeneration (beam_model.py:57-105, lattice_generation.py:64-175). */
+int pl_create(const pl_mesh_t *mesh, const pl_opts_t *opts, pl_handle *out);
+void pl_destroy(pl_handle h);
+
+/* Dirichlet / load data per dof.  fixed[6N] (0/1), ubar[6N] prescribed values (read where fixed), f[6N] nodal
+ * loads.  Replaces apply_displacement_all_nodes_with_lattice_data / apply_force_on_all_nodes_with_lattice_data
+ * (full_scale_lattice_simulation.py:39-73,124-153).  Any of ubar/f may be NULL (= zeros). */
+int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const double *f);
+
+/* New radii, same topology/segment geometry (optimisation loop; Cell.change_beam_radius cell.py:896-917). */
+int pl_update_radii(pl_handle h, const double *beam_radius);
+/* New penalised-segment geometry (when the caller re-runs the angle search, lattice_sim.py:1421-1497). */
+int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_nsub);
+
+/* Per-strut stiffness build ("assembly" of the matrix-free operator): condensed element records + the
+ * preconditioner.  Replaces Material.compute_mechanical_properties + the FFCx element kernel
+ * (material_definition.py:142-156, simulation_base.py:220-225). */
+int pl_assemble(pl_handle h);
+
+/* Explicit global K as BSR(6x6) on the device (dolfinx assemble_matrix, simulation_base.py:473-476).
+ * with_bc != 0 applies dolfinx's Dirichlet treatment (constrained rows/cols zeroed, unit diagonal). */
+int pl_assemble_bsr(pl_handle h, int with_bc, int64_t *n_block_rows, int64_t *n_blocks);
+int pl_get_bsr(pl_handle h, int64_t *rowptr /*[N+1]*/, int32_t *colidx /*[nblk]*/, double *vals /*[36*nblk]*/);
+
+/* y = K x with the full (unconstrained) operator; test hook and building block of reactions. */
+int pl_spmv(pl_handle h, const double *x, double *y);
+/* y = P K P x with P the projector on free dofs (the PCG operator). */
+int pl_spmv_free(pl_handle h, const double *x, double *y);
+/* y = BSR * x using the explicitly assembled matrix (cross-check of the two paths). */
+int pl_spmv_bsr(pl_handle h, const double *x, double *y);
+
+/* Solve K u = f with the Dirichlet data of pl_set_bc by Jacobi-PCG on the matrix-free operator.
+ * Replaces the PETSc KSP(preonly)+PC(LU) solve of simulation_base.py:501-511.  u[6N] gets the full field
+ * (prescribed values on constrained dofs).  rtol is on ||r||/||b||. */
+int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *stats);
+
+/* R = K u on every dof (caller keeps the constrained ones).  Replaces
+ * calculate_reaction_force_and_moment_at_position (simulation_base.py:582-645). */
+int pl_reactions(pl_handle h, const double *u, double *R);
+
+/* Per-strut sensitivity s_b = lam_e^T (dK_e/dr_b) u_e at fixed segment geometry (lam == NULL -> lam = u).
+ * Replaces the dS/dr contraction of LatticeOpti.calculate_gradient (lattice_opti.py:746-902) and the dormant
+ * Material.compute_gradient (material_definition.py:163-231). */
+int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr);
+
+/* Strain energy 1/2 u^T K u (LatticeOpti.compute_compliance, lattice_opti.py:645-663 uses u^T K u). */
+int pl_energy(pl_handle h, const double *u, double *energy);
+
+/* Dense condensation of a node subset: S = K_BB - K_BI K_II^-1 K_IB for the boundary nodes listed, computed
+ * column by column with the device PCG.  Replaces SchurComplement.calculate_schur_complement
+ * (schur_complement.py:75-147).  S is [6*nb x 6*nb] row-major. */
+int pl_schur(pl_handle h, const int32_t *boundary_nodes, int32_t nb, double rtol, int32_t max_iter, double *S);
+
+/* Debug / test access to the condensed per-strut records: rec[8*B] = (a, c, e1, e2, e3, dx, dy, dz). */
+int pl_get_records(pl_handle h, double *rec);
+
+/* Measurement hooks (bench.py): run `reps` launches of one kernel on the handle's stream between two HIP
+ * events and return the average milliseconds.  which: 0 = K*p (PCG operator), 1 = record build,
+ * 2 = BSR fill, 3 = one full PCG iteration, 4 = BSR SpMV. */
+int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
+/* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr. */
+int pl_algorithmic_bytes(pl_handle h, double *out3);
+
+/* ---- multi-GPU (slab partition, RCCL) ---------------------------------------------------------------- */
+/* Size of the opaque RCCL unique id the ranks must share (rank 0 fills it with pl_dist_unique_id). */
+int pl_dist_unique_id_bytes(void);
+int pl_dist_unique_id(void *id_out);
+/* Attach this handle (one per rank/GPU) to a communicator.  shared_nodes lists, for each node of THIS rank's
+ * sub-lattice that also exists on other ranks, its local index and a global id (dense 0..n_shared_global-1);
+ * partial forces on those nodes are summed across ranks after every local K*x. */
+int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const int32_t *shared_local,
+                 const int32_t *shared_global, int32_t n_shared, int32_t n_shared_global);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLATTICE_HIP_H */

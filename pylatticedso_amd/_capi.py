@@ -1,0 +1,249 @@
+"""ctypes binding of libpylattice_hip.so (C ABI: include/pylattice_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpylattice_hip.so")
+
+PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_destroy", "pl_set_bc",
+           "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
+           "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_schur",
+           "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_dist_unique_id_bytes",
+           "pl_dist_unique_id", "pl_dist_init"]
+
+
+class PlMesh(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_beams", C.c_int64), ("node_xyz", C.c_void_p),
+                ("beam_conn", C.c_void_p), ("beam_radius", C.c_void_p), ("seg_len", C.c_void_p),
+                ("seg_nsub", C.c_void_p)]
+
+
+class PlOpts(C.Structure):
+    _fields_ = [("young", C.c_double), ("poisson", C.c_double), ("kappa", C.c_double), ("pen_coef", C.c_double),
+                ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
+                ("check_every", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class PlStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
+                ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
+                ("ms_spmv_avg", C.c_double), ("reserved", C.c_double * 8)]
+
+
+class PlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpylattice_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libpylattice_hip.so (built in-tree by pylatticedso_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not found - build it with `make -C pylatticedso_amd/csrc` "
+                                "(the HIP path has no CPU fallback)")
+    lib = C.CDLL(p)
+    lib.pl_last_error.restype = C.c_char_p
+    lib.pl_version.restype = C.c_char_p
+    lib.pl_destroy.restype = None
+    lib.pl_default_opts.restype = None
+    V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
+           "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
+           "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
+           "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
+           "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V],
+           "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
+           "pl_algorithmic_bytes": [V, V], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
+           "pl_dist_init": [V, I32, I32, V, V, V, I32, I32]}
+    for name, args in sig.items():
+        getattr(lib, name).argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+def _check(lib, rc, allow=()):
+    if rc != PL_OK and rc not in allow:
+        raise PlError(rc, lib.pl_last_error().decode())
+    return rc
+
+
+class HipLattice:
+    """Owner of one device handle: the condensed lattice operator + its PCG on one MI355X."""
+
+    def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
+                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=0, check_every=32):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.node_xyz = _f64(node_xyz).reshape(-1, 3)
+        self.beam_conn = np.ascontiguousarray(beam_conn, dtype=np.int32).reshape(-1, 2)
+        self.n_nodes, self.n_beams = len(self.node_xyz), len(self.beam_conn)
+        self._radius = _f64(beam_radius, self.n_beams)
+        self._seg_len = _f64(seg_len, 3 * self.n_beams)
+        self._seg_nsub = np.ascontiguousarray(seg_nsub, dtype=np.int32).reshape(-1)
+        mesh = PlMesh(self.n_nodes, self.n_beams, _ptr(self.node_xyz), _ptr(self.beam_conn), _ptr(self._radius),
+                      _ptr(self._seg_len), _ptr(self._seg_nsub))
+        opts = PlOpts()
+        self._lib.pl_default_opts(C.byref(opts))
+        opts.young, opts.poisson, opts.kappa, opts.pen_coef = young, poisson, kappa, pen_coef
+        opts.device, opts.spmv_kernel, opts.reorder, opts.check_every = device, spmv_kernel, reorder, check_every
+        _check(self._lib, self._lib.pl_create(C.byref(mesh), C.byref(opts), C.byref(self._h)))
+        self.last_stats = None
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data -------------------------------------------------------------------------------------------
+    def set_bc(self, fixed, ubar=None, f=None):
+        n6 = 6 * self.n_nodes
+        fx = np.ascontiguousarray(np.asarray(fixed).reshape(-1) != 0, dtype=np.uint8)
+        if fx.size != n6:
+            raise ValueError("fixed must have 6*n_nodes entries")
+        ub = None if ubar is None else _f64(np.asarray(ubar).reshape(-1), n6)
+        ff = None if f is None else _f64(np.asarray(f).reshape(-1), n6)
+        _check(self._lib, self._lib.pl_set_bc(self._h, _ptr(fx), _ptr(ub), _ptr(ff)))
+
+    def update_radii(self, radius):
+        self._radius = _f64(radius, self.n_beams)
+        _check(self._lib, self._lib.pl_update_radii(self._h, _ptr(self._radius)))
+
+    def update_segments(self, seg_len, seg_nsub):
+        self._seg_len = _f64(seg_len, 3 * self.n_beams)
+        self._seg_nsub = np.ascontiguousarray(seg_nsub, dtype=np.int32).reshape(-1)
+        _check(self._lib, self._lib.pl_update_segments(self._h, _ptr(self._seg_len), _ptr(self._seg_nsub)))
+
+    def assemble(self):
+        _check(self._lib, self._lib.pl_assemble(self._h))
+
+    def assemble_bsr(self, with_bc=False):
+        nr, nb = C.c_int64(), C.c_int64()
+        _check(self._lib, self._lib.pl_assemble_bsr(self._h, int(bool(with_bc)), C.byref(nr), C.byref(nb)))
+        return nr.value, nb.value
+
+    def get_bsr(self):
+        nr, nb = self.n_nodes, self.n_nodes + 2 * self.n_beams
+        rowptr = np.empty(nr + 1, np.int64)
+        col = np.empty(nb, np.int32)
+        vals = np.empty((nb, 6, 6), np.float64)
+        _check(self._lib, self._lib.pl_get_bsr(self._h, _ptr(rowptr), _ptr(col), _ptr(vals)))
+        return rowptr, col, vals
+
+    def records(self):
+        rec = np.empty((self.n_beams, 8), np.float64)
+        _check(self._lib, self._lib.pl_get_records(self._h, _ptr(rec)))
+        return rec
+
+    # -- operator ---------------------------------------------------------------------------------------
+    def _vec_op(self, fn, x):
+        x = _f64(np.asarray(x).reshape(-1), 6 * self.n_nodes)
+        y = np.empty_like(x)
+        _check(self._lib, fn(self._h, _ptr(x), _ptr(y)))
+        return y.reshape(self.n_nodes, 6)
+
+    def spmv(self, x):
+        return self._vec_op(self._lib.pl_spmv, x)
+
+    def spmv_free(self, x):
+        return self._vec_op(self._lib.pl_spmv_free, x)
+
+    def spmv_bsr(self, x):
+        return self._vec_op(self._lib.pl_spmv_bsr, x)
+
+    def reactions(self, u):
+        return self._vec_op(self._lib.pl_reactions, u)
+
+    def solve(self, rtol=1e-8, max_iter=20000, raise_on_noconv=True):
+        u = np.empty(6 * self.n_nodes, np.float64)
+        st = PlStats()
+        rc = self._lib.pl_solve(self._h, float(rtol), int(max_iter), _ptr(u), C.byref(st))
+        self.last_stats = {k: getattr(st, k) for k, _ in PlStats._fields_ if k != "reserved"}
+        _check(self._lib, rc, allow=() if raise_on_noconv else (PL_ERR_NOCONV,))
+        return u.reshape(self.n_nodes, 6), self.last_stats
+
+    def sens(self, u, lam=None):
+        u = _f64(np.asarray(u).reshape(-1), 6 * self.n_nodes)
+        lam_a = None if lam is None else _f64(np.asarray(lam).reshape(-1), 6 * self.n_nodes)
+        out = np.empty(self.n_beams, np.float64)
+        _check(self._lib, self._lib.pl_sens(self._h, _ptr(u), _ptr(lam_a), _ptr(out)))
+        return out
+
+    def energy(self, u):
+        u = _f64(np.asarray(u).reshape(-1), 6 * self.n_nodes)
+        e = C.c_double()
+        _check(self._lib, self._lib.pl_energy(self._h, _ptr(u), C.byref(e)))
+        return e.value
+
+    def schur(self, boundary_nodes, rtol=1e-12, max_iter=20000):
+        bn = np.ascontiguousarray(boundary_nodes, dtype=np.int32)
+        S = np.empty((6 * len(bn), 6 * len(bn)), np.float64)
+        _check(self._lib, self._lib.pl_schur(self._h, _ptr(bn), len(bn), float(rtol), int(max_iter), _ptr(S)))
+        return S
+
+    # -- measurement ------------------------------------------------------------------------------------
+    def time_kernel(self, which, reps=20):
+        ms = C.c_double()
+        _check(self._lib, self._lib.pl_time_kernel(self._h, int(which), int(reps), C.byref(ms)))
+        return ms.value
+
+    def algorithmic_bytes(self):
+        out = (C.c_double * 3)()
+        _check(self._lib, self._lib.pl_algorithmic_bytes(self._h, out))
+        return {"spmv": out[0], "pcg_iter": out[1], "bsr": out[2]}
+
+    # -- multi-GPU --------------------------------------------------------------------------------------
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        lib = load_library()
+        n = lib.pl_dist_unique_id_bytes()
+        buf = C.create_string_buffer(n)
+        _check(lib, lib.pl_dist_unique_id(buf))
+        return buf.raw
+
+    def dist_init(self, rank, world, unique_id: bytes, shared_local, shared_global, n_shared_global):
+        sl = np.ascontiguousarray(shared_local, dtype=np.int32)
+        sg = np.ascontiguousarray(shared_global, dtype=np.int32)
+        buf = C.create_string_buffer(unique_id, len(unique_id))
+        _check(self._lib, self._lib.pl_dist_init(self._h, int(rank), int(world), buf, _ptr(sl), _ptr(sg),
+                                                 int(len(sl)), int(n_shared_global)))

@@ -1,0 +1,866 @@
+// libpylattice_hip.so — host side of the C ABI declared in include/pylattice_hip.h (gfx950 / MI355X).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/pylattice_hip.h"
+#include "pl_kernels.h"
+#include "pl_tile.h"
+#include "pl_dist.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define PL_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+  }
+};
+
+inline unsigned grid_for(int64_t n, int block = pl::kBlock) { return (unsigned)((n + block - 1) / block); }
+inline unsigned grid_stream(int64_t n) {
+  // memory-bound grid-stride kernels: cap at 256 CUs x 8 blocks
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + pl::kBlock - 1) / pl::kBlock, 2048));
+}
+
+}  // namespace
+
+struct pl_context {
+  pl_opts_t opt{};
+  pl::Material mat{};
+  int64_t N = 0, B = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool assembled = false, have_bc = false, have_bsr = false;
+
+  // caller numbering <-> device numbering (perm[dev] = caller node)
+  std::vector<int32_t> perm, iperm;
+  bool reordered = false;
+
+  // geometry / topology (device numbering)
+  DevBuf<double> xyz, radius, seg_len;
+  DevBuf<int32_t> conn, seg_nsub;
+  DevBuf<pl::Record> rec;
+  // node -> strut incidence, sliced ELL
+  DevBuf<int64_t> slice_ptr;
+  DevBuf<int2> ent;
+  int64_t n_slices = 0, n_ent = 0;
+  // BSR
+  DevBuf<int64_t> bsr_rowptr;
+  DevBuf<int32_t> bsr_col, ent_slot, diag_slot;
+  DevBuf<double> bsr_vals;
+  int64_t nblk = 0;
+  std::vector<int64_t> h_rowptr;
+  std::vector<int32_t> h_col;
+  // boundary data
+  DevBuf<uint8_t> fixed;       // [6N] 0/1
+  DevBuf<uint8_t> fixedbits;   // [N] 6 bits
+  DevBuf<double> ubar, f;
+  // solver state
+  DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
+  int hist_cap = 0;
+  // LDS-tile operator
+  pl::TilePlan tile;
+  // multi-GPU
+  pl::Dist dist;
+
+  pl_stats_t last{};
+  double ms_assembly = 0.0;
+
+  ~pl_context() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------
+// host <-> device vector transfer in caller numbering
+// ----------------------------------------------------------------------------------------------------------
+int upload6(pl_context *c, const double *host, double *dev, std::vector<double> &stage) {
+  const size_t n6 = (size_t)c->N * 6;
+  if (!c->reordered) {
+    PL_HIP(hipMemcpyAsync(dev, host, n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    return PL_OK;
+  }
+  stage.resize(n6);
+  for (int64_t i = 0; i < c->N; ++i) std::memcpy(&stage[6 * i], host + 6 * (size_t)c->perm[i], 6 * sizeof(double));
+  PL_HIP(hipMemcpyAsync(dev, stage.data(), n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  return PL_OK;
+}
+
+int download6(pl_context *c, const double *dev, double *host) {
+  const size_t n6 = (size_t)c->N * 6;
+  if (!c->reordered) {
+    PL_HIP(hipMemcpyAsync(host, dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    return PL_OK;
+  }
+  std::vector<double> stage(n6);
+  PL_HIP(hipMemcpyAsync(stage.data(), dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < c->N; ++i) std::memcpy(host + 6 * (size_t)c->perm[i], &stage[6 * i], 6 * sizeof(double));
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// operator launches (device vectors, device numbering)
+// ----------------------------------------------------------------------------------------------------------
+int choose_kernel(const pl_context *c) { return c->opt.spmv_kernel == 0 ? 2 : c->opt.spmv_kernel; }
+
+// y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
+int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+  const int kind = choose_kernel(c);
+  const int64_t n6 = c->N * 6;
+  if (kind == 1) {
+    PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(pl::k_spmv_atomic, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
+                       c->rec.p, x, y);
+    if (c->dist.active) {
+      int rc = pl::dist_sum_shared(c->dist, y, c->stream);
+      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+      if (masked || dot_dev)
+        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
+    } else if (masked || dot_dev) {
+      hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
+    }
+  } else if (kind == 3 && c->tile.ready && !c->dist.active) {
+    pl::launch_tile_spmv(c->tile, c->rec.p, masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream);
+  } else {
+    const unsigned g = grid_for(c->N);
+    if (c->dist.active) {
+      // local partial product, interface sum across ranks, then mask + weighted dot
+      hipLaunchKernelGGL((pl::k_spmv_gather<false, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, (double *)nullptr);
+      int rc = pl::dist_sum_shared(c->dist, y, c->stream);
+      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+      if (masked || dot_dev)
+        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
+    } else if (masked && dot_dev)
+      hipLaunchKernelGGL((pl::k_spmv_gather<true, true>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
+    else if (masked)
+      hipLaunchKernelGGL((pl::k_spmv_gather<true, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
+    else if (dot_dev)
+      hipLaunchKernelGGL((pl::k_spmv_gather<false, true>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
+    else
+      hipLaunchKernelGGL((pl::k_spmv_gather<false, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
+  }
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+int ensure_hist(pl_context *c, int cap) {
+  if (cap <= c->hist_cap) return PL_OK;
+  PL_HIP(c->hist.alloc((size_t)cap));
+  c->hist_cap = cap;
+  return PL_OK;
+}
+
+int launch_records(pl_context *c) {
+  hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
+                     c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mat, c->rec.p);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+int launch_diag(pl_context *c) {
+  hipLaunchKernelGGL(pl::k_diag_gather, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p,
+                     c->ent.p, c->rec.p, c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr, c->diag.p,
+                     c->dinv.p);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active) {
+    // the diagonal of shared nodes is the sum over ranks; then invert again
+    int rc = pl::dist_sum_shared(c->dist, c->diag.p, c->stream);
+    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of the Jacobi diagonal failed");
+    pl::launch_invert_diag(c->N * 6, c->diag.p, c->have_bc ? c->fixed.p : nullptr, c->dinv.p, c->stream);
+  }
+  return PL_OK;
+}
+
+int launch_bsr_fill(pl_context *c, int with_bc) {
+  hipLaunchKernelGGL(pl::k_bsr_fill, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p,
+                     c->ent.p, c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p,
+                     c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr, with_bc, c->bsr_vals.p);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// One PCG iteration (k = iteration index for the residual history).
+int pcg_iteration(pl_context *c, int k) {
+  const int64_t n6 = c->N * 6;
+  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, c->scal.p + pl::S_PAP);
+  if (rc) return rc;
+  if (c->dist.active) pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_PAP, 1, c->stream);
+  if (c->dist.active) {
+    pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p,
+                                   c->scal.p, c->stream);
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_NEW, 2, c->stream);
+  } else {
+    hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->scal.p);
+  }
+  hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
+                     c->p.p, c->scal.p);
+  hipLaunchKernelGGL(pl::k_pcg_rotate, dim3(1), dim3(1), 0, c->stream, c->scal.p, c->hist.p, k);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// Solve P K P x = rhs (device rhs already masked), x0 = 0.  Result in c->x.  Returns iterations through stats.
+int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+              pl_stats_t *st) {
+  const int64_t n6 = c->N * 6;
+  int rc = ensure_hist(c, max_iter + 1);
+  if (rc) return rc;
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, pl::S_COUNT * sizeof(double), c->stream));
+  if (c->dist.active)
+    pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
+                                 c->z.p, c->p.p, c->scal.p, c->stream);
+  else
+    hipLaunchKernelGGL(pl::k_pcg_init, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active) {
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD, 1, c->stream);
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB, 1, c->stream);
+  }
+  double h_scal[pl::S_COUNT];
+  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p, sizeof(h_scal), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  const double bb = h_scal[pl::S_BB];
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  if (!(bb > 0.0)) {   // zero right-hand side -> zero solution
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  const int chunk = c->opt.check_every > 0 ? c->opt.check_every : 32;
+  std::vector<double> h_hist(chunk);
+  int k = 0;
+  while (k < max_iter) {
+    const int todo = std::min(chunk, max_iter - k);
+    for (int j = 0; j < todo; ++j) {
+      rc = pcg_iteration(c, k + j);
+      if (rc) return rc;
+    }
+    PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < todo; ++j) {
+      const double rr = h_hist[j];
+      if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+      st->rel_residual = std::sqrt(rr / bb);
+      if (rr <= thresh && !st->converged) {
+        st->converged = 1;
+        st->iterations = k + j + 1;
+      }
+    }
+    k += todo;
+    if (st->converged) break;
+  }
+  if (!st->converged) st->iterations = k;
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// incidence (sliced ELL) + BSR pattern, on the host
+// ----------------------------------------------------------------------------------------------------------
+int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
+  const int64_t N = c->N, B = c->B;
+  std::vector<int32_t> deg(N, 0);
+  for (int64_t b = 0; b < B; ++b) {
+    deg[conn[2 * b]]++;
+    deg[conn[2 * b + 1]]++;
+  }
+  std::vector<int64_t> ptr(N + 1, 0);
+  for (int64_t i = 0; i < N; ++i) ptr[i + 1] = ptr[i] + deg[i];
+  struct E {
+    int32_t other, code;
+  };
+  std::vector<E> adj((size_t)ptr[N]);
+  std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t a = conn[2 * b], d = conn[2 * b + 1];
+    adj[fill[d]++] = {a, (int32_t)b};                               // node d is the strut's tip (point2)
+    adj[fill[a]++] = {d, (int32_t)((uint32_t)b | 0x80000000u)};     // node a is point1 -> reversed record
+  }
+  for (int64_t i = 0; i < N; ++i)
+    std::sort(adj.begin() + ptr[i], adj.begin() + ptr[i + 1],
+              [](const E &l, const E &r) { return l.other < r.other || (l.other == r.other && l.code < r.code); });
+
+  // sliced ELL, 64 nodes per slice
+  const int64_t S = (N + 63) / 64;
+  std::vector<int64_t> sp(S + 1, 0);
+  for (int64_t s = 0; s < S; ++s) {
+    int w = 0;
+    for (int64_t i = s * 64; i < std::min<int64_t>(N, s * 64 + 64); ++i) w = std::max(w, deg[i]);
+    sp[s + 1] = sp[s] + (int64_t)w * 64;
+  }
+  std::vector<int2> ent((size_t)sp[S], int2{-1, 0});
+  // BSR pattern: per row the diagonal block + one block per entry, columns ascending.  Parallel struts between the
+  // same pair of nodes (possible in hybrid cells) get separate blocks with equal column index.
+  c->h_rowptr.assign(N + 1, 0);
+  for (int64_t i = 0; i < N; ++i) c->h_rowptr[i + 1] = c->h_rowptr[i] + deg[i] + 1;
+  c->nblk = c->h_rowptr[N];
+  c->h_col.assign((size_t)c->nblk, 0);
+  std::vector<int32_t> ent_slot((size_t)sp[S], 0), diag_slot(N, 0);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t s = i >> 6, lane = i & 63;
+    int slot = 0;
+    bool diag_done = false;
+    for (int j = 0; j < deg[i]; ++j) {
+      const E &e = adj[ptr[i] + j];
+      if (!diag_done && e.other > i) {
+        diag_slot[i] = slot;
+        c->h_col[c->h_rowptr[i] + slot++] = (int32_t)i;
+        diag_done = true;
+      }
+      const int64_t pos = sp[s] + (int64_t)j * 64 + lane;
+      ent[pos] = int2{e.other, e.code};
+      ent_slot[pos] = slot;
+      c->h_col[c->h_rowptr[i] + slot++] = e.other;
+    }
+    if (!diag_done) {
+      diag_slot[i] = slot;
+      c->h_col[c->h_rowptr[i] + slot++] = (int32_t)i;
+    }
+  }
+  c->n_slices = S;
+  c->n_ent = sp[S];
+  PL_HIP(c->slice_ptr.alloc(S + 1));
+  PL_HIP(c->ent.alloc(std::max<size_t>(1, ent.size())));
+  PL_HIP(c->ent_slot.alloc(std::max<size_t>(1, ent_slot.size())));
+  PL_HIP(c->diag_slot.alloc(N));
+  PL_HIP(hipMemcpy(c->slice_ptr.p, sp.data(), (S + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  if (!ent.empty()) {
+    PL_HIP(hipMemcpy(c->ent.p, ent.data(), ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    PL_HIP(hipMemcpy(c->ent_slot.p, ent_slot.data(), ent_slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  PL_HIP(hipMemcpy(c->diag_slot.p, diag_slot.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+  return PL_OK;
+}
+
+bool valid(pl_handle h) { return h != nullptr; }
+
+}  // namespace
+
+// ==========================================================================================================
+// C ABI
+// ==========================================================================================================
+extern "C" {
+
+const char *pl_last_error(void) { return g_err.c_str(); }
+const char *pl_version(void) { return "pylattice_hip 0.1 (gfx950)"; }
+
+void pl_default_opts(pl_opts_t *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->young = 1013.0;   // VeroClear
+  o->poisson = 0.3;
+  o->kappa = 0.9;
+  o->pen_coef = 1.5;
+  o->device = 0;
+  o->spmv_kernel = 0;
+  o->precond = 1;
+  o->reorder = 0;
+  o->check_every = 32;
+}
+
+int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
+  if (!m || !o || !out) return fail(PL_ERR_ARG, "pl_create: null argument");
+  if (m->n_nodes <= 0 || m->n_beams <= 0) return fail(PL_ERR_ARG, "pl_create: empty mesh");
+  if (m->n_nodes >= (1LL << 31) - 64 || m->n_beams >= (1LL << 31) - 64)
+    return fail(PL_ERR_ARG, "pl_create: more than 2^31 nodes/struts per handle");
+  if (!m->node_xyz || !m->beam_conn || !m->beam_radius || !m->seg_len || !m->seg_nsub)
+    return fail(PL_ERR_ARG, "pl_create: null mesh array");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PL_ERR_NODEVICE, "pl_create: no HIP device visible (libpylattice_hip has no CPU fallback)");
+  if (o->device < 0 || o->device >= ndev) return fail(PL_ERR_ARG, "pl_create: bad device ordinal");
+  const int64_t N = m->n_nodes, B = m->n_beams;
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t a = m->beam_conn[2 * b], d = m->beam_conn[2 * b + 1];
+    if (a < 0 || d < 0 || a >= N || d >= N || a == d)
+      return fail(PL_ERR_ARG, "pl_create: strut " + std::to_string(b) + " has invalid end nodes");
+    if (!(m->beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_create: non-positive radius");
+    const double L = m->seg_len[3 * b] + m->seg_len[3 * b + 1] + m->seg_len[3 * b + 2];
+    if (!(L > 0.0)) return fail(PL_ERR_ARG, "pl_create: strut with zero length");
+    for (int k = 0; k < 3; ++k)
+      if (m->seg_len[3 * b + k] < 0.0 || (m->seg_len[3 * b + k] > 0.0 && m->seg_nsub[3 * b + k] < 1))
+        return fail(PL_ERR_ARG, "pl_create: bad segment data on strut " + std::to_string(b));
+  }
+  PL_HIP(hipSetDevice(o->device));
+  pl_context *c = new pl_context();
+  c->opt = *o;
+  c->N = N;
+  c->B = B;
+  c->mat = {o->young, o->young / (2.0 * (1.0 + o->poisson)), o->kappa, o->pen_coef};
+  auto bail = [&](int rc) {
+    delete c;
+    return rc;
+  };
+#define PL_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc) return bail(_rc);    \
+  } while (0)
+#define PL_HIPC(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PL_HIPC(hipEventCreate(&c->ev0));
+  PL_HIPC(hipEventCreate(&c->ev1));
+
+  // node ordering on the device
+  c->perm.resize(N);
+  std::iota(c->perm.begin(), c->perm.end(), 0);
+  if (o->reorder == 1) {
+    pl::spatial_order(m->node_xyz, N, c->perm);
+    c->reordered = true;
+  }
+  c->iperm.resize(N);
+  for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
+
+  std::vector<double> xyz((size_t)N * 3);
+  for (int64_t i = 0; i < N; ++i) std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
+  std::vector<int32_t> conn((size_t)B * 2);
+  for (int64_t k = 0; k < 2 * B; ++k) conn[k] = c->iperm[m->beam_conn[k]];
+
+  PL_HIPC(c->xyz.alloc(N * 3));
+  PL_HIPC(c->conn.alloc(B * 2));
+  PL_HIPC(c->radius.alloc(B));
+  PL_HIPC(c->seg_len.alloc(B * 3));
+  PL_HIPC(c->seg_nsub.alloc(B * 3));
+  PL_HIPC(c->rec.alloc(B));
+  PL_HIPC(hipMemcpy(c->xyz.p, xyz.data(), xyz.size() * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->conn.p, conn.data(), conn.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->radius.p, m->beam_radius, B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->seg_len.p, m->seg_len, 3 * B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->seg_nsub.p, m->seg_nsub, 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_TRY(build_incidence(c, conn));
+  if (o->spmv_kernel == 3) {
+    int rc = pl::build_tile_plan(c->tile, conn, N, B);
+    if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed"));
+  }
+
+  const size_t n6 = (size_t)N * 6;
+  PL_HIPC(c->fixed.alloc(n6));
+  PL_HIPC(c->fixedbits.alloc(N));
+  PL_HIPC(c->ubar.alloc(n6));
+  PL_HIPC(c->f.alloc(n6));
+  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
+    PL_HIPC(v->alloc(n6));
+  PL_HIPC(c->scal.alloc(pl::S_COUNT));
+  PL_HIPC(hipMemset(c->fixed.p, 0, n6));
+  PL_HIPC(hipMemset(c->fixedbits.p, 0, N));
+  PL_HIPC(hipMemset(c->ubar.p, 0, n6 * sizeof(double)));
+  PL_HIPC(hipMemset(c->f.p, 0, n6 * sizeof(double)));
+  PL_HIPC(hipDeviceSynchronize());
+#undef PL_TRY
+#undef PL_HIPC
+  *out = c;
+  return PL_OK;
+}
+
+void pl_destroy(pl_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->opt.device);
+  (void)hipStreamSynchronize(h->stream);
+  pl::dist_destroy(h->dist);
+  delete h;
+}
+
+int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const double *f) {
+  if (!valid(h) || !fixed) return fail(PL_ERR_ARG, "pl_set_bc: null argument");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t N = h->N;
+  const size_t n6 = (size_t)N * 6;
+  std::vector<uint8_t> fx(n6), bits(N);
+  std::vector<double> ub(n6, 0.0), ff(n6, 0.0);
+  for (int64_t i = 0; i < N; ++i) {
+    const size_t src = 6 * (size_t)h->perm[i];
+    uint8_t b = 0;
+    for (int k = 0; k < 6; ++k) {
+      const uint8_t v = fixed[src + k] ? 1 : 0;
+      fx[6 * i + k] = v;
+      b |= (uint8_t)(v << k);
+      if (ubar && v) ub[6 * i + k] = ubar[src + k];
+      if (f) ff[6 * i + k] = f[src + k];
+    }
+    bits[i] = b;
+  }
+  PL_HIP(hipMemcpy(h->fixed.p, fx.data(), n6, hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->fixedbits.p, bits.data(), N, hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->ubar.p, ub.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
+  h->have_bc = true;
+  if (h->assembled) {   // the Jacobi inverse depends on the mask
+    int rc = launch_diag(h);
+    if (rc) return rc;
+    PL_HIP(hipStreamSynchronize(h->stream));
+  }
+  return PL_OK;
+}
+
+int pl_update_radii(pl_handle h, const double *beam_radius) {
+  if (!valid(h) || !beam_radius) return fail(PL_ERR_ARG, "pl_update_radii: null argument");
+  for (int64_t b = 0; b < h->B; ++b)
+    if (!(beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_update_radii: non-positive radius");
+  PL_HIP(hipSetDevice(h->opt.device));
+  PL_HIP(hipMemcpy(h->radius.p, beam_radius, h->B * sizeof(double), hipMemcpyHostToDevice));
+  h->assembled = false;
+  h->have_bsr = false;
+  return PL_OK;
+}
+
+int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_nsub) {
+  if (!valid(h) || !seg_len || !seg_nsub) return fail(PL_ERR_ARG, "pl_update_segments: null argument");
+  PL_HIP(hipSetDevice(h->opt.device));
+  PL_HIP(hipMemcpy(h->seg_len.p, seg_len, 3 * h->B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->seg_nsub.p, seg_nsub, 3 * h->B * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->assembled = false;
+  h->have_bsr = false;
+  return PL_OK;
+}
+
+int pl_assemble(pl_handle h) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble: null handle");
+  PL_HIP(hipSetDevice(h->opt.device));
+  PL_HIP(hipEventRecord(h->ev0, h->stream));
+  int rc = launch_records(h);
+  if (rc) return rc;
+  rc = launch_diag(h);
+  if (rc) return rc;
+  PL_HIP(hipEventRecord(h->ev1, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->ms_assembly = ms;
+  h->assembled = true;
+  return PL_OK;
+}
+
+int pl_assemble_bsr(pl_handle h, int with_bc, int64_t *n_block_rows, int64_t *n_blocks) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble_bsr: null handle");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_assemble_bsr: call pl_assemble first");
+  if (with_bc && !h->have_bc) return fail(PL_ERR_STATE, "pl_assemble_bsr: with_bc needs pl_set_bc");
+  PL_HIP(hipSetDevice(h->opt.device));
+  if (!h->bsr_vals.p) {
+    PL_HIP(h->bsr_rowptr.alloc(h->N + 1));
+    PL_HIP(h->bsr_col.alloc(h->nblk));
+    PL_HIP(h->bsr_vals.alloc((size_t)h->nblk * 36));
+    PL_HIP(hipMemcpy(h->bsr_rowptr.p, h->h_rowptr.data(), (h->N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    PL_HIP(hipMemcpy(h->bsr_col.p, h->h_col.data(), h->nblk * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  PL_HIP(hipEventRecord(h->ev0, h->stream));
+  int rc = launch_bsr_fill(h, with_bc);
+  if (rc) return rc;
+  PL_HIP(hipEventRecord(h->ev1, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->ms_assembly += ms;
+  h->have_bsr = true;
+  if (n_block_rows) *n_block_rows = h->N;
+  if (n_blocks) *n_blocks = h->nblk;
+  return PL_OK;
+}
+
+int pl_get_bsr(pl_handle h, int64_t *rowptr, int32_t *colidx, double *vals) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_get_bsr: null handle");
+  if (!h->have_bsr) return fail(PL_ERR_STATE, "pl_get_bsr: call pl_assemble_bsr first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  // returned in CALLER numbering: row i of the device matrix is caller node perm[i]
+  std::vector<double> v((size_t)h->nblk * 36);
+  PL_HIP(hipMemcpy(v.data(), h->bsr_vals.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (!h->reordered) {
+    if (rowptr) std::memcpy(rowptr, h->h_rowptr.data(), (h->N + 1) * sizeof(int64_t));
+    if (colidx) std::memcpy(colidx, h->h_col.data(), h->nblk * sizeof(int32_t));
+    if (vals) std::memcpy(vals, v.data(), v.size() * sizeof(double));
+    return PL_OK;
+  }
+  // permuted: rebuild rows in caller order, columns re-sorted
+  std::vector<int64_t> rp(h->N + 1, 0);
+  for (int64_t ci = 0; ci < h->N; ++ci) {
+    const int64_t di = h->iperm[ci];
+    rp[ci + 1] = rp[ci] + (h->h_rowptr[di + 1] - h->h_rowptr[di]);
+  }
+  if (rowptr) std::memcpy(rowptr, rp.data(), (h->N + 1) * sizeof(int64_t));
+  std::vector<std::pair<int32_t, int64_t>> row;
+  for (int64_t ci = 0; ci < h->N; ++ci) {
+    const int64_t di = h->iperm[ci];
+    row.clear();
+    for (int64_t p = h->h_rowptr[di]; p < h->h_rowptr[di + 1]; ++p) row.push_back({h->perm[h->h_col[p]], p});
+    std::stable_sort(row.begin(), row.end(), [](auto &l, auto &r) { return l.first < r.first; });
+    for (size_t k = 0; k < row.size(); ++k) {
+      if (colidx) colidx[rp[ci] + k] = row[k].first;
+      if (vals) std::memcpy(vals + 36 * (rp[ci] + k), &v[36 * row[k].second], 36 * sizeof(double));
+    }
+  }
+  return PL_OK;
+}
+
+static int spmv_common(pl_handle h, const double *x, double *y, bool masked, const char *who) {
+  if (!valid(h) || !x || !y) return fail(PL_ERR_ARG, std::string(who) + ": null argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, std::string(who) + ": call pl_assemble first");
+  if (masked && !h->have_bc) return fail(PL_ERR_STATE, std::string(who) + ": call pl_set_bc first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<double> stage;
+  int rc = upload6(h, x, h->tmp.p, stage);
+  if (rc) return rc;
+  if (masked) {
+    // enforce the contract "x is zero on fixed dofs" for arbitrary caller input
+    hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(h->N * 6)), dim3(pl::kBlock), 0, h->stream, h->N * 6,
+                       h->fixed.p, h->tmp.p, h->tmp.p, (double *)nullptr);
+  }
+  rc = launch_spmv(h, h->tmp.p, h->tmp2.p, masked, nullptr);
+  if (rc) return rc;
+  return download6(h, h->tmp2.p, y);
+}
+
+int pl_spmv(pl_handle h, const double *x, double *y) { return spmv_common(h, x, y, false, "pl_spmv"); }
+int pl_spmv_free(pl_handle h, const double *x, double *y) { return spmv_common(h, x, y, true, "pl_spmv_free"); }
+
+int pl_spmv_bsr(pl_handle h, const double *x, double *y) {
+  if (!valid(h) || !x || !y) return fail(PL_ERR_ARG, "pl_spmv_bsr: null argument");
+  if (!h->have_bsr) return fail(PL_ERR_STATE, "pl_spmv_bsr: call pl_assemble_bsr first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<double> stage;
+  int rc = upload6(h, x, h->tmp.p, stage);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pl::k_bsr_spmv, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N, h->bsr_rowptr.p,
+                     h->bsr_col.p, h->bsr_vals.p, h->tmp.p, h->tmp2.p);
+  PL_HIP(hipGetLastError());
+  return download6(h, h->tmp2.p, y);
+}
+
+int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *stats) {
+  if (!valid(h) || !u) return fail(PL_ERR_ARG, "pl_solve: null argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_solve: call pl_assemble first");
+  if (!h->have_bc) return fail(PL_ERR_STATE, "pl_solve: call pl_set_bc first");
+  if (!(rtol > 0.0) || max_iter <= 0) return fail(PL_ERR_ARG, "pl_solve: rtol and max_iter must be positive");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t n6 = h->N * 6;
+  pl_stats_t st{};
+  PL_HIP(hipEventRecord(h->ev0, h->stream));
+  // lifting: tmp = K ubar (ubar is zero on free dofs)
+  int rc = launch_spmv(h, h->ubar.p, h->tmp.p, false, nullptr);
+  if (rc) return rc;
+  rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,
+                     h->ubar.p, h->x.p, h->tmp2.p);
+  PL_HIP(hipEventRecord(h->ev1, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  st.ms_solve = ms;
+  st.ms_assembly = h->ms_assembly;
+  rc = download6(h, h->tmp2.p, u);
+  if (rc) return rc;
+  h->last = st;
+  if (stats) *stats = st;
+  if (!st.converged) return fail(PL_ERR_NOCONV, "pl_solve: PCG did not reach rtol within max_iter");
+  return PL_OK;
+}
+
+int pl_reactions(pl_handle h, const double *u, double *R) { return spmv_common(h, u, R, false, "pl_reactions"); }
+
+int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
+  if (!valid(h) || !u || !dCdr) return fail(PL_ERR_ARG, "pl_sens: null argument");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<double> stage;
+  int rc = upload6(h, u, h->tmp.p, stage);
+  if (rc) return rc;
+  const double *lam_dev = h->tmp.p;
+  if (lam) {
+    rc = upload6(h, lam, h->tmp2.p, stage);
+    if (rc) return rc;
+    lam_dev = h->tmp2.p;
+  }
+  DevBuf<double> out;
+  PL_HIP(out.alloc(h->B));
+  hipLaunchKernelGGL(pl::k_sens, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
+                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mat, h->tmp.p, lam_dev, out.p);
+  PL_HIP(hipGetLastError());
+  PL_HIP(hipMemcpyAsync(dCdr, out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  return PL_OK;
+}
+
+int pl_energy(pl_handle h, const double *u, double *energy) {
+  if (!valid(h) || !u || !energy) return fail(PL_ERR_ARG, "pl_energy: null argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_energy: call pl_assemble first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<double> stage;
+  int rc = upload6(h, u, h->tmp.p, stage);
+  if (rc) return rc;
+  PL_HIP(hipMemsetAsync(h->scal.p + 7, 0, sizeof(double), h->stream));
+  hipLaunchKernelGGL(pl::k_energy, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->conn.p, h->rec.p,
+                     h->tmp.p, h->scal.p + 7);
+  PL_HIP(hipGetLastError());
+  PL_HIP(hipMemcpyAsync(energy, h->scal.p + 7, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  return PL_OK;
+}
+
+int pl_schur(pl_handle h, const int32_t *boundary_nodes, int32_t nb, double rtol, int32_t max_iter, double *S) {
+  if (!valid(h) || !boundary_nodes || !S || nb <= 0) return fail(PL_ERR_ARG, "pl_schur: bad argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_schur: call pl_assemble first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t N = h->N;
+  const size_t n6 = (size_t)N * 6;
+  for (int i = 0; i < nb; ++i)
+    if (boundary_nodes[i] < 0 || boundary_nodes[i] >= N) return fail(PL_ERR_ARG, "pl_schur: node index out of range");
+  // Column j of S = reaction on the boundary dofs when boundary dof j = 1, the other boundary dofs = 0 and the
+  // interior is in equilibrium: exactly S = K_BB - K_BI K_II^-1 K_IB.
+  std::vector<uint8_t> fixed(n6, 0);
+  for (int i = 0; i < nb; ++i)
+    for (int k = 0; k < 6; ++k) fixed[6 * (size_t)boundary_nodes[i] + k] = 1;
+  std::vector<double> ubar(n6, 0.0), u(n6), R(n6);
+  const int m = nb * 6;
+  for (int j = 0; j < m; ++j) {
+    const size_t dofj = 6 * (size_t)boundary_nodes[j / 6] + (j % 6);
+    ubar[dofj] = 1.0;
+    int rc = pl_set_bc(h, fixed.data(), ubar.data(), nullptr);
+    if (rc) return rc;
+    pl_stats_t st;
+    rc = pl_solve(h, rtol, max_iter, u.data(), &st);
+    if (rc) return rc;
+    rc = pl_reactions(h, u.data(), R.data());
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) S[(size_t)i * m + j] = R[6 * (size_t)boundary_nodes[i / 6] + (i % 6)];
+    ubar[dofj] = 0.0;
+  }
+  return PL_OK;
+}
+
+int pl_get_records(pl_handle h, double *rec) {
+  if (!valid(h) || !rec) return fail(PL_ERR_ARG, "pl_get_records: null argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_get_records: call pl_assemble first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  PL_HIP(hipMemcpy(rec, h->rec.p, h->B * sizeof(pl::Record), hipMemcpyDeviceToHost));
+  return PL_OK;
+}
+
+int pl_algorithmic_bytes(pl_handle h, double *out3) {
+  if (!valid(h) || !out3) return fail(PL_ERR_ARG, "pl_algorithmic_bytes: null argument");
+  const double w = 8.0, B = (double)h->B, N = (double)h->N;
+  out3[0] = B * (8.0 + 8.0 * w) + N * 6.0 * w * 2.0;        // bytes_spmv
+  out3[1] = out3[0] + 10.0 * (6.0 * N * w);                 //                 bytes_pcg_iter
+  out3[2] = B * (8.0 + 8.0 * w) + (N + 2.0 * B) * (36.0 * w + 4.0);   //      bytes_assembly_bsr
+  return PL_OK;
+}
+
+int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
+  if (!valid(h) || !avg_ms || reps <= 0) return fail(PL_ERR_ARG, "pl_time_kernel: bad argument");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_assemble first");
+  if ((which == 0 || which == 3) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
+  if ((which == 2 || which == 4) && !h->have_bsr) return fail(PL_ERR_STATE, "pl_time_kernel: needs pl_assemble_bsr");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t n6 = h->N * 6;
+  int rc = ensure_hist(h, reps + 1);
+  if (rc) return rc;
+  // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
+  PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  auto one = [&](int k) -> int {
+    switch (which) {
+      case 0: return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP);
+      case 1: return launch_records(h);
+      case 2: return launch_bsr_fill(h, 0);
+      case 3: return pcg_iteration(h, k);
+      case 4:
+        hipLaunchKernelGGL(pl::k_bsr_spmv, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N,
+                           h->bsr_rowptr.p, h->bsr_col.p, h->bsr_vals.p, h->p.p, h->Ap.p);
+        return PL_OK;
+      default: return fail(PL_ERR_ARG, "pl_time_kernel: unknown kernel id");
+    }
+  };
+  for (int k = 0; k < 3; ++k) {   // warm-up
+    rc = one(0);
+    if (rc) return rc;
+  }
+  PL_HIP(hipEventRecord(h->ev0, h->stream));
+  for (int k = 0; k < reps; ++k) {
+    rc = one(k);
+    if (rc) return rc;
+  }
+  PL_HIP(hipEventRecord(h->ev1, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = (double)ms / reps;
+  return PL_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------
+int pl_dist_unique_id_bytes(void) { return pl::dist_unique_id_bytes(); }
+int pl_dist_unique_id(void *id_out) {
+  if (!id_out) return fail(PL_ERR_ARG, "pl_dist_unique_id: null argument");
+  return pl::dist_unique_id(id_out) ? fail(PL_ERR_HIP, "ncclGetUniqueId failed") : PL_OK;
+}
+int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const int32_t *shared_local,
+                 const int32_t *shared_global, int32_t n_shared, int32_t n_shared_global) {
+  if (!valid(h) || !unique_id || world < 1 || rank < 0 || rank >= world || n_shared < 0)
+    return fail(PL_ERR_ARG, "pl_dist_init: bad argument");
+  if (n_shared > 0 && (!shared_local || !shared_global)) return fail(PL_ERR_ARG, "pl_dist_init: null index array");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<int32_t> loc(n_shared);
+  for (int i = 0; i < n_shared; ++i) {
+    if (shared_local[i] < 0 || shared_local[i] >= h->N || shared_global[i] < 0 || shared_global[i] >= n_shared_global)
+      return fail(PL_ERR_ARG, "pl_dist_init: shared node index out of range");
+    loc[i] = h->iperm[shared_local[i]];
+  }
+  int rc = pl::dist_init(h->dist, rank, world, unique_id, loc.data(), shared_global, n_shared, n_shared_global, h->N,
+                         h->stream);
+  if (rc) return fail(PL_ERR_HIP, "pl_dist_init: RCCL communicator setup failed (" + std::to_string(rc) + ")");
+  h->assembled = false;
+  return PL_OK;
+}
+
+}  // extern "C"

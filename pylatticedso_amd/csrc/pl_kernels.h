@@ -1,0 +1,443 @@
+// HIP kernels of libpylattice_hip (gfx950 / MI355X only; wave = 64).
+#pragma once
+#include "pl_device.h"
+
+namespace pl {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+// blockIdx -> logical block so that each of the 8 XCDs (blocks are dealt round-robin, b and b+8 share an XCD and
+// its private 4 MiB L2) walks one CONTIGUOUS eighth of the node/strut range: struts and their end nodes are then
+// served from one L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblk) {
+  const unsigned xcd = b & 7u, q = nblk >> 3, r = nblk & 7u;
+  const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum over the block, result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *smem /*[kBlock/kWave]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kBlock / kWave; ++i) t += smem[i];
+  }
+  return t;
+}
+
+__device__ __forceinline__ void load6(const double *__restrict__ p, V3 &u, V3 &t) {
+  const double2 *q = reinterpret_cast<const double2 *>(p);
+  const double2 a = q[0], b = q[1], c = q[2];
+  u = {a.x, a.y, b.x};
+  t = {b.y, c.x, c.y};
+}
+
+__device__ __forceinline__ Record load_record(const Record *__restrict__ rec, int64_t i) {
+  const double2 *q = reinterpret_cast<const double2 *>(rec + i);
+  const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+  Record r;
+  r.a = a.x; r.c = a.y; r.e1 = b.x; r.e2 = b.y; r.e3 = c.x; r.dx = c.y; r.dy = d.x; r.dz = d.y;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Record build: one thread per strut ("local stiffness build").
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_build_records(int64_t B, const double *__restrict__ xyz,
+                                                          const int32_t *__restrict__ conn,
+                                                          const double *__restrict__ radius,
+                                                          const double *__restrict__ seg_len,
+                                                          const int32_t *__restrict__ seg_nsub, Material m,
+                                                          Record *__restrict__ rec) {
+  const int64_t b = (int64_t)xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  const V3 d = {xyz[3 * (int64_t)ib] - xyz[3 * (int64_t)ia], xyz[3 * (int64_t)ib + 1] - xyz[3 * (int64_t)ia + 1],
+                xyz[3 * (int64_t)ib + 2] - xyz[3 * (int64_t)ia + 2]};
+  const double len[3] = {seg_len[3 * b], seg_len[3 * b + 1], seg_len[3 * b + 2]};
+  const int ns[3] = {seg_nsub[3 * b], seg_nsub[3 * b + 1], seg_nsub[3 * b + 2]};
+  const Flex f = strut_flexibility(radius[b], len, ns, m);
+  rec[b] = make_record(scalars_from_flex(f), d);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K*x, variant 1: one thread per strut, scatter with f64 global atomics (y must be zeroed).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_spmv_atomic(int64_t B, const int32_t *__restrict__ conn,
+                                                        const Record *__restrict__ rec, const double *__restrict__ x,
+                                                        double *__restrict__ y) {
+  const int64_t b = (int64_t)xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+  const Record r = load_record(rec, b);
+  V3 uA, tA, uB, tB, F, M;
+  load6(x + 6 * ia, uA, tA);
+  load6(x + 6 * ib, uB, tB);
+  tip_force(r, uA, tA, uB, tB, F, M);
+  const V3 d = {r.dx, r.dy, r.dz};
+  const V3 MA = (-1.0) * M - cross(d, F);
+  double *ya = y + 6 * ia, *yb = y + 6 * ib;
+  unsafeAtomicAdd(yb + 0, F.x); unsafeAtomicAdd(yb + 1, F.y); unsafeAtomicAdd(yb + 2, F.z);
+  unsafeAtomicAdd(yb + 3, M.x); unsafeAtomicAdd(yb + 4, M.y); unsafeAtomicAdd(yb + 5, M.z);
+  unsafeAtomicAdd(ya + 0, -F.x); unsafeAtomicAdd(ya + 1, -F.y); unsafeAtomicAdd(ya + 2, -F.z);
+  unsafeAtomicAdd(ya + 3, MA.x); unsafeAtomicAdd(ya + 4, MA.y); unsafeAtomicAdd(ya + 5, MA.z);
+}
+
+// y = mask .* y (atomic variant post-pass), optionally accumulating dot(x, y).
+__global__ __launch_bounds__(kBlock) void k_mask_dot(int64_t n6, const uint8_t *__restrict__ fixed,
+                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                     double *__restrict__ dot_out) {
+  __shared__ double red[kBlock / kWave];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * kBlock) {
+    double v = y[i];
+    if (fixed && fixed[i]) { v = 0.0; y[i] = 0.0; }
+    acc += x[i] * v;
+  }
+  if (dot_out) {
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K*x, variant 2: one thread per node, gather over the incident struts (sliced ELL, slice = 64 nodes = one wave).
+// No atomics, bitwise reproducible.  ent[slice_ptr[s] + j*64 + lane] = (other node, strut | end<<31); other < 0 = pad.
+// fixedbits[node] holds the 6 Dirichlet flags; MASK=true gives y = P K x (x is assumed to be 0 on fixed dofs).
+// ---------------------------------------------------------------------------------------------------------
+template <bool MASK, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_gather(int64_t N, const int64_t *__restrict__ slice_ptr,
+                                                        const int2 *__restrict__ ent, const Record *__restrict__ rec,
+                                                        const uint8_t *__restrict__ fixedbits,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        double *__restrict__ dot_out) {
+  __shared__ double red[kBlock / kWave];
+  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
+  const int64_t i = (int64_t)blk * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t slice = i >> 6;
+  double acc = 0.0;
+  if (i < N) {
+    V3 us, ts;
+    load6(x + 6 * i, us, ts);
+    V3 F = {0, 0, 0}, M = {0, 0, 0};
+    const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+      const int2 e = ent[p];
+      if (e.x >= 0) {
+        Record r = load_record(rec, e.y & 0x7fffffff);
+        if (e.y < 0) r = reversed(r);   // this node is the strut's point1
+        V3 uo, to, f, m;
+        load6(x + 6 * (int64_t)e.x, uo, to);
+        tip_force(r, uo, to, us, ts, f, m);
+        F = F + f;
+        M = M + m;
+      }
+    }
+    double out[6] = {F.x, F.y, F.z, M.x, M.y, M.z};
+    if (MASK) {
+      const unsigned fb = fixedbits[i];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (fb & (1u << k)) out[k] = 0.0;
+    }
+    double2 *q = reinterpret_cast<double2 *>(y + 6 * i);
+    q[0] = {out[0], out[1]};
+    q[1] = {out[2], out[3]};
+    q[2] = {out[4], out[5]};
+    if (DOT) acc = us.x * out[0] + us.y * out[1] + us.z * out[2] + ts.x * out[3] + ts.y * out[4] + ts.z * out[5];
+  }
+  if (DOT) {
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out, t);
+  }
+}
+
+// Jacobi diagonal (and its inverse on free dofs) by the same gather.  dinv = 1/diag on free dofs, 0 on fixed.
+__global__ __launch_bounds__(kBlock) void k_diag_gather(int64_t N, const int64_t *__restrict__ slice_ptr,
+                                                        const int2 *__restrict__ ent, const Record *__restrict__ rec,
+                                                        const uint8_t *__restrict__ fixedbits,
+                                                        double *__restrict__ diag, double *__restrict__ dinv) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t slice = i >> 6;
+  double dg[6] = {0, 0, 0, 0, 0, 0};
+  const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+  for (int64_t p = p0 + lane; p < p1; p += 64) {
+    const int2 e = ent[p];
+    if (e.x >= 0) {
+      Record r = load_record(rec, e.y & 0x7fffffff);
+      if (e.y < 0) r = reversed(r);
+      double t[6];
+      tip_diag(r, t);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dg[k] += t[k];
+    }
+  }
+  const unsigned fb = fixedbits ? fixedbits[i] : 0u;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    diag[6 * i + k] = dg[k];
+    if (dinv) dinv[6 * i + k] = ((fb >> k) & 1u) || dg[k] == 0.0 ? 0.0 : 1.0 / dg[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BSR(6x6) numeric fill: one thread per block row.  Row i holds [diag block] + one block per incident strut,
+// in the order given by blk_of_entry (columns sorted at setup).  with_bc: dolfinx Dirichlet treatment.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *__restrict__ slice_ptr,
+                                                     const int2 *__restrict__ ent, const Record *__restrict__ rec,
+                                                     const int64_t *__restrict__ rowptr,
+                                                     const int32_t *__restrict__ ent_slot,
+                                                     const int32_t *__restrict__ diag_slot,
+                                                     const uint8_t *__restrict__ fixedbits, int with_bc,
+                                                     double *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t slice = i >> 6;
+  double Kd[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Kd[k] = 0.0;
+  const unsigned fi = (with_bc && fixedbits) ? fixedbits[i] : 0u;
+  const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+  const int64_t row0 = rowptr[i];
+  for (int64_t p = p0 + lane; p < p1; p += 64) {
+    const int2 e = ent[p];
+    if (e.x >= 0) {
+      Record r = load_record(rec, e.y & 0x7fffffff);
+      if (e.y < 0) r = reversed(r);
+      double Kss[36], Kso[36];
+      tip_blocks(r, Kss, Kso);
+      const unsigned fo = (with_bc && fixedbits) ? fixedbits[e.x] : 0u;
+      double *dst = vals + 36 * (row0 + ent_slot[p]);
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          Kd[a * 6 + b] += Kss[a * 6 + b];
+          const bool z = ((fi >> a) & 1u) || ((fo >> b) & 1u);
+          dst[a * 6 + b] = z ? 0.0 : Kso[a * 6 + b];
+        }
+    }
+  }
+  double *dd = vals + 36 * (row0 + diag_slot[i]);
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const bool fa = (fi >> a) & 1u, fb = (fi >> b) & 1u;
+      dd[a * 6 + b] = (fa || fb) ? ((a == b) ? 1.0 : 0.0) : Kd[a * 6 + b];
+    }
+}
+
+// y = A x for the assembled BSR matrix: one thread per block row (cross-check path).
+__global__ __launch_bounds__(kBlock) void k_bsr_spmv(int64_t N, const int64_t *__restrict__ rowptr,
+                                                     const int32_t *__restrict__ colidx,
+                                                     const double *__restrict__ vals, const double *__restrict__ x,
+                                                     double *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+    const double *xv = x + 6 * (int64_t)colidx[p];
+    const double *A = vals + 36 * p;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[a] += A[a * 6 + b] * xv[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) y[6 * i + a] = acc[a];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PCG vector kernels.  scal[] lives on the device: 0 rz_old, 1 pAp, 2 rz_new, 3 rr, 4 bb.
+// ---------------------------------------------------------------------------------------------------------
+enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_COUNT = 8 };
+
+// x += alpha p ; r -= alpha Ap ; z = dinv r ; rz_new += r.z ; rr += r.r      (alpha = rz_old / pAp)
+__global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double *__restrict__ p,
+                                                       const double *__restrict__ Ap,
+                                                       const double *__restrict__ dinv, double *__restrict__ x,
+                                                       double *__restrict__ r, double *__restrict__ z,
+                                                       double *__restrict__ scal) {
+  __shared__ double red[2][kBlock / kWave];
+  const double pap = scal[S_PAP];
+  const double alpha = (pap != 0.0) ? scal[S_RZ_OLD] / pap : 0.0;
+  double rz = 0.0, rr = 0.0;
+  const int64_t n2 = n6 >> 1;   // n6 is even (6 per node)
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+    const double2 av = reinterpret_cast<const double2 *>(Ap)[i];
+    const double2 dv = reinterpret_cast<const double2 *>(dinv)[i];
+    double2 xv = reinterpret_cast<double2 *>(x)[i];
+    double2 rv = reinterpret_cast<double2 *>(r)[i];
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * av.x; rv.y -= alpha * av.y;
+    const double2 zv = {dv.x * rv.x, dv.y * rv.y};
+    reinterpret_cast<double2 *>(x)[i] = xv;
+    reinterpret_cast<double2 *>(r)[i] = rv;
+    reinterpret_cast<double2 *>(z)[i] = zv;
+    rz += rv.x * zv.x + rv.y * zv.y;
+    rr += rv.x * rv.x + rv.y * rv.y;
+  }
+  rz = wave_sum(rz);
+  rr = wave_sum(rr);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = rz; red[1][w] = rr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
+    unsafeAtomicAdd(scal + S_RZ_NEW, a);
+    unsafeAtomicAdd(scal + S_RR, b);
+  }
+}
+
+// p = z + beta p   (beta = rz_new / rz_old)
+__global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const double *__restrict__ z,
+                                                          double *__restrict__ p, const double *__restrict__ scal) {
+  const double old = scal[S_RZ_OLD];
+  const double beta = (old != 0.0) ? scal[S_RZ_NEW] / old : 0.0;
+  const int64_t n2 = n6 >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    const double2 zv = reinterpret_cast<const double2 *>(z)[i];
+    double2 pv = reinterpret_cast<double2 *>(p)[i];
+    pv.x = zv.x + beta * pv.x;
+    pv.y = zv.y + beta * pv.y;
+    reinterpret_cast<double2 *>(p)[i] = pv;
+  }
+}
+
+// End of iteration k: record ||r||^2, rotate the scalars.
+__global__ void k_pcg_rotate(double *__restrict__ scal, double *__restrict__ hist, int k) {
+  hist[k] = scal[S_RR];
+  scal[S_RZ_OLD] = scal[S_RZ_NEW];
+  scal[S_RZ_NEW] = 0.0;
+  scal[S_RR] = 0.0;
+  scal[S_PAP] = 0.0;
+}
+
+// r = mask.*(f - y) ; z = dinv r ; p = z ; x = 0 ; rz_old = r.z ; bb = r.r
+__global__ __launch_bounds__(kBlock) void k_pcg_init(int64_t n6, const double *__restrict__ f,
+                                                     const double *__restrict__ Kubar,
+                                                     const uint8_t *__restrict__ fixed,
+                                                     const double *__restrict__ dinv, double *__restrict__ x,
+                                                     double *__restrict__ r, double *__restrict__ z,
+                                                     double *__restrict__ p, double *__restrict__ scal) {
+  __shared__ double red[2][kBlock / kWave];
+  double rz = 0.0, rr = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * kBlock) {
+    const double rv = fixed[i] ? 0.0 : (f[i] - Kubar[i]);
+    const double zv = dinv[i] * rv;
+    x[i] = 0.0;
+    r[i] = rv;
+    z[i] = zv;
+    p[i] = zv;
+    rz += rv * zv;
+    rr += rv * rv;
+  }
+  rz = wave_sum(rz);
+  rr = wave_sum(rr);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = rz; red[1][w] = rr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
+    unsafeAtomicAdd(scal + S_RZ_OLD, a);
+    unsafeAtomicAdd(scal + S_BB, b);
+  }
+}
+
+// u = fixed ? ubar : x
+__global__ __launch_bounds__(kBlock) void k_compose_solution(int64_t n6, const uint8_t *__restrict__ fixed,
+                                                             const double *__restrict__ ubar,
+                                                             const double *__restrict__ x, double *__restrict__ u) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * kBlock)
+    u[i] = fixed[i] ? ubar[i] : x[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-strut sensitivity s_b = lam_e^T (dK_e/dr) u_e and strain energy (one thread per strut, no scatter).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sens(int64_t B, const double *__restrict__ xyz,
+                                                 const int32_t *__restrict__ conn, const double *__restrict__ radius,
+                                                 const double *__restrict__ seg_len,
+                                                 const int32_t *__restrict__ seg_nsub, Material m,
+                                                 const double *__restrict__ u, const double *__restrict__ lam,
+                                                 double *__restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+  const V3 d = {xyz[3 * ib] - xyz[3 * ia], xyz[3 * ib + 1] - xyz[3 * ia + 1], xyz[3 * ib + 2] - xyz[3 * ia + 2]};
+  const double len[3] = {seg_len[3 * b], seg_len[3 * b + 1], seg_len[3 * b + 2]};
+  const int ns[3] = {seg_nsub[3 * b], seg_nsub[3 * b + 1], seg_nsub[3 * b + 2]};
+  const double r = radius[b];
+  const Flex f = strut_flexibility(r, len, ns, m);
+  const Record dr = make_record(dscalars_dr(f, r), d);
+  V3 uA, tA, uB, tB, F, M;
+  load6(u + 6 * ia, uA, tA);
+  load6(u + 6 * ib, uB, tB);
+  tip_force(dr, uA, tA, uB, tB, F, M);
+  // energy-conjugate pairing: lam_e . (dK u)_e = F.(dlu) + M.(dlth) with the SAME relative deformations of lam
+  V3 lA, mA, lB, mB;
+  load6(lam + 6 * ia, lA, mA);
+  load6(lam + 6 * ib, lB, mB);
+  const V3 dlu = lB - lA + cross(d, mA);
+  const V3 dlt = mB - mA;
+  out[b] = dot(F, dlu) + dot(M, dlt);
+}
+
+// partial strain energies 1/2 e^T K e per strut, block-reduced and atomically added.
+__global__ __launch_bounds__(kBlock) void k_energy(int64_t B, const int32_t *__restrict__ conn,
+                                                   const Record *__restrict__ rec, const double *__restrict__ u,
+                                                   double *__restrict__ out) {
+  __shared__ double red[kBlock / kWave];
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  double e = 0.0;
+  if (b < B) {
+    const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+    const Record r = load_record(rec, b);
+    V3 uA, tA, uB, tB, F, M;
+    load6(u + 6 * ia, uA, tA);
+    load6(u + 6 * ib, uB, tB);
+    tip_force(r, uA, tA, uB, tB, F, M);
+    const V3 d = {r.dx, r.dy, r.dz};
+    e = 0.5 * (dot(F, uB - uA + cross(d, tA)) + dot(M, tB - tA));
+  }
+  const double t = block_sum(e, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, t);
+}
+
+// gather / scatter helpers for the node permutation and interface packing
+__global__ void k_gather6(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ src,
+                          double *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 6) return;
+  const int64_t node = i / 6, k = i - node * 6;
+  dst[i] = src[6 * (int64_t)idx[node] + k];
+}
+__global__ void k_scatter6(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ src,
+                           double *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 6) return;
+  const int64_t node = i / 6, k = i - node * 6;
+  dst[6 * (int64_t)idx[node] + k] = src[i];
+}
+
+}  // namespace pl

@@ -1,0 +1,382 @@
+"""Array-backed (SoA) construction of the lattice the hot path consumes.
+
+This is the host-side restatement of what the reference builds as a Python object graph:
+
+* ``generate``      <- Lattice.generate_lattice (lattice.py:421-483) + Cell.generate_beams (cell.py:293-382)
+                       + Lattice.define_beam_node_index (lattice.py:665-698)
+* ``gradient_table``<- gradient_properties.get_grad_settings (gradient_properties.py:44-137)
+* ``compute_lzone`` <- define_connected_beams_for_all_nodes / define_angles_between_beams (lattice.py:805-904),
+                       Beam.get_angle_between_beams (beam.py:204-277), function_penalization_Lzone (utils.py:432-453)
+* ``penalize``      <- LatticeSim.set_penalized_beams (lattice_sim.py:245-308) + Beam.get_point_on_beam_at_distance
+                       (beam.py:279-326) + gmsh subdivision of every segment (lattice_generation.py:50-101)
+
+Everything is numpy; nothing here does stiffness arithmetic (that lives in the HIP library).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .geometries import get_beam_structure
+
+PENALIZATION_COEFFICIENT = 1.5   # lattice_sim.py:112, beam.py:71
+MESH_ELEMENT_LENGTH = 0.05       # lattice_generation.py:50 (fraction of cell_size_x)
+
+
+def gradient_table(ncx, ncy, ncz, rule, direction, parameters):
+    """Rows [fx, fy, fz] for cell index 0..max(n)-1 (gradient_properties.py:44-137)."""
+    n = [ncx, ncy, ncz]
+
+    def factor(i, total, p):
+        mid = total / 2
+        if rule == "constant":
+            return 1.0
+        if rule == "linear":
+            return 1.0 + i * p
+        if rule == "parabolic":
+            return 1.0 + (i / mid) * p if i < mid else 1.0 + ((total - i - 1) / mid) * p
+        if rule == "sinusoide":
+            return 1.0 + p * math.sin((i / total) * math.pi)
+        if rule == "exponential":
+            return 1.0 + math.exp(i * p)
+        raise ValueError(f"Unknown gradient rule: {rule}")
+
+    idx = [0, 0, 0]
+    rows = []
+    for _ in range(max(n)):
+        rows.append([factor(idx[d], n[d], parameters[d]) if direction[d] == 1 else 1.0 for d in range(3)])
+        for d in range(3):
+            if direction[d] == 1 and idx[d] < n[d] - 1:
+                idx[d] += 1
+    return np.asarray(rows, dtype=np.float64)
+
+
+@dataclass
+class LatticeArrays:
+    """Design lattice (before joint penalisation)."""
+    node_xyz: np.ndarray            # (N,3) f64, sorted by (x,y,z)  -> node index
+    beam_conn: np.ndarray           # (B,2) i32, point1 -> point2 as first created
+    beam_radius: np.ndarray         # (B,)  f64
+    beam_type: np.ndarray           # (B,)  i32 geometry index
+    beam_cell0: np.ndarray          # (B,)  i32 primary cell (cell_belongings[0])
+    cell_pos: np.ndarray            # (C,3) i32
+    cell_coord: np.ndarray          # (C,3) f64 min corner
+    cell_size: np.ndarray           # (C,3) f64
+    cell_radii: np.ndarray          # (C,G) f64 radius per geometry (after gradient)
+    cell_beam_ptr: np.ndarray       # (C+1,) CSR cell -> beams
+    cell_beam_idx: np.ndarray
+    cell_node_ptr: np.ndarray       # (C+1,) CSR cell -> nodes
+    cell_node_idx: np.ndarray
+    bbox: np.ndarray                # (6,) xmin,xmax,ymin,ymax,zmin,zmax
+    cell_size_nominal: tuple = (1.0, 1.0, 1.0)
+    extras: dict = field(default_factory=dict)
+
+    @property
+    def n_nodes(self):
+        return len(self.node_xyz)
+
+    @property
+    def n_beams(self):
+        return len(self.beam_conn)
+
+    @property
+    def n_cells(self):
+        return len(self.cell_pos)
+
+
+def _csr_from_pairs(rows, cols, nrows):
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    keep = np.ones(len(rows), bool)
+    keep[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+    rows, cols = rows[keep], cols[keep]
+    ptr = np.zeros(nrows + 1, np.int64)
+    np.add.at(ptr, rows + 1, 1)
+    return np.cumsum(ptr), cols.astype(np.int64)
+
+
+def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim=None, erased_blocks=None,
+             cell_radii_override=None) -> LatticeArrays:
+    """Vectorised Lattice.generate_lattice: cells in i,j,k order, struts of every geometry, nodes and struts
+    de-duplicated through coordinates rounded to 9 decimals (first creator wins, cell.py:312-368)."""
+    nx, ny, nz = num_cells
+    csx, csy, csz = cell_size
+    if grad_dim is None:
+        grad_dim = np.ones((max(nx, ny, nz), 3))
+    if grad_radius is None:
+        grad_radius = np.ones((max(nx, ny, nz), 3))
+
+    def starts(n, cs, ax):
+        s = np.zeros(n)
+        for i in range(1, n):
+            s[i] = s[i - 1] + cs * grad_dim[i - 1][ax]
+        return s
+
+    xs, ys, zs = starts(nx, csx, 0), starts(ny, csy, 1), starts(nz, csz, 2)
+    I, J, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    pos = np.stack([I.ravel(), J.ravel(), K.ravel()], axis=1).astype(np.int32)
+    coord = np.stack([xs[pos[:, 0]], ys[pos[:, 1]], zs[pos[:, 2]]], axis=1)
+    if erased_blocks:
+        keep = np.ones(len(pos), bool)
+        for blk in erased_blocks:
+            inside = np.ones(len(pos), bool)
+            for d in range(3):
+                inside &= (blk[d] <= coord[:, d]) & (coord[:, d] <= blk[d] + blk[d + 3])
+            keep &= ~inside
+        pos, coord = pos[keep], coord[keep]
+    C = len(pos)
+    size = np.stack([csx * grad_dim[pos[:, 0], 0], csy * grad_dim[pos[:, 1], 1], csz * grad_dim[pos[:, 2], 2]], axis=1)
+    gfac = grad_radius[pos[:, 0], 0] * grad_radius[pos[:, 1], 1] * grad_radius[pos[:, 2], 2]
+    radii = np.asarray(radii, dtype=np.float64)
+    cell_radii = radii[None, :] * gfac[:, None]
+    if cell_radii_override is not None:
+        cell_radii = np.asarray(cell_radii_override, dtype=np.float64).reshape(C, len(radii))
+
+    # template of one cell: all geometries with radius > 0, in geom order (cell.py:272-288)
+    tmpl, ttype = [], []
+    for g, (name, r) in enumerate(zip(geom_types, radii)):
+        if r > 0.0:
+            fr = get_beam_structure(name)
+            tmpl.append(fr)
+            ttype.append(np.full(len(fr), g, np.int32))
+    tmpl = np.concatenate(tmpl)
+    ttype = np.concatenate(ttype)
+    nb = len(tmpl)
+
+    # end points of every (cell, template strut): frac*size + coordinate  (cell.py:300-305)
+    P1 = tmpl[None, :, 0:3] * size[:, None, :] + coord[:, None, :]
+    P2 = tmpl[None, :, 3:6] * size[:, None, :] + coord[:, None, :]
+    pts = np.stack([P1, P2], axis=2).reshape(-1, 3)             # creation order: cell, strut, end
+    key = np.round(pts, 9) + 0.0                                 # +0.0 folds -0.0
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.ravel()
+    xyz_first = pts[first]
+    order = np.lexsort((xyz_first[:, 2], xyz_first[:, 1], xyz_first[:, 0]))   # node index = sort by (x,y,z)
+    rank = np.empty(len(order), np.int64)
+    rank[order] = np.arange(len(order))
+    node_xyz = xyz_first[order]
+    pid = rank[inv].reshape(C, nb, 2)
+
+    N = len(node_xyz)
+    lo = np.minimum(pid[..., 0], pid[..., 1]).ravel()
+    hi = np.maximum(pid[..., 0], pid[..., 1]).ravel()
+    bkey = lo * N + hi
+    _, bfirst, binv = np.unique(bkey, return_index=True, return_inverse=True)
+    binv = binv.ravel()
+    conn_u = pid.reshape(-1, 2)[bfirst]
+    cell_of = np.repeat(np.arange(C), nb)
+    t_of = np.tile(ttype, C)
+    rad_u = cell_radii[cell_of[bfirst], t_of[bfirst]]
+    typ_u = t_of[bfirst]
+    cell0_u = cell_of[bfirst]
+    # beam index = sort by (min point, max point, radius)  (lattice.py:675-685); min point == lower node index
+    border = np.lexsort((rad_u, np.maximum(conn_u[:, 0], conn_u[:, 1]), np.minimum(conn_u[:, 0], conn_u[:, 1])))
+    brank = np.empty(len(border), np.int64)
+    brank[border] = np.arange(len(border))
+    beam_conn = conn_u[border].astype(np.int32)
+    bid = brank[binv]                                           # (C*nb,) beam index of each created strut
+
+    cb_ptr, cb_idx = _csr_from_pairs(cell_of, bid, C)
+    cn_ptr, cn_idx = _csr_from_pairs(np.repeat(np.arange(C), nb * 2), pid.ravel(), C)
+    bbox = np.array([node_xyz[:, 0].min(), node_xyz[:, 0].max(), node_xyz[:, 1].min(), node_xyz[:, 1].max(),
+                     node_xyz[:, 2].min(), node_xyz[:, 2].max()])
+    return LatticeArrays(node_xyz=node_xyz, beam_conn=beam_conn, beam_radius=rad_u[border],
+                         beam_type=typ_u[border].astype(np.int32), beam_cell0=cell0_u[border].astype(np.int32),
+                         cell_pos=pos, cell_coord=coord, cell_size=size, cell_radii=cell_radii,
+                         cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr, cell_node_idx=cn_idx,
+                         bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)))
+
+
+# ------------------------------------------------------------------------------------------------
+# joint penalisation
+# ------------------------------------------------------------------------------------------------
+def _lzone_of(radius, angle_deg):
+    """function_penalization_Lzone (utils.py:432-453), vectorised."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        L = radius / np.tan(np.radians(angle_deg) / 2.0)
+    L = np.where(angle_deg > 170.0, 0.0000001, L)
+    return np.where(angle_deg == 0.0, 0.0, L)
+
+
+def point_tags(xyz, box):
+    """Point.tag_point (point.py:169-235) for many points; -1 where the reference returns None."""
+    xmin, xmax, ymin, ymax, zmin, zmax = box
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    ex = [(x == xmin), (x > xmin) & (x < xmax), (x == xmax)]
+    ey = [(y == ymin), (y > ymin) & (y < ymax), (y == ymax)]
+    ez = [(z == zmin), (z > zmin) & (z < zmax), (z == zmax)]
+    tag = np.full(len(xyz), -1, np.int64)
+    table = {  # (ix, iy, iz) with 0=min 1=inside 2=max
+        (0, 1, 1): 12, (2, 1, 1): 13, (1, 0, 1): 11, (1, 2, 1): 14, (1, 1, 0): 10, (1, 1, 2): 15,
+        (0, 0, 1): 102, (1, 0, 0): 100, (2, 0, 1): 104, (1, 0, 2): 108, (0, 1, 0): 101, (2, 1, 0): 103,
+        (0, 2, 1): 106, (1, 2, 0): 105, (2, 2, 1): 107, (1, 2, 2): 111, (0, 1, 2): 109, (2, 1, 2): 110,
+        (0, 0, 0): 1000, (2, 0, 0): 1001, (0, 2, 0): 1002, (2, 2, 0): 1003, (0, 0, 2): 1004, (2, 0, 2): 1005,
+        (0, 2, 2): 1006, (2, 2, 2): 1007}
+    for (i, j, k), code in table.items():
+        tag[ex[i] & ey[j] & ez[k]] = code
+    return tag
+
+
+_EDGE_GROUPS = [[102, 104, 106, 107], [100, 108, 105, 111], [101, 109, 103, 110]]
+_FACE_GROUPS = [[10, 15], [11, 14], [12, 13]]
+
+
+def _angle_periodic(xyz, tag, ba, bb):
+    """Beam.get_angle_between_beams with periodicity=True, scalar restatement of beam.py:204-277
+    (including its 'last matching candidate wins' loops).  ba/bb = (p1, p2) node ids."""
+    p1 = p2 = None
+
+    def scan(group):
+        nonlocal p1, p2
+        for i1, c1 in enumerate(ba):
+            if tag[c1] > 0 and tag[c1] in group:
+                p1 = i1
+                for i2, c2 in enumerate(bb):
+                    if tag[c2] > 0 and tag[c2] in group:
+                        p2 = i2
+                        break
+
+    scan(range(1000, 1008))
+    if p1 is None and p2 is None:
+        for g in _EDGE_GROUPS:
+            scan(g)
+    if p1 is None and p2 is None:
+        for g in _FACE_GROUPS:
+            scan(g)
+    a1, a2 = ba
+    b1, b2 = bb
+    if a1 == b1 or (p1 == 0 and p2 == 0):
+        u, v = xyz[a2] - xyz[a1], xyz[b2] - xyz[b1]
+    elif a1 == b2 or (p1 == 0 and p2 == 1):
+        u, v = xyz[a2] - xyz[a1], xyz[b1] - xyz[b2]
+    elif a2 == b1 or (p1 == 1 and p2 == 0):
+        u, v = xyz[a1] - xyz[a2], xyz[b2] - xyz[b1]
+    elif a2 == b2 or (p1 == 1 and p2 == 1):
+        u, v = xyz[a1] - xyz[a2], xyz[b1] - xyz[b2]
+    else:
+        return None
+    c = float(u @ v) / (math.sqrt(float(u @ u)) * math.sqrt(float(v @ v)))
+    return math.degrees(math.acos(max(min(c, 1.0), -1.0)))
+
+
+def compute_lzone(lat: LatticeArrays, periodicity: bool = False) -> np.ndarray:
+    """(B,2) penalisation length at each strut end: over the other struts meeting at that node, the one that
+    maximises L = r_other / tan(angle/2) (lattice.py:871-904)."""
+    xyz, conn, rad = lat.node_xyz, lat.beam_conn.astype(np.int64), lat.beam_radius
+    B, N = len(conn), len(xyz)
+    if not periodicity:
+        # half-edges sorted by node
+        he_node = conn.ravel()                                   # (2B,) node of half-edge h = 2*b + end
+        he_far = conn[:, ::-1].ravel()
+        dirv = xyz[he_far] - xyz[he_node]
+        dnorm = np.sqrt(dirv[:, 0] * dirv[:, 0] + dirv[:, 1] * dirv[:, 1] + dirv[:, 2] * dirv[:, 2])
+        order = np.argsort(he_node, kind="stable")
+        ptr = np.zeros(N + 1, np.int64)
+        np.add.at(ptr, he_node + 1, 1)
+        ptr = np.cumsum(ptr)
+        deg = np.diff(ptr)
+        lz = np.zeros(2 * B)
+        # group nodes by valence so each group is a dense (n, v, v) problem
+        for v in np.unique(deg):
+            if v < 2:
+                continue
+            nodes = np.flatnonzero(deg == v)
+            hes = order[ptr[nodes][:, None] + np.arange(v)[None, :]]          # (n, v) half-edge ids
+            d = dirv[hes]                                                     # (n, v, 3)
+            # same operation order as beam.py:269-273: ((x1 x2 + y1 y2) + z1 z2) / (|u| |v|)
+            dot = (d[:, :, None, 0] * d[:, None, :, 0] + d[:, :, None, 1] * d[:, None, :, 1]
+                   + d[:, :, None, 2] * d[:, None, :, 2])
+            nn = dnorm[hes]
+            cosang = np.clip(dot / (nn[:, :, None] * nn[:, None, :]), -1.0, 1.0)
+            ang = np.degrees(np.arccos(cosang))
+            r_other = rad[hes // 2][:, None, :] * np.ones((1, v, 1))          # (n, i, j) radius of j
+            L = _lzone_of(r_other, ang)
+            valid = (ang > 1e-12) & ~np.eye(v, dtype=bool)[None]
+            L = np.where(valid, L, -1.0)
+            best = L.max(axis=2)
+            lz[hes] = np.where(best < 0.0, 0.0, best)
+        return lz.reshape(B, 2)
+
+    # periodic lattices (small single-cell models used for the Schur datasets): scalar restatement
+    tag = point_tags(xyz, lat.bbox)
+    xmin, xmax, ymin, ymax, zmin, zmax = lat.bbox
+    inc = [[] for _ in range(N)]
+    for b, (a, c) in enumerate(conn):
+        inc[a].append(b)
+        inc[c].append(b)
+    tol = 1e-9
+    w = xyz.copy()
+    w[np.abs(w[:, 0] - xmax) <= tol, 0] = xmin
+    w[np.abs(w[:, 1] - ymax) <= tol, 1] = ymin
+    w[np.abs(w[:, 2] - zmax) <= tol, 2] = zmin
+    buckets = {}
+    for i, k in enumerate(map(tuple, np.round(w / tol).astype(np.int64))):
+        buckets.setdefault(k, []).append(i)
+    merged = [None] * N
+    for ids in buckets.values():
+        s = sorted(set(b for i in ids for b in inc[i]))
+        for i in ids:
+            merged[i] = s
+    lz = np.zeros((B, 2))
+    for b in range(B):
+        for e in range(2):
+            best = -1.0
+            for nb in merged[conn[b, e]]:
+                if nb == b:
+                    continue
+                ang = _angle_periodic(xyz, tag, tuple(conn[b]), tuple(conn[nb]))
+                if ang is None or not ang > 1e-12:
+                    continue
+                L = float(_lzone_of(np.float64(rad[nb]), np.float64(ang)))
+                if L > best:
+                    best = L
+            lz[b, e] = 0.0 if best < 0 else best
+    return lz
+
+
+@dataclass
+class PenalizedBeams:
+    """Per design-lattice strut: the up-to-three colinear segments it is meshed as."""
+    seg_len: np.ndarray      # (B,3) geometric length of [pen@point1, middle, pen@point2]; 0 where absent
+    seg_nsub: np.ndarray     # (B,3) i32 number of equal P1 sub-elements gmsh puts on each segment
+    pen_xyz: np.ndarray      # (B,2,3) coordinates of the two penalisation points (NaN where absent)
+    lzone: np.ndarray        # (B,2)
+
+
+def gmsh_subdivisions(length, h):
+    """int(length/h + 0.99), >= 1 where length > 0 (gmsh 1-D mesher with a uniform size field)."""
+    n = np.floor(np.asarray(length) / h + 0.99).astype(np.int32)
+    return np.where(np.asarray(length) > 0, np.maximum(n, 1), 0).astype(np.int32)
+
+
+def penalize(lat: LatticeArrays, lzone: np.ndarray | None, mesh_size: float | None = None) -> PenalizedBeams:
+    """Split every strut into pen(L1) + middle + pen(L2) exactly where the reference puts the new points
+    (start + (end-start)/round(length,4) * L, beam.py:300-312) and count gmsh sub-elements per segment."""
+    xyz, conn = lat.node_xyz, lat.beam_conn
+    B = len(conn)
+    h = (MESH_ELEMENT_LENGTH * lat.cell_size_nominal[0]) if mesh_size is None else mesh_size
+    pa, pb = xyz[conn[:, 0]], xyz[conn[:, 1]]
+    d = pb - pa
+    true_len = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2 + d[:, 2] ** 2)
+    if lzone is None:
+        lzone = np.zeros((B, 2))
+    uniq, inv = np.unique(true_len, return_inverse=True)
+    len4 = np.array([round(float(v), 4) for v in uniq])[inv.ravel()]          # Beam.length (beam.py:135)
+    L1, L2 = lzone[:, 0], lzone[:, 1]
+    has1, has2 = L1 > 0, L2 > 0
+    q1 = pa + (d / len4[:, None]) * L1[:, None]
+    q2 = pb + ((-d) / len4[:, None]) * L2[:, None]
+    start = np.where(has1[:, None], q1, pa)
+    mid_end = np.where(has2[:, None], q2, pb)
+
+    def dist(u, v):
+        w = v - u
+        return np.sqrt(w[:, 0] ** 2 + w[:, 1] ** 2 + w[:, 2] ** 2)
+
+    seg_len = np.stack([np.where(has1, dist(pa, q1), 0.0), dist(start, mid_end),
+                        np.where(has2, dist(q2, pb), 0.0)], axis=1)
+    seg_nsub = gmsh_subdivisions(seg_len, h)
+    pen_xyz = np.stack([np.where(has1[:, None], q1, np.nan), np.where(has2[:, None], q2, np.nan)], axis=1)
+    return PenalizedBeams(seg_len=seg_len, seg_nsub=seg_nsub, pen_xyz=pen_xyz, lzone=np.asarray(lzone, float))

@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference's ``LatticeSim`` for the FEM hot path, backed by arrays.
+
+Mirrors (same names, argument meaning and error behaviour) the parts of
+``src/pyLatticeSim/lattice_sim.py`` and ``src/pyLatticeDesign/lattice.py`` that feed
+``solve_FEM_FenicsX``: preset parsing (lattice.py:212-311, lattice_sim.py:201-238), joint penalisation
+(lattice_sim.py:245-308), boundary conditions (lattice_sim.py:405-494, lattice.py:1320-1411) and the
+``xsol`` packing (lattice_sim.py:502-542).  Node data live in (N,6) arrays instead of ``Point`` lists:
+
+    fixed_DOF, displacement_vector, applied_force, reaction_force_vector, index_boundary
+
+Documented deviation: the reference splits a strut shared by two cells once PER CELL
+(lattice_sim.py:250-303), leaving duplicate segments whose points carry no index (its gmsh model is then
+ill-defined for e.g. multi-cell Octet); here every strut is penalised exactly once.
+"""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import lattice_arrays as LA
+
+_ROOT = Path(__file__).resolve().parents[1]
+PRESET_DIR = _ROOT / "data" / "inputs" / "preset_lattice"
+
+# E, nu of the reference's material cards (src/pyLatticeDesign/materials/*.json)
+MATERIALS = {"VeroClear": (1013.0, 0.3), "TPU": (20000.0, 0.3), "Ti-6Al-4V": (104000.0, 0.35)}
+_SURFACES = ["Xmin", "Xmax", "Ymin", "Ymax", "Zmin", "Zmax", "Xmid", "Ymid", "Zmid"]
+_DOF_MAP = {"X": 0, "Y": 1, "Z": 2, "RX": 3, "RY": 4, "RZ": 5}
+
+
+def open_lattice_parameters(file_name):
+    """utils.open_lattice_parameters (utils.py:111-130): preset name relative to data/inputs/preset_lattice,
+    or an absolute path; '.json' appended when missing.  A dict is passed through (extension)."""
+    if isinstance(file_name, dict):
+        return file_name
+    json_path = PRESET_DIR / file_name
+    if json_path.suffix != ".json":
+        json_path = json_path.with_suffix(".json")
+    try:
+        with open(json_path, "r") as fh:
+            return json.load(fh)
+    except FileNotFoundError:
+        raise FileNotFoundError(f"The file {json_path} does not exist.")
+
+
+def material_properties(name):
+    if name in MATERIALS:
+        return MATERIALS[name]
+    p = os.environ.get("PYLATTICE_MATERIAL_PATH")
+    if p and os.path.exists(os.path.join(p, f"{name}.json")):
+        with open(os.path.join(p, f"{name}.json")) as fh:
+            d = json.load(fh)
+        return float(d["Young_modulus"]), float(d["Poisson_ratio"])
+    raise FileNotFoundError(f"Material file not found: {name}.json")
+
+
+class LatticeSim:
+    def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0,
+                 enable_domain_decomposition_solver: bool = False):
+        if mesh_trimmer is not None:
+            raise NotImplementedError("mesh_trimmer is outside the accelerated path")
+        self._verbose = verbose
+        self.domain_decomposition_solver = enable_domain_decomposition_solver
+        self.n_DOF_per_node = 6
+        self.penalization_coefficient = LA.PENALIZATION_COEFFICIENT
+        self.is_penalized = False
+        params = open_lattice_parameters(name_file)
+        self._extract_geometry(params)
+        self.define_simulation_parameters(params)
+        self.lattice = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
+                                   (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
+                                   self.radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,
+                                   erased_blocks=self.eraser_blocks)
+        lat = self.lattice
+        self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max = map(float, lat.bbox)
+        N = lat.n_nodes
+        self.fixed_DOF = np.zeros((N, 6), dtype=bool)
+        self.displacement_vector = np.zeros((N, 6))
+        self.applied_force = np.zeros((N, 6))
+        self.reaction_force_vector = np.zeros((N, 6))
+        self.penalized = None
+        if self.enable_simulation_properties and not self.domain_decomposition_solver:
+            self.define_angles_between_beams()
+            self.set_penalized_beams()
+        else:
+            self.lzone = np.zeros((lat.n_beams, 2))
+            self.penalized = LA.penalize(lat, None)
+        self.define_node_index_boundary()
+        self.set_boundary_conditions()
+        self._device = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _extract_geometry(self, p):
+        geometry = p.get("geometry", {})
+        cs, nc = geometry.get("cell_size", {}), geometry.get("number_of_cells", {})
+        self.cell_size_x, self.cell_size_y, self.cell_size_z = cs.get("x"), cs.get("y"), cs.get("z")
+        self.num_cells_x, self.num_cells_y, self.num_cells_z = nc.get("x"), nc.get("y"), nc.get("z")
+        self.radii = geometry.get("radii")
+        self.geom_types = geometry.get("geom_types")
+        if None in [self.cell_size_x, self.cell_size_y, self.cell_size_z, self.num_cells_x, self.num_cells_y,
+                    self.num_cells_z, self.radii, self.geom_types]:
+            raise ValueError("Missing geometry parameters in JSON file.")
+        if geometry.get("enable_randomness", False):
+            raise NotImplementedError("enable_randomness is outside the accelerated path")
+        grad = p.get("gradient", {})
+
+        def table(block, keys):
+            if not block:
+                return None
+            return LA.gradient_table(self.num_cells_x, self.num_cells_y, self.num_cells_z,
+                                     block.get("rule", "constant"),
+                                     [block.get(f"direction_{a}", False) for a in "xyz"],
+                                     [block.get(f"parameter_{a}", 0.0) for a in "xyz"])
+
+        self.grad_radius = table(grad.get("radii", {}), None)
+        self.grad_dim = table(grad.get("cell_dimension", {}), None)
+        sup = p.get("supplementary", {})
+        blocks = []
+        for blk in sup.get("erased_blocks", {}).values():
+            s, d = blk.get("start_point", {}), blk.get("dimensions_block", {})
+            blocks.append([s.get("x", 0.0), s.get("y", 0.0), s.get("z", 0.0), d.get("x", 0.0), d.get("y", 0.0),
+                           d.get("z", 0.0)])
+        self.eraser_blocks = blocks or None
+        if sup.get("symmetries"):
+            raise NotImplementedError("symmetries are outside the accelerated path")
+
+    def define_simulation_parameters(self, name_file):
+        """lattice_sim.py:201-238."""
+        p = open_lattice_parameters(name_file)
+        sim = p.get("simulation_parameters", {})
+        self.enable_simulation_properties = bool(sim.get("enable", False))
+        self.material_name = sim.get("material", "VeroClear")
+        self.enable_periodicity = sim.get("periodicity", False)
+        if sim.get("DDM") is None and self.domain_decomposition_solver:
+            raise ValueError("Schur complement computation method must be defined in the input file.")
+        self.boundary_conditions = p.get("boundary_conditions", {})
+        self.young_modulus, self.poisson_ratio = material_properties(self.material_name)
+
+    # ------------------------------------------------------------------------------------------------
+    def get_number_cells(self):
+        return self.lattice.n_cells
+
+    def get_number_beams(self):
+        return self.lattice.n_beams
+
+    def get_number_nodes(self):
+        return self.lattice.n_nodes
+
+    def get_lattice_boundary_box(self):
+        return [self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max]
+
+    # ------------------------------------------------------------------------------------------------
+    def define_angles_between_beams(self):
+        self.lzone = LA.compute_lzone(self.lattice, bool(self.enable_periodicity))
+
+    def set_penalized_beams(self):
+        self.penalized = LA.penalize(self.lattice, self.lzone)
+        self.is_penalized = True
+
+    def define_node_index_boundary(self):
+        """Boundary index of every node lying on the box of one of its cells (lattice_sim.py:546-563), numbered in
+        the order get_global_displacement visits them (cells in order, nodes by rounded coordinates)."""
+        lat = self.lattice
+        N = lat.n_nodes
+        self.index_boundary = np.full(N, -1, np.int64)
+        on_box = np.zeros(N, bool)
+        ptr, idx = lat.cell_node_ptr, lat.cell_node_idx
+        cell_of = np.repeat(np.arange(lat.n_cells), np.diff(ptr))
+        xyz = lat.node_xyz[idx]
+        lo, hi = lat.cell_coord[cell_of], lat.cell_coord[cell_of] + lat.cell_size[cell_of]
+        on = ((xyz == lo) | (xyz == hi)).any(axis=1)
+        on_box[idx[on]] = True
+        # visit order: cell-major, then (round(x,9), round(y,9), round(z,9), index); node index already sorts by xyz
+        order = np.lexsort((idx, cell_of))
+        seq = idx[order]
+        seq = seq[on_box[seq]]
+        _, first = np.unique(seq, return_index=True)
+        visit = seq[np.sort(first)]
+        self.index_boundary[visit] = np.arange(len(visit))
+        self.max_index_boundary = len(visit) - 1
+        self._boundary_visit_order = visit
+
+    # ------------------------------------------------------------------------------------------------
+    def get_cells_on_surfaces(self, surfaces):
+        """lattice.py:1363-1411: iterative extrema filter on the integer cell positions."""
+        pos = self.lattice.cell_pos
+        cand = np.arange(len(pos))
+        for token in surfaces:
+            t = token.strip().lower()
+            if not t:
+                continue
+            ax = {"x": 0, "y": 1, "z": 2}.get(t[0])
+            if ax is None:
+                raise ValueError(f"Invalid axis in constraint '{token}', expected X/Y/Z with min/max.")
+            if "min" in t:
+                ext = pos[cand, ax].min()
+            elif "max" in t:
+                ext = pos[cand, ax].max()
+            else:
+                raise ValueError(f"Invalid extrema in constraint '{token}', expected 'min' or 'max'.")
+            cand = cand[pos[cand, ax] == ext]
+            if len(cand) == 0:
+                return cand
+        return cand
+
+    def find_point_on_lattice_surface(self, surfaceNames, surface_cells=None):
+        """Node ids on the given surfaces (lattice.py:1320-1359)."""
+        if not all(s in _SURFACES for s in surfaceNames):
+            raise ValueError("Invalid surface name_lattice(s).")
+        lat = self.lattice
+        cells = self.get_cells_on_surfaces(surfaceNames)
+        names = surface_cells if surface_cells is not None else surfaceNames
+        out = []
+        for c in cells:
+            nodes = lat.cell_node_idx[lat.cell_node_ptr[c]:lat.cell_node_ptr[c + 1]]
+            xyz = lat.node_xyz[nodes]
+            keep = np.ones(len(nodes), bool)
+            for s in names:
+                ax = "XYZ".index(s[0])
+                if s.endswith("max"):
+                    val = lat.cell_coord[c, ax] + lat.cell_size[c, ax]
+                else:   # min and mid both refer to the cell's lower corner (cell.py:451-462)
+                    val = lat.cell_coord[c, ax]
+                keep &= xyz[:, ax] == val
+            out.append(nodes[keep])
+        pts = np.unique(np.concatenate(out)) if out else np.zeros(0, np.int64)
+        if len(pts) == 0:
+            raise ValueError("No points found on the specified surfaces.")
+        return pts
+
+    def apply_constraints_nodes(self, surfaces, value, DOF, type_constraint="Displacement", surface_cells=None):
+        """lattice_sim.py:405-458: displacement -> value + fixed flag; force -> total / number of target nodes
+        whose dof is free."""
+        pts = self.find_point_on_lattice_surface(surfaces, surface_cells)
+        pts = pts[self.index_boundary[pts] >= 0]
+        if len(pts) == 0:
+            raise ValueError("No nodes found on the specified surfaces for constraint application.")
+        targets = {d: int((~self.fixed_DOF[pts, d]).sum()) for d in DOF}
+        for val, d in zip(value, DOF):
+            if type_constraint == "Displacement":
+                self.displacement_vector[pts, d] = val
+                self.fixed_DOF[pts, d] = True
+            elif type_constraint == "Force":
+                self.applied_force[pts, d] = val / max(1, targets[d])
+            else:
+                raise ValueError("Invalid type of constraint. Use 'Displacement' or 'Force'.")
+
+    def set_boundary_conditions(self):
+        """lattice_sim.py:460-494."""
+        for key, block in self.boundary_conditions.items():
+            if key not in ["Force", "Displacement"]:
+                raise ValueError(f"Invalid boundary condition type: {key}. Must be 'Force' or 'Displacement'.")
+            for _name, data in block.items():
+                if "Surface" not in data or "Value" not in data or "DOF" not in data:
+                    raise ValueError("Invalid boundary condition data. 'Surface', 'Value' and 'DOF' are required.")
+                if not isinstance(data["Surface"], list):
+                    raise ValueError("Surface must be a list of strings.")
+                if not isinstance(data["Value"], list):
+                    raise ValueError("Value must be a list of floats.")
+                if not isinstance(data["DOF"], list):
+                    raise ValueError("DOF must be a list of strings.")
+                if len(data["Value"]) != len(data["DOF"]):
+                    raise ValueError("Value and DOF must have the same length.")
+                if not all(d in _DOF_MAP for d in data["DOF"]):
+                    raise ValueError("DOF must be one of 'X', 'Y', 'Z', 'RX', 'RY', 'RZ'.")
+                if not all(s in _SURFACES for s in data["Surface"]):
+                    raise ValueError("Surface must be one of 'Xmin', 'Xmax', 'Ymin', 'Ymax', 'Zmin', 'Zmax', "
+                                     "'Xmid', 'Ymid', 'Zmid'.")
+                self.apply_constraints_nodes(data["Surface"], data["Value"], [_DOF_MAP[d] for d in data["DOF"]],
+                                             key, data.get("SurfaceCells", None))
+
+    # ------------------------------------------------------------------------------------------------
+    def get_global_displacement(self, withFixed: bool = False, OnlyImposed: bool = False):
+        """lattice_sim.py:502-542: free dofs of the cell-boundary nodes in visit order."""
+        disp, index = [], []
+        for n in self._boundary_visit_order:
+            for i in range(6):
+                free = not self.fixed_DOF[n, i]
+                if free and not OnlyImposed:
+                    disp.append(self.displacement_vector[n, i])
+                    index.append(int(self.index_boundary[n]))
+                elif free and self.applied_force[n, i] == 0:
+                    disp.append(0)
+                elif withFixed or OnlyImposed:
+                    disp.append(self.displacement_vector[n, i])
+                    index.append(int(self.index_boundary[n]))
+        if not OnlyImposed:
+            self.global_displacement_index = index
+        return np.array(disp), index
+
+    # ------------------------------------------------------------------------------------------------
+    def device_model(self, **kw):
+        """The HIP handle for this lattice (created on first use; no CPU fallback)."""
+        from ._capi import HipLattice
+        if self._device is None:
+            pen = self.penalized
+            self._device = HipLattice(self.lattice.node_xyz, self.lattice.beam_conn, self.lattice.beam_radius,
+                                      pen.seg_len, pen.seg_nsub, self.young_modulus, self.poisson_ratio,
+                                      pen_coef=self.penalization_coefficient, **kw)
+        return self._device

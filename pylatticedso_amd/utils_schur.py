@@ -1,0 +1,40 @@
+"""Drop-in for ``get_schur_complement`` (src/pyLatticeSim/utils_schur.py:22-53) on MI355X."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def node_order_to_simulate(lattice, cell_index=0, tol=1e-9):
+    """Cell.define_node_order_to_simulate (cell.py:611-680): boundary nodes bucketed by the first face they lie on
+    in the priority Xmin,Xmax,Ymin,Ymax,Zmin,Zmax, each bucket sorted by its in-plane coordinates."""
+    lat = lattice.lattice
+    nodes = lat.cell_node_idx[lat.cell_node_ptr[cell_index]:lat.cell_node_ptr[cell_index + 1]]
+    nodes = nodes[lattice.index_boundary[nodes] >= 0]
+    xyz = lat.node_xyz[nodes]
+    lo = lat.cell_coord[cell_index]
+    hi = lo + lat.cell_size[cell_index]
+    on = np.stack([np.abs(xyz[:, 0] - lo[0]) <= tol, np.abs(xyz[:, 0] - hi[0]) <= tol,
+                   np.abs(xyz[:, 1] - lo[1]) <= tol, np.abs(xyz[:, 1] - hi[1]) <= tol,
+                   np.abs(xyz[:, 2] - lo[2]) <= tol, np.abs(xyz[:, 2] - hi[2]) <= tol], axis=1)
+    face = np.argmax(on, axis=1)
+    keys = {0: (1, 2, 0), 1: (1, 2, 0), 2: (0, 2, 1), 3: (0, 2, 1), 4: (0, 1, 2), 5: (0, 1, 2)}
+    ordered = []
+    for f in range(6):
+        sel = np.flatnonzero(face == f)
+        k = keys[f]
+        o = np.lexsort((xyz[sel, k[2]], xyz[sel, k[1]], xyz[sel, k[0]]))
+        ordered.extend(nodes[sel[o]])
+    return np.asarray(ordered, dtype=np.int64)
+
+
+def get_schur_complement(lattice, cell_index=None, rtol=1e-13, max_iter=200000):
+    """S = K_BB - K_BI K_II^-1 K_IB of one cell on its boundary nodes, (6 n_b, 6 n_b), node order as the reference."""
+    if cell_index is None and lattice.get_number_cells() > 1:
+        raise ValueError("The lattice must contain only one cell for Schur complement calculation or specify a "
+                         "cell_index.")
+    if lattice.get_number_cells() > 1:
+        raise NotImplementedError("cell_index on multi-cell lattices: build a one-cell LatticeSim instead")
+    order = node_order_to_simulate(lattice, 0)
+    dev = lattice.device_model()
+    dev.assemble()
+    return dev.schur(order, rtol=rtol, max_iter=max_iter)
