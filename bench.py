@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — beams/s of "assembly + PCG solve" on synthetic periodic lattices (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 50x50x50 Octet, r = 0.03, cell size 1, VeroClear,
+joint penalisation on, cantilever (all 6 dofs clamped on Xmin, total force -0.1 in Z on Xmax), fp64.
+For N > 1 GPUs the lattice is 50 x (50 N) x 50 cut into N y-slabs of 50 layers (weak scaling: 3.03 M struts per
+GPU; growing along y keeps the cantilever's aspect ratio, hence its conditioning, fixed); interface forces and
+PCG dot products are all-reduced with RCCL inside libpylattice_hip.
+
+One "step" = per-strut stiffness build (condensed records + Jacobi diagonal) + explicit BSR(6x6) global-K
+assembly + matrix-free Jacobi-PCG solve to ||r|| <= rtol ||b|| — all on data already resident in HBM.
+value = struts of the whole job * steps / time.  The roofline object prices the dominant kernel (K*p) with the
+algorithmic bytes of SURVEY.md 8(d) and a HIP-event timing taken on the library's own stream; cpu_baseline is the
+plain-C oracle (oracle/beam_pcg.c, 1 thread) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+E, NU = 1013.0, 0.3
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cantilever_bc(xyz, x_max, n_targets_global=None, weight=None):
+    """fixed / ubar / f arrays of the cantilever: clamp Xmin, total Fz = -0.1 spread over the Xmax nodes."""
+    n = len(xyz)
+    fixed = np.zeros((n, 6), np.uint8)
+    fixed[xyz[:, 0] == 0.0] = 1
+    tgt = xyz[:, 0] == x_max
+    f = np.zeros((n, 6))
+    cnt = n_targets_global if n_targets_global is not None else int(tgt.sum())
+    f[tgt, 2] = -0.1 / cnt
+    return fixed, f, tgt
+
+
+def cpu_baseline(cells, radius, rtol):
+    """Plain-C oracle (1 thread) on a bounded sample of the same workload: same lattice type / BCs, fewer cells."""
+    from oracle import c_oracle
+    from pylatticedso_amd import lattice_arrays as LA
+    lat = LA.generate((1, 1, 1), (cells,) * 3, ["Octet"], [radius])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed, f, _ = cantilever_bc(lat.node_xyz, float(cells))
+    t0 = time.perf_counter()
+    sc = c_oracle.condense_unique(lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU)
+    u, it, rel = c_oracle.pcg(lat.node_xyz, lat.beam_conn, sc, fixed, np.zeros_like(f), f, rtol=rtol, maxit=100000)
+    dt = time.perf_counter() - t0
+    return {"value": lat.n_beams / dt, "unit": "beams/s", "cores": 1, "kind": "port",
+            "sample": f"{cells}^3 Octet r={radius} cantilever, {lat.n_beams} struts, {abs(it)} Jacobi-PCG iterations "
+                      f"to rtol {rtol:g} in {dt:.1f} s (oracle/beam_pcg.c, gcc -O2, 1 thread)"}, u
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=50, help="cells per edge (per GPU along y)")
+    ap.add_argument("--geom", default="Octet")
+    ap.add_argument("--radius", type=float, default=0.03)
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--max-iter", type=int, default=100000)
+    ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
+    ap.add_argument("--reorder", type=int, default=1)
+    ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from pylatticedso_amd import _capi, lattice_arrays as LA, partition as PT
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+
+    n = args.cells
+    ncell = (n, n * world, n)
+    t0 = time.perf_counter()
+    if world == 1:
+        lat = LA.generate((1, 1, 1), ncell, [args.geom], [args.radius])
+        pen = LA.penalize(lat, LA.compute_lzone(lat))
+        xyz, conn, rad, seg_len, seg_nsub = lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub
+        n_tgt = None
+    else:
+        slab = PT.build_slab((1, 1, 1), ncell, [args.geom], [args.radius], rank, world, axis=1)
+        xyz, conn, rad, seg_len, seg_nsub = slab.node_xyz, slab.beam_conn, slab.beam_radius, slab.seg_len, slab.seg_nsub
+    log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
+
+    dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
+                           reorder=args.reorder)
+    n_beams_total = len(conn)
+    if world > 1:
+        keys = [None] * world
+        dist.all_gather_object(keys, slab.iface_key)
+        ok, gid, nsg = PT.global_interface_ids(keys, rank)
+        uid = [_capi.HipLattice.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dev.dist_init(rank, world, uid[0], slab.iface_local[ok], gid, nsg)
+        # global number of loaded nodes / struts (shared nodes counted once: they belong to the lower slab)
+        lower_plane = np.zeros(len(xyz), bool)
+        if rank > 0:
+            lower_plane[slab.iface_local[ok][slab.iface_key[ok][:, 0] == slab.layers[0]]] = True
+        cnt = torch.tensor([float(((xyz[:, 0] == float(n)) & ~lower_plane).sum()), float(len(conn))],
+                           dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt)
+        n_tgt, n_beams_total = int(cnt[0].item()), int(cnt[1].item())
+    fixed, f, _ = cantilever_bc(xyz, float(n), n_tgt)
+    dev.set_bc(fixed, None, f)
+
+    def step():
+        dev.assemble()
+        if not args.no_bsr:
+            dev.assemble_bsr(False)
+        return dev.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: K*p.  HIP events on the library's stream (torch events only see torch's stream).
+    ms_spmv = dev.time_kernel(0, 50)
+    ms_iter = dev.time_kernel(3, 50)
+    ms_rec = dev.time_kernel(1, 20)
+    ms_bsr = dev.time_kernel(2, 10) if not args.no_bsr else None
+    ab = dev.algorithmic_bytes()
+    achieved = ab["spmv"] / (ms_spmv * 1e-3) / 1e9
+
+    out = {
+        "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {args.geom} r={args.radius} cantilever "
+                               f"(BASELINE.json configs[1] per GPU)",
+                   "struts": n_beams_total, "struts_per_gpu": len(conn), "nodes_per_gpu": len(xyz),
+                   "partition": "single GPU" if world == 1 else f"{world} y-slabs, RCCL interface all-reduce",
+                   "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
+                   "rel_residual": st["rel_residual"], "preconditioner": "Jacobi",
+                   "step": "records + Jacobi diag" + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
+                   "spmv_kernel": args.kernel, "reorder": args.reorder},
+        "roofline": {"bound": "hbm", "kernel": "K*p (per-node gather over condensed struts)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},
+        "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
+                       "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
+                       "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"]},
+    }
+    if rank == 0 and world == 1 and args.cpu_cells > 0:
+        cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol)
+        out["cpu_baseline"] = cb
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    dev.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

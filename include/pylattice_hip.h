@@ -112,7 +112,7 @@ int pl_spmv_bsr(pl_handle h, const double *x, double *y);
 
 /* Solve K u = f with the Dirichlet data of pl_set_bc by Jacobi-PCG on the matrix-free operator.
  * Replaces the PETSc KSP(preonly)+PC(LU) solve of simulation_base.py:501-511.  u[6N] gets the full field
- * (prescribed values on constrained dofs).  rtol is on ||r||/||b||. */
+ * (prescribed values on constrained dofs; u == NULL keeps it on the device only).  rtol is on ||r||/||b||. */
 int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *stats);
 
 /* R = K u on every dof (caller keeps the constrained ones).  Replaces

@@ -194,12 +194,15 @@ class HipLattice:
     def reactions(self, u):
         return self._vec_op(self._lib.pl_reactions, u)
 
-    def solve(self, rtol=1e-8, max_iter=20000, raise_on_noconv=True):
-        u = np.empty(6 * self.n_nodes, np.float64)
+    def solve(self, rtol=1e-8, max_iter=20000, raise_on_noconv=True, download=True):
+        """PCG solve; returns (u[N,6], stats).  download=False leaves u on the device and returns stats only."""
+        u = np.empty(6 * self.n_nodes, np.float64) if download else None
         st = PlStats()
         rc = self._lib.pl_solve(self._h, float(rtol), int(max_iter), _ptr(u), C.byref(st))
         self.last_stats = {k: getattr(st, k) for k, _ in PlStats._fields_ if k != "reserved"}
         _check(self._lib, rc, allow=() if raise_on_noconv else (PL_ERR_NOCONV,))
+        if not download:
+            return self.last_stats
         return u.reshape(self.n_nodes, 6), self.last_stats
 
     def sens(self, u, lam=None):

@@ -680,7 +680,7 @@ int pl_spmv_bsr(pl_handle h, const double *x, double *y) {
 }
 
 int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *stats) {
-  if (!valid(h) || !u) return fail(PL_ERR_ARG, "pl_solve: null argument");
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_solve: null handle");   // u == NULL: leave the solution on the device
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_solve: call pl_assemble first");
   if (!h->have_bc) return fail(PL_ERR_STATE, "pl_solve: call pl_set_bc first");
   if (!(rtol > 0.0) || max_iter <= 0) return fail(PL_ERR_ARG, "pl_solve: rtol and max_iter must be positive");
@@ -701,8 +701,10 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   st.ms_solve = ms;
   st.ms_assembly = h->ms_assembly;
-  rc = download6(h, h->tmp2.p, u);
-  if (rc) return rc;
+  if (u) {
+    rc = download6(h, h->tmp2.p, u);
+    if (rc) return rc;
+  }
   h->last = st;
   if (stats) *stats = st;
   if (!st.converged) return fail(PL_ERR_NOCONV, "pl_solve: PCG did not reach rtol within max_iter");

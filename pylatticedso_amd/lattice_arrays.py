@@ -98,9 +98,12 @@ def _csr_from_pairs(rows, cols, nrows):
 
 
 def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim=None, erased_blocks=None,
-             cell_radii_override=None) -> LatticeArrays:
+             cell_radii_override=None, cell_range=None) -> LatticeArrays:
     """Vectorised Lattice.generate_lattice: cells in i,j,k order, struts of every geometry, nodes and struts
-    de-duplicated through coordinates rounded to 9 decimals (first creator wins, cell.py:312-368)."""
+    de-duplicated through coordinates rounded to 9 decimals (first creator wins, cell.py:312-368).
+
+    ``cell_range`` = ((i0,i1),(j0,j1),(k0,k1)) restricts generation to a box of cells of the SAME global lattice
+    (coordinates, gradients and creation order are those of the full lattice) - used by the slab partition."""
     nx, ny, nz = num_cells
     csx, csy, csz = cell_size
     if grad_dim is None:
@@ -115,7 +118,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
         return s
 
     xs, ys, zs = starts(nx, csx, 0), starts(ny, csy, 1), starts(nz, csz, 2)
-    I, J, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    rng = cell_range if cell_range is not None else ((0, nx), (0, ny), (0, nz))
+    I, J, K = np.meshgrid(np.arange(*rng[0]), np.arange(*rng[1]), np.arange(*rng[2]), indexing="ij")
     pos = np.stack([I.ravel(), J.ravel(), K.ravel()], axis=1).astype(np.int32)
     coord = np.stack([xs[pos[:, 0]], ys[pos[:, 1]], zs[pos[:, 2]]], axis=1)
     if erased_blocks:
