@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
     ap.add_argument("--reorder", type=int, default=1)
+    ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
+    ap.add_argument("--kernels-only", action="store_true", help="skip the timed steps, only time the kernels")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     args = ap.parse_args()
@@ -113,7 +115,7 @@ def main():
     log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
 
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder)
+                           reorder=args.reorder, lanes_per_node=args.lpn)
     n_beams_total = len(conn)
     if world > 1:
         keys = [None] * world

@@ -56,11 +56,13 @@ typedef struct {
   double kappa;          /* shear correction, 0.9 in material_definition.py:45 */
   double pen_coef;       /* radius multiplier of penalised segments, 1.5 (beam.py:71) */
   int32_t device;        /* HIP device ordinal */
-  int32_t spmv_kernel;   /* 0 = auto, 1 = per-strut + f64 atomics, 2 = per-node gather (sliced ELL), 3 = LDS tiles */
+  int32_t spmv_kernel;   /* 0 = auto (3 if reorder else 2), 1 = per-strut + f64 global atomics, 2 = per-node gather
+                            (sliced ELL), 3 = per-strut with LDS tile accumulators */
   int32_t precond;       /* 0 = none, 1 = Jacobi (diagonal), 2 = 6x6 block Jacobi */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
   int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
-  int32_t reserved[7];
+  int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
+  int32_t reserved[6];
 } pl_opts_t;
 
 typedef struct {

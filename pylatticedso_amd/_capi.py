@@ -31,7 +31,8 @@ class PlMesh(C.Structure):
 class PlOpts(C.Structure):
     _fields_ = [("young", C.c_double), ("poisson", C.c_double), ("kappa", C.c_double), ("pen_coef", C.c_double),
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
-                ("check_every", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class PlStats(C.Structure):
@@ -99,7 +100,7 @@ class HipLattice:
     """Owner of one device handle: the condensed lattice operator + its PCG on one MI355X."""
 
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
-                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=0, check_every=32):
+                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=32, lanes_per_node=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -114,6 +115,7 @@ class HipLattice:
         self._lib.pl_default_opts(C.byref(opts))
         opts.young, opts.poisson, opts.kappa, opts.pen_coef = young, poisson, kappa, pen_coef
         opts.device, opts.spmv_kernel, opts.reorder, opts.check_every = device, spmv_kernel, reorder, check_every
+        opts.lanes_per_node = lanes_per_node
         _check(self._lib, self._lib.pl_create(C.byref(mesh), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
 

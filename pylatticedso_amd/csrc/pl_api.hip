@@ -67,6 +67,8 @@ struct pl_context {
   // caller numbering <-> device numbering (perm[dev] = caller node)
   std::vector<int32_t> perm, iperm;
   bool reordered = false;
+  // caller strut order <-> device strut order (bperm[dev] = caller strut); struts are numbered by home tile
+  std::vector<int32_t> bperm;
 
   // geometry / topology (device numbering)
   DevBuf<double> xyz, radius, seg_len;
@@ -76,6 +78,7 @@ struct pl_context {
   DevBuf<int64_t> slice_ptr;
   DevBuf<int2> ent;
   int64_t n_slices = 0, n_ent = 0;
+  int lpn = pl::kDefaultLPN;   // lanes per node of the gather kernels (1, 2, 4, 8 or 16)
   // BSR
   DevBuf<int64_t> bsr_rowptr;
   DevBuf<int32_t> bsr_col, ent_slot, diag_slot;
@@ -141,7 +144,36 @@ int download6(pl_context *c, const double *dev, double *host) {
 // ----------------------------------------------------------------------------------------------------------
 // operator launches (device vectors, device numbering)
 // ----------------------------------------------------------------------------------------------------------
-int choose_kernel(const pl_context *c) { return c->opt.spmv_kernel == 0 ? 2 : c->opt.spmv_kernel; }
+// auto: the LDS-tile kernel when the nodes are brick-ordered (its tiles are then compact), else the per-node gather
+int choose_kernel(const pl_context *c) {
+  if (c->opt.spmv_kernel != 0) return c->opt.spmv_kernel;
+  return (c->reordered && c->tile.ready) ? 3 : 2;
+}
+
+template <int LPN>
+void launch_gather_lpn(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+  const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);   // one wave per ELL slice
+#define PL_G(M, D)                                                                                               \
+  hipLaunchKernelGGL((pl::k_spmv_gather<LPN, M, D>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, \
+                     c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev)
+  if (masked && dot_dev) PL_G(true, true);
+  else if (masked) PL_G(true, false);
+  else if (dot_dev) PL_G(false, true);
+  else PL_G(false, false);
+#undef PL_G
+}
+
+int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+  switch (c->lpn) {
+    case 1: launch_gather_lpn<1>(c, x, y, masked, dot_dev); break;
+    case 2: launch_gather_lpn<2>(c, x, y, masked, dot_dev); break;
+    case 4: launch_gather_lpn<4>(c, x, y, masked, dot_dev); break;
+    case 8: launch_gather_lpn<8>(c, x, y, masked, dot_dev); break;
+    case 16: launch_gather_lpn<16>(c, x, y, masked, dot_dev); break;
+    default: return fail(PL_ERR_ARG, "lanes per node must be 1, 2, 4, 8 or 16");
+  }
+  return PL_OK;
+}
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
@@ -160,30 +192,26 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
       hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
     }
-  } else if (kind == 3 && c->tile.ready && !c->dist.active) {
-    pl::launch_tile_spmv(c->tile, c->rec.p, masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream);
-  } else {
-    const unsigned g = grid_for(c->N);
-    if (c->dist.active) {
-      // local partial product, interface sum across ranks, then mask + weighted dot
-      hipLaunchKernelGGL((pl::k_spmv_gather<false, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
-                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, (double *)nullptr);
+  } else if (kind == 3 && c->tile.ready) {
+    const bool local_only = c->dist.active;
+    pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, (masked && !local_only) ? c->fixedbits.p : nullptr, x, y,
+                         local_only ? nullptr : dot_dev, c->stream);
+    if (local_only) {
       int rc = pl::dist_sum_shared(c->dist, y, c->stream);
       if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
       if (masked || dot_dev)
         pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
-    } else if (masked && dot_dev)
-      hipLaunchKernelGGL((pl::k_spmv_gather<true, true>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
-                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
-    else if (masked)
-      hipLaunchKernelGGL((pl::k_spmv_gather<true, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
-                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
-    else if (dot_dev)
-      hipLaunchKernelGGL((pl::k_spmv_gather<false, true>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
-                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
-    else
-      hipLaunchKernelGGL((pl::k_spmv_gather<false, false>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N,
-                         c->slice_ptr.p, c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev);
+    }
+  } else {
+    const bool local_only = c->dist.active;   // partial product first, interface sum across ranks, then mask + dot
+    int rc = dispatch_gather(c, x, y, masked && !local_only, local_only ? nullptr : dot_dev);
+    if (rc) return rc;
+    if (local_only) {
+      rc = pl::dist_sum_shared(c->dist, y, c->stream);
+      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+      if (masked || dot_dev)
+        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
+    }
   }
   PL_HIP(hipGetLastError());
   return PL_OK;
@@ -204,9 +232,14 @@ int launch_records(pl_context *c) {
 }
 
 int launch_diag(pl_context *c) {
-  hipLaunchKernelGGL(pl::k_diag_gather, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p,
-                     c->ent.p, c->rec.p, c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr, c->diag.p,
-                     c->dinv.p);
+  const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
+  const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
+#define PL_D(L)                                                                                                  \
+  hipLaunchKernelGGL((pl::k_diag_gather<L>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, c->ent.p, \
+                     c->rec.p, fb, c->diag.p, c->dinv.p)
+  switch (c->lpn) { case 1: PL_D(1); break; case 2: PL_D(2); break; case 4: PL_D(4); break; case 8: PL_D(8); break;
+                    default: PL_D(16); }
+#undef PL_D
   PL_HIP(hipGetLastError());
   if (c->dist.active) {
     // the diagonal of shared nodes is the sum over ranks; then invert again
@@ -218,9 +251,14 @@ int launch_diag(pl_context *c) {
 }
 
 int launch_bsr_fill(pl_context *c, int with_bc) {
-  hipLaunchKernelGGL(pl::k_bsr_fill, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p,
-                     c->ent.p, c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p,
-                     c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr, with_bc, c->bsr_vals.p);
+  const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
+  const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
+#define PL_B(L)                                                                                                  \
+  hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, c->ent.p,  \
+                     c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p, fb, with_bc, c->bsr_vals.p)
+  switch (c->lpn) { case 1: PL_B(1); break; case 2: PL_B(2); break; case 4: PL_B(4); break; case 8: PL_B(8); break;
+                    default: PL_B(16); }
+#undef PL_B
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -228,20 +266,20 @@ int launch_bsr_fill(pl_context *c, int with_bc) {
 // One PCG iteration (k = iteration index for the residual history).
 int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
-  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, c->scal.p + pl::S_PAP);
+  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, c->scal.p + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
-  if (c->dist.active) pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_PAP, 1, c->stream);
+  if (c->dist.active) pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_PAP * pl::kSlots, pl::kSlots, c->stream);
   if (c->dist.active) {
     pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p,
                                    c->scal.p, c->stream);
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_NEW, 2, c->stream);
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);
   } else {
     hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
                        c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->scal.p);
   }
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
                      c->p.p, c->scal.p);
-  hipLaunchKernelGGL(pl::k_pcg_rotate, dim3(1), dim3(1), 0, c->stream, c->scal.p, c->hist.p, k);
+  hipLaunchKernelGGL(pl::k_pcg_rotate, dim3(1), dim3(pl::kWave), 0, c->stream, c->scal.p, c->hist.p, k);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -252,7 +290,7 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   const int64_t n6 = c->N * 6;
   int rc = ensure_hist(c, max_iter + 1);
   if (rc) return rc;
-  PL_HIP(hipMemsetAsync(c->scal.p, 0, pl::S_COUNT * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
   if (c->dist.active)
     pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
                                  c->z.p, c->p.p, c->scal.p, c->stream);
@@ -261,13 +299,15 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
   PL_HIP(hipGetLastError());
   if (c->dist.active) {
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD, 1, c->stream);
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB, 1, c->stream);
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream);
+    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream);
   }
-  double h_scal[pl::S_COUNT];
-  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p, sizeof(h_scal), hipMemcpyDeviceToHost, c->stream));
+  double h_scal[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p + pl::S_BB * pl::kSlots, sizeof(h_scal), hipMemcpyDeviceToHost,
+                        c->stream));
   PL_HIP(hipStreamSynchronize(c->stream));
-  const double bb = h_scal[pl::S_BB];
+  double bb = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) bb += h_scal[k];
   st->b_norm = std::sqrt(bb);
   st->iterations = 0;
   st->converged = 0;
@@ -330,13 +370,16 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
     std::sort(adj.begin() + ptr[i], adj.begin() + ptr[i + 1],
               [](const E &l, const E &r) { return l.other < r.other || (l.other == r.other && l.code < r.code); });
 
-  // sliced ELL, 64 nodes per slice
-  const int64_t S = (N + 63) / 64;
+  // sliced ELL: kSliceNodes (16) nodes per slice, width padded to a multiple of kLPN (4) so that one slice is a
+  // whole number of 64-entry wave trips
+  const int SN = pl::kWave / c->lpn;
+  const int64_t S = (N + SN - 1) / SN;
   std::vector<int64_t> sp(S + 1, 0);
   for (int64_t s = 0; s < S; ++s) {
     int w = 0;
-    for (int64_t i = s * 64; i < std::min<int64_t>(N, s * 64 + 64); ++i) w = std::max(w, deg[i]);
-    sp[s + 1] = sp[s] + (int64_t)w * 64;
+    for (int64_t i = s * SN; i < std::min<int64_t>(N, s * SN + SN); ++i) w = std::max(w, deg[i]);
+    w = (w + c->lpn - 1) / c->lpn * c->lpn;
+    sp[s + 1] = sp[s] + (int64_t)w * SN;
   }
   std::vector<int2> ent((size_t)sp[S], int2{-1, 0});
   // BSR pattern: per row the diagonal block + one block per entry, columns ascending.  Parallel struts between the
@@ -347,7 +390,7 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
   c->h_col.assign((size_t)c->nblk, 0);
   std::vector<int32_t> ent_slot((size_t)sp[S], 0), diag_slot(N, 0);
   for (int64_t i = 0; i < N; ++i) {
-    const int64_t s = i >> 6, lane = i & 63;
+    const int64_t s = i / SN, lane = i % SN;
     int slot = 0;
     bool diag_done = false;
     for (int j = 0; j < deg[i]; ++j) {
@@ -357,7 +400,7 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
         c->h_col[c->h_rowptr[i] + slot++] = (int32_t)i;
         diag_done = true;
       }
-      const int64_t pos = sp[s] + (int64_t)j * 64 + lane;
+      const int64_t pos = sp[s] + (int64_t)j * SN + lane;
       ent[pos] = int2{e.other, e.code};
       ent_slot[pos] = slot;
       c->h_col[c->h_rowptr[i] + slot++] = e.other;
@@ -404,7 +447,7 @@ void pl_default_opts(pl_opts_t *o) {
   o->device = 0;
   o->spmv_kernel = 0;
   o->precond = 1;
-  o->reorder = 0;
+  o->reorder = 1;
   o->check_every = 32;
 }
 
@@ -437,6 +480,11 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   c->N = N;
   c->B = B;
   c->mat = {o->young, o->young / (2.0 * (1.0 + o->poisson)), o->kappa, o->pen_coef};
+  c->lpn = o->lanes_per_node > 0 ? o->lanes_per_node : pl::kDefaultLPN;
+  if (c->lpn != 1 && c->lpn != 2 && c->lpn != 4 && c->lpn != 8 && c->lpn != 16) {
+    delete c;
+    return fail(PL_ERR_ARG, "pl_create: lanes_per_node must be 0 (default), 1, 2, 4, 8 or 16");
+  }
   auto bail = [&](int rc) {
     delete c;
     return rc;
@@ -459,9 +507,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   // node ordering on the device
   c->perm.resize(N);
   std::iota(c->perm.begin(), c->perm.end(), 0);
+  std::vector<int32_t> tile_start, tile_of;
   if (o->reorder == 1) {
-    pl::spatial_order(m->node_xyz, N, c->perm);
+    pl::spatial_order(m->node_xyz, N, c->perm, tile_start);
     c->reordered = true;
+  } else {
+    pl::chunk_tiles(N, tile_start);
   }
   c->iperm.resize(N);
   for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
@@ -469,7 +520,25 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   std::vector<double> xyz((size_t)N * 3);
   for (int64_t i = 0; i < N; ++i) std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
   std::vector<int32_t> conn((size_t)B * 2);
-  for (int64_t k = 0; k < 2 * B; ++k) conn[k] = c->iperm[m->beam_conn[k]];
+  {
+    std::vector<int32_t> conn0((size_t)B * 2);
+    for (int64_t k = 0; k < 2 * B; ++k) conn0[k] = c->iperm[m->beam_conn[k]];
+    pl::tile_strut_order(conn0, N, B, tile_start, tile_of, c->bperm);
+    for (int64_t b = 0; b < B; ++b) {
+      conn[2 * b] = conn0[2 * (size_t)c->bperm[b]];
+      conn[2 * b + 1] = conn0[2 * (size_t)c->bperm[b] + 1];
+    }
+  }
+  std::vector<double> radius(B), seg_len((size_t)B * 3);
+  std::vector<int32_t> seg_nsub((size_t)B * 3);
+  for (int64_t b = 0; b < B; ++b) {
+    const size_t ob = (size_t)c->bperm[b];
+    radius[b] = m->beam_radius[ob];
+    for (int k = 0; k < 3; ++k) {
+      seg_len[3 * b + k] = m->seg_len[3 * ob + k];
+      seg_nsub[3 * b + k] = m->seg_nsub[3 * ob + k];
+    }
+  }
 
   PL_HIPC(c->xyz.alloc(N * 3));
   PL_HIPC(c->conn.alloc(B * 2));
@@ -479,13 +548,13 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(c->rec.alloc(B));
   PL_HIPC(hipMemcpy(c->xyz.p, xyz.data(), xyz.size() * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->conn.p, conn.data(), conn.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  PL_HIPC(hipMemcpy(c->radius.p, m->beam_radius, B * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIPC(hipMemcpy(c->seg_len.p, m->seg_len, 3 * B * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIPC(hipMemcpy(c->seg_nsub.p, m->seg_nsub, 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->radius.p, radius.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->seg_len.p, seg_len.data(), 3 * B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->seg_nsub.p, seg_nsub.data(), 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_TRY(build_incidence(c, conn));
-  if (o->spmv_kernel == 3) {
-    int rc = pl::build_tile_plan(c->tile, conn, N, B);
-    if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed"));
+  {
+    int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
+    if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
 
   const size_t n6 = (size_t)N * 6;
@@ -495,7 +564,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(c->f.alloc(n6));
   for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
     PL_HIPC(v->alloc(n6));
-  PL_HIPC(c->scal.alloc(pl::S_COUNT));
+  PL_HIPC(c->scal.alloc(pl::S_COUNT * pl::kSlots));
   PL_HIPC(hipMemset(c->fixed.p, 0, n6));
   PL_HIPC(hipMemset(c->fixedbits.p, 0, N));
   PL_HIPC(hipMemset(c->ubar.p, 0, n6 * sizeof(double)));
@@ -552,7 +621,9 @@ int pl_update_radii(pl_handle h, const double *beam_radius) {
   for (int64_t b = 0; b < h->B; ++b)
     if (!(beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_update_radii: non-positive radius");
   PL_HIP(hipSetDevice(h->opt.device));
-  PL_HIP(hipMemcpy(h->radius.p, beam_radius, h->B * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double> radius(h->B);
+  for (int64_t b = 0; b < h->B; ++b) radius[b] = beam_radius[h->bperm[b]];
+  PL_HIP(hipMemcpy(h->radius.p, radius.data(), h->B * sizeof(double), hipMemcpyHostToDevice));
   h->assembled = false;
   h->have_bsr = false;
   return PL_OK;
@@ -561,8 +632,15 @@ int pl_update_radii(pl_handle h, const double *beam_radius) {
 int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_nsub) {
   if (!valid(h) || !seg_len || !seg_nsub) return fail(PL_ERR_ARG, "pl_update_segments: null argument");
   PL_HIP(hipSetDevice(h->opt.device));
-  PL_HIP(hipMemcpy(h->seg_len.p, seg_len, 3 * h->B * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIP(hipMemcpy(h->seg_nsub.p, seg_nsub, 3 * h->B * sizeof(int32_t), hipMemcpyHostToDevice));
+  std::vector<double> sl((size_t)h->B * 3);
+  std::vector<int32_t> sn((size_t)h->B * 3);
+  for (int64_t b = 0; b < h->B; ++b)
+    for (int k = 0; k < 3; ++k) {
+      sl[3 * b + k] = seg_len[3 * (size_t)h->bperm[b] + k];
+      sn[3 * b + k] = seg_nsub[3 * (size_t)h->bperm[b] + k];
+    }
+  PL_HIP(hipMemcpy(h->seg_len.p, sl.data(), 3 * h->B * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->seg_nsub.p, sn.data(), 3 * h->B * sizeof(int32_t), hipMemcpyHostToDevice));
   h->assembled = false;
   h->have_bsr = false;
   return PL_OK;
@@ -730,8 +808,10 @@ int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
   hipLaunchKernelGGL(pl::k_sens, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
                      h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mat, h->tmp.p, lam_dev, out.p);
   PL_HIP(hipGetLastError());
-  PL_HIP(hipMemcpyAsync(dCdr, out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> tmp(h->B);
+  PL_HIP(hipMemcpyAsync(tmp.data(), out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
+  for (int64_t b = 0; b < h->B; ++b) dCdr[h->bperm[b]] = tmp[b];
   return PL_OK;
 }
 
@@ -742,12 +822,16 @@ int pl_energy(pl_handle h, const double *u, double *energy) {
   std::vector<double> stage;
   int rc = upload6(h, u, h->tmp.p, stage);
   if (rc) return rc;
-  PL_HIP(hipMemsetAsync(h->scal.p + 7, 0, sizeof(double), h->stream));
+  double *aux = h->scal.p + pl::S_AUX * pl::kSlots;
+  double h_aux[pl::kSlots];
+  PL_HIP(hipMemsetAsync(aux, 0, sizeof(h_aux), h->stream));
   hipLaunchKernelGGL(pl::k_energy, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->conn.p, h->rec.p,
-                     h->tmp.p, h->scal.p + 7);
+                     h->tmp.p, aux);
   PL_HIP(hipGetLastError());
-  PL_HIP(hipMemcpyAsync(energy, h->scal.p + 7, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipMemcpyAsync(h_aux, aux, sizeof(h_aux), hipMemcpyDeviceToHost, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
+  *energy = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) *energy += h_aux[k];
   return PL_OK;
 }
 
@@ -786,7 +870,9 @@ int pl_get_records(pl_handle h, double *rec) {
   if (!valid(h) || !rec) return fail(PL_ERR_ARG, "pl_get_records: null argument");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_get_records: call pl_assemble first");
   PL_HIP(hipSetDevice(h->opt.device));
-  PL_HIP(hipMemcpy(rec, h->rec.p, h->B * sizeof(pl::Record), hipMemcpyDeviceToHost));
+  std::vector<pl::Record> tmp(h->B);
+  PL_HIP(hipMemcpy(tmp.data(), h->rec.p, h->B * sizeof(pl::Record), hipMemcpyDeviceToHost));
+  for (int64_t b = 0; b < h->B; ++b) std::memcpy(rec + 8 * (size_t)h->bperm[b], &tmp[b], sizeof(pl::Record));
   return PL_OK;
 }
 
@@ -812,7 +898,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   auto one = [&](int k) -> int {
     switch (which) {
-      case 0: return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP);
+      case 0: return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots);
       case 1: return launch_records(h);
       case 2: return launch_bsr_fill(h, 0);
       case 3: return pcg_iteration(h, k);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_mask_dot_w(int64_t n6, const uint8_t
   }
   if (dot_out) {
     const double t = block_sum(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out, t);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), t);
   }
 }
 
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_w(int64_t n6, const doubl
                                                          double *__restrict__ r, double *__restrict__ z,
                                                          double *__restrict__ scal) {
   __shared__ double red[2][kBlock / kWave];
-  const double pap = scal[S_PAP];
-  const double alpha = (pap != 0.0) ? scal[S_RZ_OLD] / pap : 0.0;
+  const double pap = scalar_read(scal, S_PAP);
+  const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
   double rz = 0.0, rr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * kBlock) {
     const double xv = x[i] + alpha * p[i];
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_w(int64_t n6, const doubl
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
-    unsafeAtomicAdd(scal + S_RZ_NEW, a);
-    unsafeAtomicAdd(scal + S_RR, b);
+    scalar_add(scal, S_RZ_NEW, a);
+    scalar_add(scal, S_RR, b);
   }
 }
 
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init_w(int64_t n6, const double 
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
-    unsafeAtomicAdd(scal + S_RZ_OLD, a);
-    unsafeAtomicAdd(scal + S_BB, b);
+    scalar_add(scal, S_RZ_OLD, a);
+    scalar_add(scal, S_BB, b);
   }
 }
 

@@ -6,6 +6,9 @@ namespace pl {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+constexpr int kDefaultLPN = 4;          // lanes per node in the gather kernels (64 / LPN nodes per wave / ELL slice)
+constexpr int kSlots = 32;              // every device-side reduction scalar is spread over 32 atomics targets:
+                                        // 2000+ blocks adding into ONE address serialise at the memory side
 
 // blockIdx -> logical block so that each of the 8 XCDs (blocks are dealt round-robin, b and b+8 share an XCD and
 // its private 4 MiB L2) walks one CONTIGUOUS eighth of the node/strut range: struts and their end nodes are then
@@ -19,6 +22,19 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblk) {
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Reduction scalars live as kSlots partial sums; slot chosen by block so concurrent blocks rarely collide.
+__device__ __forceinline__ void scalar_add(double *scal, int which, double v) {
+  unsafeAtomicAdd(scal + which * kSlots + (blockIdx.x & (kSlots - 1)), v);
+}
+// Every lane of the calling wave gets the total.
+__device__ __forceinline__ double scalar_read(const double *scal, int which) {
+  const int lane = threadIdx.x & 63;
+  double v = (lane < kSlots) ? scal[which * kSlots + lane] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atomic(int64_t B, const int32_t
   unsafeAtomicAdd(ya + 3, MA.x); unsafeAtomicAdd(ya + 4, MA.y); unsafeAtomicAdd(ya + 5, MA.z);
 }
 
-// y = mask .* y (atomic variant post-pass), optionally accumulating dot(x, y).
+// y = mask .* y (atomic variant post-pass), optionally accumulating dot(x, y) into dot_out[kSlots].
 __global__ __launch_bounds__(kBlock) void k_mask_dot(int64_t n6, const uint8_t *__restrict__ fixed,
                                                      const double *__restrict__ x, double *__restrict__ y,
                                                      double *__restrict__ dot_out) {
@@ -107,16 +123,26 @@ __global__ __launch_bounds__(kBlock) void k_mask_dot(int64_t n6, const uint8_t *
   }
   if (dot_out) {
     const double t = block_sum(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out, t);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), t);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K*x, variant 2: one thread per node, gather over the incident struts (sliced ELL, slice = 64 nodes = one wave).
-// No atomics, bitwise reproducible.  ent[slice_ptr[s] + j*64 + lane] = (other node, strut | end<<31); other < 0 = pad.
+// K*x, variant 2: per-node gather over the incident struts.  kLPN = 4 lanes share one node (16 nodes per wave), so a
+// 12-valent Octet node is three loop trips per lane and the launch has 4x the waves of a lane-per-node mapping.
+// Sliced ELL, one slice = 16 nodes = one wave:  ent[slice_ptr[s] + j*16 + n] = j-th strut of node 16 s + n as
+// (other node, strut | end<<31), other < 0 = padding; slice width is a multiple of 4 so that lane = (j%4)*16 + n
+// reads 64 consecutive entries per trip.  No atomics, bitwise reproducible.
 // fixedbits[node] holds the 6 Dirichlet flags; MASK=true gives y = P K x (x is assumed to be 0 on fixed dofs).
 // ---------------------------------------------------------------------------------------------------------
-template <bool MASK, bool DOT>
+template <int LPN>
+__device__ __forceinline__ double lpn_sum(double v) {
+#pragma unroll
+  for (int o = kWave / LPN; o < kWave; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPN, bool MASK, bool DOT>
 __global__ __launch_bounds__(kBlock) void k_spmv_gather(int64_t N, const int64_t *__restrict__ slice_ptr,
                                                         const int2 *__restrict__ ent, const Record *__restrict__ rec,
                                                         const uint8_t *__restrict__ fixedbits,
@@ -124,55 +150,70 @@ __global__ __launch_bounds__(kBlock) void k_spmv_gather(int64_t N, const int64_t
                                                         double *__restrict__ dot_out) {
   __shared__ double red[kBlock / kWave];
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
-  const int64_t i = (int64_t)blk * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int64_t slice = i >> 6;
+  constexpr int kSliceNodes = kWave / LPN;
+  const int lane = threadIdx.x & 63, sub = lane / kSliceNodes;
+  const int64_t slice = (int64_t)blk * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t i = slice * kSliceNodes + (lane & (kSliceNodes - 1));
   double acc = 0.0;
-  if (i < N) {
-    V3 us, ts;
-    load6(x + 6 * i, us, ts);
+  if (slice * kSliceNodes < N) {          // wave-uniform
+    const bool live = i < N;
+    V3 us = {0, 0, 0}, ts = {0, 0, 0};
+    if (live) load6(x + 6 * i, us, ts);
     V3 F = {0, 0, 0}, M = {0, 0, 0};
     const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+#pragma unroll 2
     for (int64_t p = p0 + lane; p < p1; p += 64) {
       const int2 e = ent[p];
       if (e.x >= 0) {
         Record r = load_record(rec, e.y & 0x7fffffff);
-        if (e.y < 0) r = reversed(r);   // this node is the strut's point1
         V3 uo, to, f, m;
         load6(x + 6 * (int64_t)e.x, uo, to);
+        if (e.y < 0) r = reversed(r);   // this node is the strut's point1
         tip_force(r, uo, to, us, ts, f, m);
         F = F + f;
         M = M + m;
       }
     }
-    double out[6] = {F.x, F.y, F.z, M.x, M.y, M.z};
-    if (MASK) {
-      const unsigned fb = fixedbits[i];
+    double out[6] = {lpn_sum<LPN>(F.x), lpn_sum<LPN>(F.y), lpn_sum<LPN>(F.z),
+                     lpn_sum<LPN>(M.x), lpn_sum<LPN>(M.y), lpn_sum<LPN>(M.z)};
+    if (live) {
+      if (MASK) {
+        const unsigned fb = fixedbits[i];
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (fb & (1u << k)) out[k] = 0.0;
+        for (int k = 0; k < 6; ++k)
+          if (fb & (1u << k)) out[k] = 0.0;
+      }
+      double2 *q = reinterpret_cast<double2 *>(y + 6 * i);
+      if (LPN >= 4) {   // lanes sub = 0,1,2 of a node store one 16-byte third of its row each
+        if (sub == 0) q[0] = {out[0], out[1]};
+        else if (sub == 1) q[1] = {out[2], out[3]};
+        else if (sub == 2) q[2] = {out[4], out[5]};
+      } else if (sub == 0) {
+        q[0] = {out[0], out[1]};
+        q[1] = {out[2], out[3]};
+        q[2] = {out[4], out[5]};
+      }
+      if (DOT && sub == 0)
+        acc = us.x * out[0] + us.y * out[1] + us.z * out[2] + ts.x * out[3] + ts.y * out[4] + ts.z * out[5];
     }
-    double2 *q = reinterpret_cast<double2 *>(y + 6 * i);
-    q[0] = {out[0], out[1]};
-    q[1] = {out[2], out[3]};
-    q[2] = {out[4], out[5]};
-    if (DOT) acc = us.x * out[0] + us.y * out[1] + us.z * out[2] + ts.x * out[3] + ts.y * out[4] + ts.z * out[5];
   }
   if (DOT) {
     const double t = block_sum(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out, t);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), t);
   }
 }
 
 // Jacobi diagonal (and its inverse on free dofs) by the same gather.  dinv = 1/diag on free dofs, 0 on fixed.
+template <int LPN>
 __global__ __launch_bounds__(kBlock) void k_diag_gather(int64_t N, const int64_t *__restrict__ slice_ptr,
                                                         const int2 *__restrict__ ent, const Record *__restrict__ rec,
                                                         const uint8_t *__restrict__ fixedbits,
                                                         double *__restrict__ diag, double *__restrict__ dinv) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t slice = i >> 6;
+  constexpr int kSliceNodes = kWave / LPN;
+  const int lane = threadIdx.x & 63, sub = lane / kSliceNodes;
+  const int64_t slice = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t i = slice * kSliceNodes + (lane & (kSliceNodes - 1));
+  if (slice * kSliceNodes >= N) return;
   double dg[6] = {0, 0, 0, 0, 0, 0};
   const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
   for (int64_t p = p0 + lane; p < p1; p += 64) {
@@ -186,18 +227,24 @@ __global__ __launch_bounds__(kBlock) void k_diag_gather(int64_t N, const int64_t
       for (int k = 0; k < 6; ++k) dg[k] += t[k];
     }
   }
-  const unsigned fb = fixedbits ? fixedbits[i] : 0u;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    diag[6 * i + k] = dg[k];
-    if (dinv) dinv[6 * i + k] = ((fb >> k) & 1u) || dg[k] == 0.0 ? 0.0 : 1.0 / dg[k];
+  for (int k = 0; k < 6; ++k) dg[k] = lpn_sum<LPN>(dg[k]);
+  if (i < N && sub == 0) {
+    const unsigned fb = fixedbits ? fixedbits[i] : 0u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      diag[6 * i + k] = dg[k];
+      if (dinv) dinv[6 * i + k] = (((fb >> k) & 1u) || dg[k] == 0.0) ? 0.0 : 1.0 / dg[k];
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BSR(6x6) numeric fill: one thread per block row.  Row i holds [diag block] + one block per incident strut,
-// in the order given by blk_of_entry (columns sorted at setup).  with_bc: dolfinx Dirichlet treatment.
+// BSR(6x6) numeric fill, same lane mapping: every lane writes the off-diagonal blocks of its entries, the diagonal
+// block is the lane-group sum of the Kss blocks.  Row i holds [diag block] + one block per incident strut, columns
+// ascending (slots fixed at setup).  with_bc: dolfinx Dirichlet treatment (rows/cols zeroed, unit diagonal).
 // ---------------------------------------------------------------------------------------------------------
+template <int LPN>
 __global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *__restrict__ slice_ptr,
                                                      const int2 *__restrict__ ent, const Record *__restrict__ rec,
                                                      const int64_t *__restrict__ rowptr,
@@ -205,16 +252,18 @@ __global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *_
                                                      const int32_t *__restrict__ diag_slot,
                                                      const uint8_t *__restrict__ fixedbits, int with_bc,
                                                      double *__restrict__ vals) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t slice = i >> 6;
+  constexpr int kSliceNodes = kWave / LPN;
+  const int lane = threadIdx.x & 63, sub = lane / kSliceNodes;
+  const int64_t slice = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t i = slice * kSliceNodes + (lane & (kSliceNodes - 1));
+  if (slice * kSliceNodes >= N) return;
+  const bool live = i < N;
   double Kd[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) Kd[k] = 0.0;
-  const unsigned fi = (with_bc && fixedbits) ? fixedbits[i] : 0u;
+  const unsigned fi = (live && with_bc && fixedbits) ? fixedbits[i] : 0u;
   const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
-  const int64_t row0 = rowptr[i];
+  const int64_t row0 = live ? rowptr[i] : 0;
   for (int64_t p = p0 + lane; p < p1; p += 64) {
     const int2 e = ent[p];
     if (e.x >= 0) {
@@ -234,14 +283,18 @@ __global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *_
         }
     }
   }
-  double *dd = vals + 36 * (row0 + diag_slot[i]);
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+  for (int k = 0; k < 36; ++k) Kd[k] = lpn_sum<LPN>(Kd[k]);
+  if (live && sub == 0) {
+    double *dd = vals + 36 * (row0 + diag_slot[i]);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const bool fa = (fi >> a) & 1u, fb = (fi >> b) & 1u;
-      dd[a * 6 + b] = (fa || fb) ? ((a == b) ? 1.0 : 0.0) : Kd[a * 6 + b];
-    }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const bool fa = (fi >> a) & 1u, fb = (fi >> b) & 1u;
+        dd[a * 6 + b] = (fa || fb) ? ((a == b) ? 1.0 : 0.0) : Kd[a * 6 + b];
+      }
+  }
 }
 
 // y = A x for the assembled BSR matrix: one thread per block row (cross-check path).
@@ -265,9 +318,9 @@ __global__ __launch_bounds__(kBlock) void k_bsr_spmv(int64_t N, const int64_t *_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// PCG vector kernels.  scal[] lives on the device: 0 rz_old, 1 pAp, 2 rz_new, 3 rr, 4 bb.
+// PCG vector kernels.  Reduction scalars live on the device as kSlots partial sums each: scal[which*kSlots + slot].
 // ---------------------------------------------------------------------------------------------------------
-enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_COUNT = 8 };
+enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_AUX = 5, S_COUNT = 8 };
 
 // x += alpha p ; r -= alpha Ap ; z = dinv r ; rz_new += r.z ; rr += r.r      (alpha = rz_old / pAp)
 __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double *__restrict__ p,
@@ -276,8 +329,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
                                                        double *__restrict__ r, double *__restrict__ z,
                                                        double *__restrict__ scal) {
   __shared__ double red[2][kBlock / kWave];
-  const double pap = scal[S_PAP];
-  const double alpha = (pap != 0.0) ? scal[S_RZ_OLD] / pap : 0.0;
+  const double pap = scalar_read(scal, S_PAP);
+  const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
   double rz = 0.0, rr = 0.0;
   const int64_t n2 = n6 >> 1;   // n6 is even (6 per node)
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
@@ -303,16 +356,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
-    unsafeAtomicAdd(scal + S_RZ_NEW, a);
-    unsafeAtomicAdd(scal + S_RR, b);
+    scalar_add(scal, S_RZ_NEW, a);
+    scalar_add(scal, S_RR, b);
   }
 }
 
 // p = z + beta p   (beta = rz_new / rz_old)
 __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const double *__restrict__ z,
                                                           double *__restrict__ p, const double *__restrict__ scal) {
-  const double old = scal[S_RZ_OLD];
-  const double beta = (old != 0.0) ? scal[S_RZ_NEW] / old : 0.0;
+  const double old = scalar_read(scal, S_RZ_OLD);
+  const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   const int64_t n2 = n6 >> 1;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     const double2 zv = reinterpret_cast<const double2 *>(z)[i];
@@ -323,13 +376,17 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const doub
   }
 }
 
-// End of iteration k: record ||r||^2, rotate the scalars.
+// End of iteration k: record ||r||^2, rotate the scalars (launch with kSlots threads).
 __global__ void k_pcg_rotate(double *__restrict__ scal, double *__restrict__ hist, int k) {
-  hist[k] = scal[S_RR];
-  scal[S_RZ_OLD] = scal[S_RZ_NEW];
-  scal[S_RZ_NEW] = 0.0;
-  scal[S_RR] = 0.0;
-  scal[S_PAP] = 0.0;
+  const int s = threadIdx.x;
+  const double rr = scalar_read(scal, S_RR);
+  if (s == 0) hist[k] = rr;
+  if (s < kSlots) {
+    scal[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
+    scal[S_RZ_NEW * kSlots + s] = 0.0;
+    scal[S_RR * kSlots + s] = 0.0;
+    scal[S_PAP * kSlots + s] = 0.0;
+  }
 }
 
 // r = mask.*(f - y) ; z = dinv r ; p = z ; x = 0 ; rz_old = r.z ; bb = r.r
@@ -359,8 +416,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(int64_t n6, const double *_
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
-    unsafeAtomicAdd(scal + S_RZ_OLD, a);
-    unsafeAtomicAdd(scal + S_BB, b);
+    scalar_add(scal, S_RZ_OLD, a);
+    scalar_add(scal, S_BB, b);
   }
 }
 
@@ -421,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_energy(int64_t B, const int32_t *__r
     e = 0.5 * (dot(F, uB - uA + cross(d, tA)) + dot(M, tB - tA));
   }
   const double t = block_sum(e, red);
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, t);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out + (blockIdx.x & (kSlots - 1)), t);
 }
 
 // gather / scatter helpers for the node permutation and interface packing

@@ -1,20 +1,36 @@
-// Node ordering + the LDS-tile operator of libpylattice_hip (gfx950).
+// Node ordering + the LDS-tile K*x operator of libpylattice_hip (gfx950).
+//
+// Variant 3 of K*x ("one thread per strut, accumulate in LDS"):
+//   * nodes are renumbered brick by brick (spatial_order) and cut into TILES of consecutive nodes (<= kTileMaxNodes);
+//   * struts are renumbered by HOME tile = the lower of their two end tiles, so a tile's home struts are one
+//     contiguous range whose 64-byte records and connectivity stream in fully coalesced; struts whose other end
+//     lies in a higher tile are additionally listed in that tile's FOREIGN list (their record is read a second time,
+//     from L2 when the two tiles run on the same XCD);
+//   * one 256-thread workgroup per tile: every thread evaluates whole struts (both end forces), adds the ends that
+//     belong to the tile into an LDS accumulator with ds_add_f64, and the tile's rows of y are written once,
+//     coalesced, with the Dirichlet mask and the p.Ap partial dot product fused in.
+// No global atomics; the only non-determinism is the order of the LDS adds.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <numeric>
 #include <vector>
 
 #include "pl_kernels.h"
 
 namespace pl {
 
-// Spatial order of the nodes: the bounding box is cut into cubic bricks of `brick` average-spacing units, bricks
-// are walked x-slab by x-slab (so an XCD's contiguous share of the node range is a slab of the lattice) and the
-// nodes of one brick are contiguous.  perm[new] = old.
-inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &perm, double nodes_per_brick = 256.0) {
+constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 24 KiB per workgroup
+
+// Spatial order of the nodes: the bounding box is cut into cubic bricks holding ~nodes_per_brick nodes, bricks are
+// walked x-slab by x-slab (an XCD's contiguous share of the tile range is then a slab of the lattice) and the nodes
+// of one brick are contiguous.  perm[new] = old.  tile_start gets the brick boundaries (bricks larger than
+// kTileMaxNodes are cut), ending with N.
+inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &perm, std::vector<int32_t> &tile_start,
+                          double nodes_per_brick = 256.0) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int64_t i = 0; i < N; ++i)
     for (int k = 0; k < 3; ++k) {
@@ -22,26 +38,214 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
       hi[k] = std::max(hi[k], xyz[3 * i + k]);
     }
   double vol = 1.0;
-  for (int k = 0; k < 3; ++k) vol *= std::max(hi[k] - lo[k], 1e-300);
-  const double side = std::cbrt(vol * nodes_per_brick / (double)std::max<int64_t>(N, 1));
+  int dims = 0;
+  for (int k = 0; k < 3; ++k)
+    if (hi[k] - lo[k] > 0) {
+      vol *= hi[k] - lo[k];
+      ++dims;
+    }
+  const double side = dims ? std::pow(vol * nodes_per_brick / (double)std::max<int64_t>(N, 1), 1.0 / dims) : 1.0;
   int64_t nb[3];
   for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / side));
   std::vector<int64_t> key(N);
   for (int64_t i = 0; i < N; ++i) {
     int64_t c[3];
     for (int k = 0; k < 3; ++k)
-      c[k] = std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / side));
+      c[k] = std::max<int64_t>(0, std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / side)));
     key[i] = (c[0] * nb[1] + c[1]) * nb[2] + c[2];
   }
   std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  tile_start.clear();
+  int64_t run0 = 0;
+  for (int64_t i = 0; i <= N; ++i) {
+    if (i == N || (i > 0 && key[perm[i]] != key[perm[i - 1]])) {
+      // close run [run0, i): cut into equal pieces of at most kTileMaxNodes
+      const int64_t len = i - run0;
+      const int64_t pieces = (len + kTileMaxNodes - 1) / kTileMaxNodes;
+      for (int64_t q = 0; q < pieces; ++q) tile_start.push_back((int32_t)(run0 + q * len / pieces));
+      run0 = i;
+    }
+  }
+  tile_start.push_back((int32_t)N);
 }
 
-// LDS-tile operator (variant 3) — plan is built on demand; see pl_tile_impl below.
+// Tiles for an un-reordered numbering: plain chunks of 256 consecutive nodes.
+inline void chunk_tiles(int64_t N, std::vector<int32_t> &tile_start, int chunk = 256) {
+  tile_start.clear();
+  for (int64_t i = 0; i < N; i += chunk) tile_start.push_back((int32_t)i);
+  tile_start.push_back((int32_t)N);
+}
+
+template <typename T>
+struct TBuf {
+  T *p = nullptr;
+  ~TBuf() { if (p) (void)hipFree(p); }
+  hipError_t upload(const std::vector<T> &v) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    const size_t n = std::max<size_t>(1, v.size());
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};
+
 struct TilePlan {
   bool ready = false;
+  int64_t n_tiles = 0;
+  TBuf<int32_t> tile_start;     // [n_tiles+1] node range of each tile
+  TBuf<int64_t> home_ptr;       // [n_tiles+1] strut range of each tile (struts are numbered by home tile)
+  TBuf<int64_t> foreign_ptr;    // [n_tiles+1]
+  TBuf<int32_t> foreign_idx;    // strut ids
+  int64_t n_foreign = 0;
 };
-inline int build_tile_plan(TilePlan &, const std::vector<int32_t> &, int64_t, int64_t) { return 0; }
-inline void launch_tile_spmv(TilePlan &, const Record *, const uint8_t *, const double *, double *, double *,
-                             hipStream_t) {}
+
+// Computes the strut permutation (bperm[new] = old) that numbers struts by home tile and, inside a tile, so that
+// consecutive struts touch different nodes (LDS atomics of one wave instruction then hit distinct addresses).
+inline void tile_strut_order(const std::vector<int32_t> &conn, int64_t N, int64_t B,
+                             const std::vector<int32_t> &tile_start, std::vector<int32_t> &tile_of,
+                             std::vector<int32_t> &bperm) {
+  const int64_t T = (int64_t)tile_start.size() - 1;
+  tile_of.assign(N, 0);
+  for (int64_t t = 0; t < T; ++t)
+    for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of[i] = (int32_t)t;
+  std::vector<int32_t> home(B), occ(B);
+  std::vector<int32_t> cnt(N, 0);
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t a = conn[2 * b], d = conn[2 * b + 1];
+    home[b] = std::min(tile_of[a], tile_of[d]);
+    const int32_t pivot = tile_of[d] == home[b] ? d : a;   // an end that lies in the home tile
+    occ[b] = cnt[pivot]++;
+  }
+  bperm.resize(B);
+  std::iota(bperm.begin(), bperm.end(), 0);
+  std::stable_sort(bperm.begin(), bperm.end(), [&](int32_t l, int32_t r) {
+    if (home[l] != home[r]) return home[l] < home[r];
+    return occ[l] < occ[r];
+  });
+}
+
+// conn must already be in the NEW strut numbering.
+inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int64_t N, int64_t B,
+                           const std::vector<int32_t> &tile_start, const std::vector<int32_t> &tile_of) {
+  const int64_t T = (int64_t)tile_start.size() - 1;
+  std::vector<int64_t> home_ptr(T + 1, 0), foreign_ptr(T + 1, 0);
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t ta = tile_of[conn[2 * b]], tb = tile_of[conn[2 * b + 1]];
+    home_ptr[std::min(ta, tb) + 1]++;
+    if (ta != tb) foreign_ptr[std::max(ta, tb) + 1]++;
+  }
+  for (int64_t t = 0; t < T; ++t) {
+    home_ptr[t + 1] += home_ptr[t];
+    foreign_ptr[t + 1] += foreign_ptr[t];
+  }
+  std::vector<int32_t> foreign_idx((size_t)foreign_ptr[T]);
+  std::vector<int64_t> fill(foreign_ptr.begin(), foreign_ptr.end() - 1);
+  int64_t prev_home = -1;
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t ta = tile_of[conn[2 * b]], tb = tile_of[conn[2 * b + 1]];
+    const int64_t h = std::min(ta, tb);
+    if (h < prev_home) return 1;   // struts are not numbered by home tile
+    prev_home = h;
+    if (ta != tb) foreign_idx[fill[std::max(ta, tb)]++] = (int32_t)b;
+  }
+  for (int64_t t = 0; t < T; ++t)
+    if (tile_start[t + 1] - tile_start[t] > kTileMaxNodes) return 2;
+  plan.n_tiles = T;
+  plan.n_foreign = foreign_ptr[T];
+  if (plan.tile_start.upload(tile_start) != hipSuccess) return 3;
+  if (plan.home_ptr.upload(home_ptr) != hipSuccess) return 3;
+  if (plan.foreign_ptr.upload(foreign_ptr) != hipSuccess) return 3;
+  if (plan.foreign_idx.upload(foreign_idx) != hipSuccess) return 3;
+  plan.ready = true;
+  return 0;
+}
+
+__device__ __forceinline__ void lds_add6(double *dst, V3 f, V3 m) {
+  unsafeAtomicAdd(dst + 0, f.x);
+  unsafeAtomicAdd(dst + 1, f.y);
+  unsafeAtomicAdd(dst + 2, f.z);
+  unsafeAtomicAdd(dst + 3, m.x);
+  unsafeAtomicAdd(dst + 4, m.y);
+  unsafeAtomicAdd(dst + 5, m.z);
+}
+
+__device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
+                                           const Record *__restrict__ rec, const double *__restrict__ x,
+                                           double *ys) {
+  const int2 c = conn2[b];
+  const Record r = load_record(rec, b);
+  V3 uA, tA, uB, tB, F, M;
+  load6(x + 6 * (int64_t)c.x, uA, tA);
+  load6(x + 6 * (int64_t)c.y, uB, tB);
+  tip_force(r, uA, tA, uB, tB, F, M);
+  if (c.y >= n0 && c.y < n1) lds_add6(ys + 6 * (c.y - n0), F, M);
+  if (c.x >= n0 && c.x < n1) {
+    const V3 d = {r.dx, r.dy, r.dz};
+    lds_add6(ys + 6 * (c.x - n0), (-1.0) * F, (-1.0) * M - cross(d, F));
+  }
+}
+
+template <bool MASK, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
+                                                      const int64_t *__restrict__ home_ptr,
+                                                      const int64_t *__restrict__ foreign_ptr,
+                                                      const int32_t *__restrict__ foreign_idx,
+                                                      const int2 *__restrict__ conn2, const Record *__restrict__ rec,
+                                                      const uint8_t *__restrict__ fixedbits,
+                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      double *__restrict__ dot_out) {
+  __shared__ double ys[kTileMaxNodes * 6];
+  __shared__ double red[kBlock / kWave];
+  const unsigned t = xcd_block(blockIdx.x, gridDim.x);
+  const int n0 = tile_start[t], n1 = tile_start[t + 1];
+  const int nn = n1 - n0;
+  for (int i = threadIdx.x; i < nn * 6; i += kBlock) ys[i] = 0.0;
+  __syncthreads();
+  const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
+#pragma unroll 2
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut(b, n0, n1, conn2, rec, x, ys);
+  const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
+#pragma unroll 2
+  for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock) tile_strut(foreign_idx[k], n0, n1, conn2, rec, x, ys);
+  __syncthreads();
+  double acc = 0.0;
+  const double2 *ys2 = reinterpret_cast<const double2 *>(ys);
+  double2 *y2 = reinterpret_cast<double2 *>(y) + 3 * (int64_t)n0;
+  const double2 *x2 = reinterpret_cast<const double2 *>(x) + 3 * (int64_t)n0;
+  for (int i = threadIdx.x; i < nn * 3; i += kBlock) {
+    double2 v = ys2[i];
+    if (MASK) {
+      const int node = i / 3, part = i - 3 * node;
+      const unsigned fb = fixedbits[n0 + node] >> (2 * part);
+      if (fb & 1u) v.x = 0.0;
+      if (fb & 2u) v.y = 0.0;
+    }
+    y2[i] = v;
+    if (DOT) {
+      const double2 xv = x2[i];
+      acc += xv.x * v.x + xv.y * v.y;
+    }
+  }
+  if (DOT) {
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+  }
+}
+
+inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint8_t *fixedbits,
+                             const double *x, double *y, double *dot_dev, hipStream_t s) {
+  const dim3 g((unsigned)plan.n_tiles), blk(kBlock);
+  const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
+#define PL_T(M, D)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_tile<M, D>), g, blk, 0, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
+                     plan.foreign_idx.p, conn2, rec, fixedbits, x, y, dot_dev)
+  if (fixedbits && dot_dev) PL_T(true, true);
+  else if (fixedbits) PL_T(true, false);
+  else if (dot_dev) PL_T(false, true);
+  else PL_T(false, false);
+#undef PL_T
+}
 
 }  // namespace pl

@@ -16,7 +16,7 @@ from pylatticedso_amd.utils_schur import get_schur_complement  # noqa: E402
 from pylatticedso_amd.utils_simulation import solve_FEM_FenicsX  # noqa: E402
 
 E, NU = 1013.0, 0.3
-KERNELS = [1, 2]
+KERNELS = [1, 2, 3]
 
 
 def _sim(golden_dir, name):
