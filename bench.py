@@ -47,6 +47,11 @@ def cantilever_bc(xyz, x_max, n_targets_global=None, weight=None):
     return fixed, f, tgt
 
 
+def dev_kernel_name(kernel, reorder):
+    k = kernel if kernel else (3 if reorder else 2)
+    return {1: "k_spmv_atomic", 2: "k_spmv_gather", 3: "k_spmv_tile"}[k]
+
+
 def cpu_baseline(cells, radius, rtol):
     """Plain-C oracle (1 thread) on a bounded sample of the same workload: same lattice type / BCs, fewer cells."""
     from oracle import c_oracle
@@ -167,6 +172,15 @@ def main():
     ms_bsr = dev.time_kernel(2, 10) if not args.no_bsr else None
     ab = dev.algorithmic_bytes()
     achieved = ab["spmv"] / (ms_spmv * 1e-3) / 1e9
+    # HBM bytes per K*p launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
+    # gfx950: FETCH_SIZE counts half of 16-B/lane streaming reads - see profiles/README.md).  Valid for the default
+    # single-GPU workload only.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
+    if world == 1 and n == 50 and args.geom == "Octet" and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if pmc.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder):
+            traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
 
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
@@ -180,9 +194,9 @@ def main():
                    "rel_residual": st["rel_residual"], "preconditioner": "Jacobi",
                    "step": "records + Jacobi diag" + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder},
-        "roofline": {"bound": "hbm", "kernel": "K*p (per-node gather over condensed struts)",
+        "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},
+                     "traffic": traffic, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"]},

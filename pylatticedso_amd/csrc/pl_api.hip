@@ -263,23 +263,24 @@ int launch_bsr_fill(pl_context *c, int with_bc) {
   return PL_OK;
 }
 
-// One PCG iteration (k = iteration index for the residual history).
+// One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
 int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
-  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, c->scal.p + pl::S_PAP * pl::kSlots);
+  const int set = pl::S_COUNT * pl::kSlots;
+  double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
+  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
-  if (c->dist.active) pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_PAP * pl::kSlots, pl::kSlots, c->stream);
   if (c->dist.active) {
-    pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p,
-                                   c->scal.p, c->stream);
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);
+    pl::dist_sum_scalars(c->dist, cur + pl::S_PAP * pl::kSlots, pl::kSlots, c->stream);
+    pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
+                                   c->stream);
+    pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);
   } else {
     hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->scal.p);
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur);
   }
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
-                     c->p.p, c->scal.p);
-  hipLaunchKernelGGL(pl::k_pcg_rotate, dim3(1), dim3(pl::kWave), 0, c->stream, c->scal.p, c->hist.p, k);
+                     c->p.p, cur, nxt, c->hist.p, k);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -290,7 +291,7 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   const int64_t n6 = c->N * 6;
   int rc = ensure_hist(c, max_iter + 1);
   if (rc) return rc;
-  PL_HIP(hipMemsetAsync(c->scal.p, 0, pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
   if (c->dist.active)
     pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
                                  c->z.p, c->p.p, c->scal.p, c->stream);
@@ -564,7 +565,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(c->f.alloc(n6));
   for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
     PL_HIPC(v->alloc(n6));
-  PL_HIPC(c->scal.alloc(pl::S_COUNT * pl::kSlots));
+  PL_HIPC(c->scal.alloc(2 * pl::S_COUNT * pl::kSlots));   // two sets, selected by iteration parity
   PL_HIPC(hipMemset(c->fixed.p, 0, n6));
   PL_HIPC(hipMemset(c->fixedbits.p, 0, N));
   PL_HIPC(hipMemset(c->ubar.p, 0, n6 * sizeof(double)));

@@ -361,11 +361,26 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
   }
 }
 
-// p = z + beta p   (beta = rz_new / rz_old)
+// p = z + beta p   (beta = rz_new / rz_old), and the end-of-iteration scalar bookkeeping: the reduction scalars are
+// double-buffered by iteration parity, so block 0 can record ||r||^2 and prepare the NEXT iteration's set
+// (rz_old <- rz_new, accumulators zeroed) while the other blocks still read the current one.
 __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const double *__restrict__ z,
-                                                          double *__restrict__ p, const double *__restrict__ scal) {
+                                                          double *__restrict__ p, const double *__restrict__ scal,
+                                                          double *__restrict__ scal_next, double *__restrict__ hist,
+                                                          int k) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < kWave) {
+    const double rr = scalar_read(scal, S_RR);
+    const int s = threadIdx.x;
+    if (s == 0) hist[k] = rr;
+    if (s < kSlots) {
+      scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
+      scal_next[S_RZ_NEW * kSlots + s] = 0.0;
+      scal_next[S_RR * kSlots + s] = 0.0;
+      scal_next[S_PAP * kSlots + s] = 0.0;
+    }
+  }
   const int64_t n2 = n6 >> 1;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     const double2 zv = reinterpret_cast<const double2 *>(z)[i];
@@ -373,19 +388,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const doub
     pv.x = zv.x + beta * pv.x;
     pv.y = zv.y + beta * pv.y;
     reinterpret_cast<double2 *>(p)[i] = pv;
-  }
-}
-
-// End of iteration k: record ||r||^2, rotate the scalars (launch with kSlots threads).
-__global__ void k_pcg_rotate(double *__restrict__ scal, double *__restrict__ hist, int k) {
-  const int s = threadIdx.x;
-  const double rr = scalar_read(scal, S_RR);
-  if (s == 0) hist[k] = rr;
-  if (s < kSlots) {
-    scal[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
-    scal[S_RZ_NEW * kSlots + s] = 0.0;
-    scal[S_RR * kSlots + s] = 0.0;
-    scal[S_PAP * kSlots + s] = 0.0;
   }
 }
 

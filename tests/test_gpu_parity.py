@@ -259,3 +259,71 @@ def test_ddm_golden_cross_check(golden_dir):
     L._device.close()
     assert len(xsol) == len(g["xsol"])
     assert _rel(xsol, g["xsol"]) < 5e-3
+
+
+def test_rccl_path_with_single_rank_communicator(golden_dir):
+    """The multi-GPU code path (RCCL communicator, interface pack / all-reduce / unpack, weighted dot products)
+    driven with world = 1 on the one GPU of the test box: results must equal the plain path."""
+    _, L = _sim(golden_dir, "bcc_4x4x4")
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    with _device(L) as ref:
+        ref.set_bc(L.fixed_DOF, None, f)
+        ref.assemble()
+        u0, st0 = ref.solve(rtol=1e-11)
+    shared = np.flatnonzero(lat.node_xyz[:, 1] == 2.0)          # pretend the plane y = 2 is a slab interface
+    with _device(L) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        u1, st1 = dev.solve(rtol=1e-11)
+        x = np.random.default_rng(0).standard_normal(6 * lat.n_nodes)
+        y1 = dev.spmv(x)
+    with _device(L) as ref:
+        ref.assemble()
+        y0 = ref.spmv(x)
+    assert _rel(y1, y0) < 1e-14
+    assert _rel(u1, u0) < 1e-9
+    assert abs(st1["iterations"] - st0["iterations"]) <= 2
+
+
+def test_full_size_properties_config2():
+    """BASELINE.json configs[1] (50^3 Octet, 3.03 M struts): size-independent properties of the device operator
+    and of the solve - symmetry, linearity, rigid-body null space, true residual, Clapeyron (f.u = u.K.u)."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 50
+    lat = LA.generate((1, 1, 1), (n, n, n), ["Octet"], [0.03])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    assert lat.n_beams == 3030000 and lat.n_nodes == 515151
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == float(n)
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    rng = np.random.default_rng(11)
+    for kernel in (3, 2):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              spmv_kernel=kernel) as dev:
+            dev.assemble()
+            a, b = rng.standard_normal((2, 6 * lat.n_nodes))
+            Ka, Kb = dev.spmv(a).ravel(), dev.spmv(b).ravel()
+            assert abs(b @ Ka - a @ Kb) < 1e-10 * abs(b @ Ka)
+            assert _rel(dev.spmv(a - 2.0 * b).ravel(), Ka - 2.0 * Kb) < 1e-12
+            om = np.array([0.3, -0.2, 0.5])
+            rigid = np.c_[np.cross(om, lat.node_xyz) + [1.0, 2.0, 3.0], np.tile(om, (lat.n_nodes, 1))]
+            assert np.abs(dev.spmv(rigid)).max() < 1e-7 * np.abs(Ka).max()
+            if kernel == 3:
+                dev.set_bc(fixed, None, f)
+                u, st = dev.solve(rtol=1e-8, max_iter=20000)
+                assert st["converged"] == 1
+                R = dev.spmv(u)
+                res = np.where(fixed != 0, 0.0, f - R)
+                assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8          # true residual, not the recurrence
+                assert abs((f * u).sum() - 2.0 * dev.energy(u)) < 1e-7 * abs((f * u).sum())
+                assert np.all(u[fixed != 0] == 0.0)
+                u_ref = u
+            else:
+                dev.set_bc(fixed, None, f)
+                u2, _ = dev.solve(rtol=1e-8, max_iter=20000)
+                assert _rel(u2, u_ref) < 1e-6                                    # two independent kernels agree
