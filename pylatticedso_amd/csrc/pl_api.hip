@@ -183,35 +183,21 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
     hipLaunchKernelGGL(pl::k_spmv_atomic, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
                        c->rec.p, x, y);
-    if (c->dist.active) {
-      int rc = pl::dist_sum_shared(c->dist, y, c->stream);
-      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
-      if (masked || dot_dev)
-        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
-    } else if (masked || dot_dev) {
+    if (masked || dot_dev)
       hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
-    }
   } else if (kind == 3 && c->tile.ready) {
-    const bool local_only = c->dist.active;
-    pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, (masked && !local_only) ? c->fixedbits.p : nullptr, x, y,
-                         local_only ? nullptr : dot_dev, c->stream);
-    if (local_only) {
-      int rc = pl::dist_sum_shared(c->dist, y, c->stream);
-      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
-      if (masked || dot_dev)
-        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
-    }
+    pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream);
   } else {
-    const bool local_only = c->dist.active;   // partial product first, interface sum across ranks, then mask + dot
-    int rc = dispatch_gather(c, x, y, masked && !local_only, local_only ? nullptr : dot_dev);
+    int rc = dispatch_gather(c, x, y, masked, dot_dev);
     if (rc) return rc;
-    if (local_only) {
-      rc = pl::dist_sum_shared(c->dist, y, c->stream);
-      if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
-      if (masked || dot_dev)
-        pl::launch_mask_dot_weighted(n6, masked ? c->fixed.p : nullptr, c->dist.weight.p, x, y, dot_dev, c->stream);
-    }
+  }
+  if (c->dist.active) {
+    // Every rank now holds the product of ITS struts.  The Dirichlet mask commutes with the sum over ranks, and
+    // x.(K x) = sum_r x_r.(K_r x_r) with the LOCAL partial products and NO multiplicity weights, so the kernels above
+    // ran exactly as on one GPU; the interface rows and the 32 slots of the partial dot travel in one all-reduce.
+    int rc = pl::dist_sum_shared(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
+    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
   }
   PL_HIP(hipGetLastError());
   return PL_OK;
@@ -271,7 +257,6 @@ int pcg_iteration(pl_context *c, int k) {
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
   if (c->dist.active) {
-    pl::dist_sum_scalars(c->dist, cur + pl::S_PAP * pl::kSlots, pl::kSlots, c->stream);
     pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
                                    c->stream);
     pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);

@@ -67,18 +67,30 @@ inline int dist_unique_id(void *out) {
   return 0;
 }
 
-// y[shared] <- sum over ranks of y[shared]
-inline int dist_sum_shared(Dist &d, double *y, hipStream_t s) {
-  if (!d.active || d.n_shared_global == 0) return 0;
-  const size_t n = (size_t)d.n_shared_global * 6;
-  if (hipMemsetAsync(d.pack.p, 0, n * sizeof(double), s) != hipSuccess) return 1;
+__global__ void k_copy_small(int n, const double *__restrict__ src, double *__restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// y[shared] <- sum over ranks of y[shared]; optionally `nscal` device scalars (e.g. the 32 slots of a LOCAL partial
+// dot product) ride in the tail of the same message and are summed over ranks too: ONE collective.
+inline int dist_sum_shared(Dist &d, double *y, hipStream_t s, double *scal = nullptr, int nscal = 0) {
+  if (!d.active) return 0;
+  const size_t nrow = (size_t)d.n_shared_global * 6;
+  const size_t n = nrow + (size_t)(scal ? nscal : 0);
+  if (n == 0) return 0;
+  if (nrow && hipMemsetAsync(d.pack.p, 0, nrow * sizeof(double), s) != hipSuccess) return 1;
   if (d.n_shared > 0)
     hipLaunchKernelGGL(k_pack_shared, dim3((unsigned)((d.n_shared * 6 + 255) / 256)), dim3(256), 0, s, d.n_shared,
                        d.local_idx.p, d.global_idx.p, y, d.pack.p);
+  if (scal && nscal > 0)
+    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((nscal + 63) / 64)), dim3(64), 0, s, nscal, scal, d.pack.p + nrow);
   if (ncclAllReduce(d.pack.p, d.pack.p, n, ncclDouble, ncclSum, d.comm, s) != ncclSuccess) return 2;
   if (d.n_shared > 0)
     hipLaunchKernelGGL(k_unpack_shared, dim3((unsigned)((d.n_shared * 6 + 255) / 256)), dim3(256), 0, s, d.n_shared,
                        d.local_idx.p, d.global_idx.p, d.pack.p, y);
+  if (scal && nscal > 0)
+    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((nscal + 63) / 64)), dim3(64), 0, s, nscal, d.pack.p + nrow, scal);
   return 0;
 }
 
@@ -98,7 +110,7 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
   d.n_shared_global = n_shared_global;
   if (d.local_idx.alloc(std::max(1, n_shared)) != hipSuccess) return 2;
   if (d.global_idx.alloc(std::max(1, n_shared)) != hipSuccess) return 2;
-  if (d.pack.alloc(std::max<size_t>(1, (size_t)n_shared_global * 6)) != hipSuccess) return 2;
+  if (d.pack.alloc((size_t)n_shared_global * 6 + 4 * kSlots) != hipSuccess) return 2;   // rows + scalar tail
   if (d.weight.alloc((size_t)N * 6) != hipSuccess) return 2;
   if (n_shared > 0) {
     if (hipMemcpy(d.local_idx.p, loc, n_shared * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return 3;

@@ -1,0 +1,379 @@
+"""Host-side mirror of the reference's ``LatticeOpti`` for the sensitivity pass of the hot path.
+
+Mirrors ``src/pyLatticeOpti/lattice_opti.py``: preset block ``optimization_informations`` (:228-256), the
+parameterisations ``constant`` / ``constant+hybrid`` / ``unit_cell`` / ``linear`` (:467-560, :1468-1485),
+normalisation (:1318-1400), ``objective`` (:430-465), ``compute_compliance`` (:645-663), ``gradient`` (:701-731) with
+its sign flip and ``(r_max − r_min)/C0`` scaling, and the SciPy SLSQP driver (:141-195, stays SciPy).
+
+What runs on the GPU: the equilibrium solve (``solve_FEM_FenicsX``), the adjoint solve for displacement objectives and
+the per-strut contraction ``λ_eᵀ (∂K_e/∂r) u_e`` (``pl_sens``) — the reference obtains the same quantity as
+``u_cellᵀ (∂S/∂r) u_cell`` with a finite-differenced cell Schur complement (``lattice_sim.py:1020-1054``), at fixed
+penalised-segment geometry (convention (i) of SURVEY.md appendix A).
+
+Out of scope here: the kriging relative-density surrogate; the density constraint uses the
+direct strut-volume formula instead.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .lattice_sim import LatticeSim, open_lattice_parameters
+from .utils_simulation import solve_FEM_FenicsX
+
+_DOF = {"X": 0, "Y": 1, "Z": 2, "RX": 3, "RY": 4, "RZ": 5}
+
+
+class LatticeOpti(LatticeSim):
+    def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0, convergence_plotting: bool = False):
+        info = open_lattice_parameters(name_file).get("optimization_informations", {})
+        if info.get("simulation_type", None) == "DDM":
+            raise NotImplementedError("simulation_type 'DDM' (Schur surrogate) is a 'next' row of SURVEY.md §8f; "
+                                      "use 'FEM'")
+        super().__init__(name_file, mesh_trimmer, verbose, False)
+        self.solution = None
+        self.actual_objective = None
+        self.denorm_objective = None
+        self.initial_value_objective = None
+        self.actualGradient = None
+        self.initial_parameters = None
+        self.bounds = None
+        self.constraints = []
+        self.iteration = 0
+        self.optim_ftol = 1e-6
+        self.optim_disp = True
+        self.optim_eps = 1e-3
+        self.actual_optimization_parameters = []
+        self._sim_is_current = False
+        self.min_radius = 0.01
+        self.max_radius = 0.1
+        self._history = {"iteration": [], "objective_norm": [], "objective": [], "relative_density": [],
+                         "parameters": [], "timestamp": []}
+        lat = self.lattice
+        self.size_x, self.size_y, self.size_z = (self.x_max - self.x_min, self.y_max - self.y_min,
+                                                 self.z_max - self.z_min)
+        self._get_optimization_parameters(name_file)
+        self._set_number_parameters_optimization()
+        # strut -> (cell, type) of the LAST cell that holds it: Cell.change_beam_radius (cell.py:896-917) is called
+        # cell after cell, so a strut shared by several cells ends with the last one's radius
+        cell_of = np.repeat(np.arange(lat.n_cells), np.diff(lat.cell_beam_ptr))
+        self._beam_cell = np.zeros(lat.n_beams, np.int64)
+        self._beam_cell[lat.cell_beam_idx] = cell_of          # later cells overwrite earlier ones
+        gr = self.grad_radius if self.grad_radius is not None else np.ones((max(self.num_cells_x, self.num_cells_y,
+                                                                                self.num_cells_z), 3))
+        pos = lat.cell_pos
+        self._cell_gfac = gr[pos[:, 0], 0] * gr[pos[:, 1], 1] * gr[pos[:, 2], 2]     # Cell.get_radius (cell.py:385-412)
+        self._cell_center = lat.cell_coord + 0.5 * lat.cell_size
+        self._x0 = self._y0 = self._z0 = 0.0
+
+    # -- preset ----------------------------------------------------------------------------------------
+    def _get_optimization_parameters(self, name_file):
+        info = open_lattice_parameters(name_file).get("optimization_informations", {})
+        self.objective_function = info.get("objective_function", None)
+        self.objective_type = info.get("objective_type", None)
+        self.objectif_data = info.get("objective_data", None)
+        self.optim_max_iteration = info.get("max_iterations", 20)
+        self.constraints_dict = info.get("constraints", {})
+        self.optimization_parameters = info.get("optimization_parameters", None)
+        if self.optimization_parameters is None:
+            raise ValueError("No optimization parameters defined.")
+        self._simulation_type = info.get("simulation_type", None)
+        if self._simulation_type not in {"FEM", "DDM"}:
+            raise ValueError("Invalid simulation type for optimization. Choose 'FEM' or 'DDM'.")
+        self.enable_normalization = info.get("enable_parameter_normalization", False)
+        self.enable_gradient_computing = info.get("enable_gradient_computing", False)
+
+    def _set_number_parameters_optimization(self):
+        t = self.optimization_parameters["type"]
+        if t == "unit_cell":
+            self.number_parameters = self.lattice.n_cells * len(self.geom_types)
+        elif t == "linear":
+            dirs = self.optimization_parameters.get("direction", [])
+            if not dirs:
+                raise ValueError("No directions provided for linear optimization.")
+            if any(d not in {"x", "y", "z"} for d in dirs):
+                raise ValueError(f"Invalid direction in {dirs}; valid are 'x', 'y', 'z'.")
+            self.number_parameters = len(dirs) + 1
+        elif t == "constant":
+            self.number_parameters = len(self.geom_types) if self.optimization_parameters.get("hybrid", False) else 1
+        else:
+            raise ValueError("Invalid optimization parameters type.")
+
+    def redefine_optim_parameters(self, max_iteration=None, ftol=None, disp=None, eps=None):
+        if max_iteration is not None:
+            self.optim_max_iteration = max_iteration
+        if ftol is not None:
+            self.optim_ftol = ftol
+        if disp is not None:
+            self.optim_disp = disp
+        if eps is not None:
+            self.optim_eps = eps
+
+    # -- normalisation (lattice_opti.py:1318-1400) ---------------------------------------------------------
+    def _clamp_radius(self, v):
+        return max(self.min_radius, min(self.max_radius, float(v)))
+
+    def denormalize_optimization_parameters(self, r_norm):
+        if not self.enable_normalization:
+            return list(r_norm)
+        return [self._clamp_radius(v * (self.max_radius - self.min_radius) + self.min_radius) for v in r_norm]
+
+    def normalize_optimization_parameters(self, r):
+        if not self.enable_normalization:
+            return list(r)
+        out = []
+        for v in r:
+            if v < self.min_radius or v > self.max_radius:
+                raise ValueError("Optimization parameter out of bounds.")
+            out.append((v - self.min_radius) / (self.max_radius - self.min_radius))
+        return out
+
+    def normalize_objective(self, value):
+        if not self.enable_normalization:
+            return float(value)
+        if self.initial_value_objective is None:
+            s = abs(float(value))
+            self.initial_value_objective = s if s != 0.0 else 1.0
+        return float(value) / self.initial_value_objective
+
+    def _to_normalized_theta_space(self, grad_dr):
+        if not self.enable_normalization:
+            return grad_dr
+        if self.initial_value_objective in (None, 0.0):
+            raise RuntimeError("Normalization scale not initialized; call objective() once before grad.")
+        return grad_dr * (self.max_radius - self.min_radius) / self.initial_value_objective
+
+    # -- parameters -> radii --------------------------------------------------------------------------------
+    def _cell_radii_from_parameters(self, theta):
+        """(C, G) base radii per cell and geometry + d r_cell / d theta as a sparse description."""
+        t = self.optimization_parameters["type"]
+        C, G = self.lattice.n_cells, len(self.geom_types)
+        theta = list(map(float, theta))
+        if t == "constant":
+            if self.optimization_parameters.get("hybrid", False):
+                if len(theta) != G:
+                    raise ValueError(f"Expected {G} parameters for hybrid constant mode, got {len(theta)}.")
+                per = self.denormalize_optimization_parameters(theta)
+                return np.tile(np.asarray(per), (C, 1))
+            r = self.denormalize_optimization_parameters([theta[0]])[0]
+            return np.full((C, G), r)
+        if t == "unit_cell":
+            return np.asarray(self.denormalize_optimization_parameters(theta)).reshape(C, G)
+        if t == "linear":
+            dirs = self.optimization_parameters.get("direction", [])
+            d_phys = self.denormalize_optimization_parameters([theta[-1]])[0]
+            span = self.max_radius - self.min_radius
+            L = np.maximum([self.size_x, self.size_y, self.size_z], 1e-16)
+            h = (self._cell_center - [self._x0, self._y0, self._z0]) / L
+            s = np.zeros(C)
+            for i, dkey in enumerate(dirs):
+                s += theta[i] * h[:, "xyz".index(dkey)]
+            val = np.clip(d_phys + span * s, self.min_radius, self.max_radius)
+            return np.tile(val[:, None], (1, G))
+        raise ValueError("Invalid optimization parameters type.")
+
+    def set_optimization_parameters(self, optimization_parameters_actual):
+        """lattice_opti.py:467-560: map the optimiser's vector to strut radii (device update, topology untouched)."""
+        theta = [float(v) for v in optimization_parameters_actual]
+        if len(theta) != self.number_parameters:
+            raise ValueError("Invalid number of optimization parameters.")
+        if (self.actual_optimization_parameters is not None
+                and len(self.actual_optimization_parameters) == len(theta)
+                and np.allclose(theta, self.actual_optimization_parameters, rtol=1e-10, atol=1e-10)):
+            return
+        self._sim_is_current = False
+        self.actual_optimization_parameters = list(theta)
+        self.cell_radii = self._cell_radii_from_parameters(theta)
+        lat = self.lattice
+        lat.beam_radius = (self.cell_radii[self._beam_cell, lat.beam_type] * self._cell_gfac[self._beam_cell])
+        dev = self.device_model()
+        dev.update_radii(lat.beam_radius)
+
+    # -- equilibrium / objective ------------------------------------------------------------------------------
+    def _initialize_simulation_parameters(self):
+        self.reaction_force_vector[:] = 0.0
+        self.displacement_vector[:] = 0.0
+        self.fixed_DOF[:] = False
+        self.applied_force[:] = 0.0
+        self.set_boundary_conditions()
+
+    def _simulate_lattice_equilibrium(self):
+        self._initialize_simulation_parameters()
+        _, self._model = solve_FEM_FenicsX(self)
+        self._sim_is_current = True
+
+    def compute_compliance(self):
+        """C = sum_k f_k u_k over loaded dofs (lattice_opti.py:645-663)."""
+        return float((self.applied_force * self.displacement_vector).sum())
+
+    def _objective_nodes(self, surfaces):
+        return self.find_point_on_lattice_surface(surfaces)
+
+    def calculate_objective(self):
+        if self.objective_type == "compliance":
+            return self.compute_compliance()
+        if self.objective_type == "displacement":
+            nodes = self._objective_nodes(self.objectif_data["Surface"])
+            vals = [self.displacement_vector[n, _DOF[d]] for n in nodes for d in self.objectif_data["DOF"]]
+            mean_disp = float(np.mean(vals))
+            if self.objective_function == "max":
+                return -mean_disp
+            if self.objective_function == "min":
+                return mean_disp
+            raise ValueError("objective_function must be 'min' or 'max'")
+        raise ValueError("Invalid objective function type.")
+
+    def objective(self, r):
+        self.set_optimization_parameters(r)
+        if not self._sim_is_current:
+            self._simulate_lattice_equilibrium()
+        objective = self.calculate_objective()
+        self.denorm_objective = objective
+        val = self.normalize_objective(objective)
+        if self.objective_function == "max":
+            val = -val
+        elif self.objective_function != "min":
+            raise ValueError("objective_function must be 'min' or 'max'")
+        self.actual_objective = val
+        return val
+
+    # -- sensitivities ------------------------------------------------------------------------------------------
+    def _adjoint(self, q):
+        """Solve K lam = q on the free dofs (lam = 0 on constrained ones) with the device PCG."""
+        dev = self.device_model()
+        fixed = self._model._fixed
+        dev.set_bc(fixed, None, np.where(fixed, 0.0, q))
+        lam, _ = dev.solve(rtol=1e-10, max_iter=200000)
+        dev.set_bc(fixed, self._model._ubar, self._model._f)     # restore the equilibrium problem
+        return lam
+
+    def strut_sensitivities(self):
+        """s_b such that d(objective)/d r_b = −s_b at fixed segment geometry (compliance: s_b = u_eᵀ ∂K_e/∂r u_e)."""
+        dev = self.device_model()
+        u = self._model.u
+        if self.objective_type == "compliance":
+            lam = u
+            if np.any(self._model._ubar != 0.0):      # prescribed displacements: the adjoint is not u itself
+                lam = self._adjoint(self._model._f)
+            return dev.sens(u, None if lam is u else lam)
+        if self.objective_type == "displacement":
+            nodes = self._objective_nodes(self.objectif_data["Surface"])
+            q = np.zeros_like(u)
+            cnt = len(nodes) * len(self.objectif_data["DOF"])
+            sign = -1.0 if self.objective_function == "max" else 1.0
+            for d in self.objectif_data["DOF"]:
+                q[nodes, _DOF[d]] += sign / cnt
+            return dev.sens(u, self._adjoint(q))
+        raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
+
+    def calculate_gradient(self):
+        """Raw gradient in the reference's sign convention (lattice_opti.py:735-907): sum over the struts driven by
+        each parameter of λ_eᵀ (∂K_e/∂r) u_e, chained through Cell.get_radius and the parameterisation."""
+        s = self.strut_sensitivities()
+        lat = self.lattice
+        G = len(self.geom_types)
+        s_cell = np.zeros((lat.n_cells, G))
+        np.add.at(s_cell, (self._beam_cell, lat.beam_type), s * self._cell_gfac[self._beam_cell])
+        t = self.optimization_parameters["type"]
+        if t == "unit_cell":
+            return s_cell.ravel()
+        if t == "constant":
+            if self.optimization_parameters.get("hybrid", False):
+                return s_cell.sum(axis=0)
+            return np.array([s_cell.sum()])
+        if t == "linear":
+            dirs = self.optimization_parameters.get("direction", [])
+            theta = self.actual_optimization_parameters
+            span = self.max_radius - self.min_radius
+            L = np.maximum([self.size_x, self.size_y, self.size_z], 1e-16)
+            h = (self._cell_center - [self._x0, self._y0, self._z0]) / L
+            d_phys = self.denormalize_optimization_parameters([theta[-1]])[0]
+            r_un = d_phys + span * sum(theta[i] * h[:, "xyz".index(k)] for i, k in enumerate(dirs))
+            active = (r_un > self.min_radius + 1e-12) & (r_un < self.max_radius - 1e-12)
+            sc = s_cell.sum(axis=1) * active
+            grad = np.zeros(self.number_parameters)
+            for i, k in enumerate(dirs):
+                grad[i] = (sc * span * h[:, "xyz".index(k)]).sum()
+            grad[-1] = sc.sum()
+            return grad
+        raise NotImplementedError(f"Gradient for optimization type '{t}' not implemented yet.")
+
+    def gradient(self, r):
+        """d(normalised objective)/d(theta) (lattice_opti.py:701-731)."""
+        self.set_optimization_parameters(r)
+        if not self._sim_is_current:
+            self._simulate_lattice_equilibrium()
+        g = -self.calculate_gradient()
+        if self.objective_function == "max":
+            g = -g        # objective() negates the (normalised) value for 'max'; keep the pair consistent
+        if self.optimization_parameters["type"] == "linear":
+            # slopes act on the physical radius directly (span already applied); only the intercept is normalised
+            scale = np.ones(self.number_parameters)
+            if self.enable_normalization:
+                scale[:] = 1.0 / self.initial_value_objective
+                scale[-1] *= (self.max_radius - self.min_radius)
+            g = g * scale
+        else:
+            g = self._to_normalized_theta_space(g)
+        self.actualGradient = g.copy()
+        return g
+
+    # -- density constraint (direct strut-volume formula) ---------------------------------------------------------
+    def relative_density(self):
+        lat = self.lattice
+        d = lat.node_xyz[lat.beam_conn[:, 1]] - lat.node_xyz[lat.beam_conn[:, 0]]
+        vol = np.pi * lat.beam_radius ** 2 * np.linalg.norm(d, axis=1)
+        return float(vol.sum() / lat.cell_size.prod(axis=1).sum())
+
+    def density_constraint(self, r):
+        self.set_optimization_parameters(r)
+        return self.relative_density() - float(self.constraints_dict["relative_density"]["value"])
+
+    # -- driver (SciPy SLSQP, as the reference) ---------------------------------------------------------------------
+    def _initialize_optimization_solver(self):
+        from scipy.optimize import Bounds
+        lo, hi = (0.0, 1.0) if self.enable_normalization else (self.min_radius, self.max_radius)
+        t = self.optimization_parameters["type"]
+        init = float(np.mean(self.normalize_optimization_parameters(self.radii)))
+        if t == "linear":
+            self.bounds = Bounds(lb=[-1.0] * (self.number_parameters - 1) + [lo],
+                                 ub=[1.0] * (self.number_parameters - 1) + [hi])
+            self.initial_parameters = [0.0] * (self.number_parameters - 1) + [init]
+        else:
+            self.bounds = Bounds(lb=[lo] * self.number_parameters, ub=[hi] * self.number_parameters)
+            if t == "constant" and self.optimization_parameters.get("hybrid", False):
+                self.initial_parameters = self.normalize_optimization_parameters(self.radii)
+            else:
+                self.initial_parameters = [init] * self.number_parameters
+
+    def callback_function(self, r):
+        self.iteration += 1
+        self._history["iteration"].append(self.iteration)
+        self._history["objective_norm"].append(self.actual_objective)
+        self._history["objective"].append(self.denorm_objective)
+        self._history["relative_density"].append(self.relative_density())
+        self._history["parameters"].append(list(map(float, r)))
+        self._history["timestamp"].append(time.time())
+
+    def optimize_lattice(self):
+        from scipy.optimize import NonlinearConstraint, minimize
+        self.initial_value_objective = None
+        self.iteration = 0
+        self._sim_is_current = False
+        self.actual_optimization_parameters = []
+        self._initialize_optimization_solver()
+        self.constraints = []
+        if "relative_density" in self.constraints_dict:
+            mode = self.constraints_dict["relative_density"].get("mode", "upper")
+            lb, ub = {"upper": (-np.inf, 0.0), "lower": (0.0, np.inf), "eq": (0.0, 0.0)}.get(mode, (-np.inf, 0.0))
+            self.constraints.append(NonlinearConstraint(self.density_constraint, lb, ub))
+        kw = dict(fun=self.objective, x0=self.initial_parameters, method="SLSQP", bounds=self.bounds,
+                  constraints=self.constraints, callback=self.callback_function,
+                  options={"maxiter": self.optim_max_iteration, "ftol": self.optim_ftol, "disp": self.optim_disp,
+                           "eps": self.optim_eps})
+        if self.enable_gradient_computing:
+            kw["jac"] = self.gradient
+        self.solution = minimize(**kw)
+        self.set_optimization_parameters(self.solution.x)
+        return self.solution

@@ -1,0 +1,91 @@
+"""Sensitivity pass (LatticeOpti.objective / gradient) on the GPU: analytic per-strut gradients vs central finite
+differences of the objective itself, for every parameterisation, and a short SLSQP run."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from pylatticedso_amd.lattice_opti import LatticeOpti  # noqa: E402
+
+BASE = {
+    "geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": 3, "y": 2, "z": 2},
+                 "radii": [0.05], "geom_types": ["BCC"]},
+    "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False},
+    "boundary_conditions": {
+        "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"],
+                                   "Value": [0, 0, 0, 0, 0, 0]}},
+        "Force": {"Load": {"Surface": ["Xmax", "Zmax"], "DOF": ["Z"], "Value": [-0.1]}}},
+    "optimization_informations": {
+        "objective_function": "min", "objective_type": "compliance", "max_iterations": 5,
+        "optimization_parameters": {"type": "constant", "hybrid": False},
+        "constraints": {"relative_density": {"value": 0.05}},
+        "enable_parameter_normalization": True, "enable_gradient_computing": True, "simulation_type": "FEM"}}
+
+
+def _preset(**opt):
+    p = copy.deepcopy(BASE)
+    for k, v in opt.items():
+        if k == "geometry":
+            p["geometry"].update(v)
+        else:
+            p["optimization_informations"][k] = v
+    return p
+
+
+def _fd_check(L, theta, idxs, h=1e-4, tol=2e-5):
+    L.objective(theta)                       # initialises the normalisation scale C0
+    g = L.gradient(theta)
+    for i in idxs:
+        tp, tm = list(theta), list(theta)
+        tp[i] += h
+        tm[i] -= h
+        fd = (L.objective(tp) - L.objective(tm)) / (2 * h)
+        assert abs(g[i] - fd) <= tol * max(abs(fd), abs(g).max()), (i, g[i], fd)
+    return g
+
+
+def test_gradient_constant_compliance():
+    L = LatticeOpti(_preset())
+    g = _fd_check(L, [0.45], [0])
+    assert g[0] < 0          # thicker struts -> lower compliance
+
+
+def test_gradient_unit_cell_compliance():
+    L = LatticeOpti(_preset(optimization_parameters={"type": "unit_cell"}))
+    rng = np.random.default_rng(0)
+    theta = list(0.3 + 0.4 * rng.random(L.number_parameters))
+    assert L.number_parameters == 12
+    _fd_check(L, theta, [0, 5, 11])
+
+
+def test_gradient_hybrid_constant_and_graded_radius():
+    p = _preset(optimization_parameters={"type": "constant", "hybrid": True},
+                geometry={"radii": [0.05, 0.04], "geom_types": ["BCC", "Hybrid4"]})
+    p["gradient"] = {"radii": {"rule": "linear", "direction_x": True, "direction_y": False, "direction_z": False,
+                               "parameter_x": 0.2, "parameter_y": 0.0, "parameter_z": 0.0}}
+    L = LatticeOpti(p)
+    _fd_check(L, [0.4, 0.3], [0, 1])
+
+
+def test_gradient_linear_field():
+    L = LatticeOpti(_preset(optimization_parameters={"type": "linear", "direction": ["x", "z"]}))
+    _fd_check(L, [0.2, -0.1, 0.5], [0, 1, 2])
+
+
+def test_gradient_displacement_objective_adjoint():
+    p = _preset(objective_type="displacement", objective_function="max",
+                objective_data={"Surface": ["Xmax"], "DOF": ["Z"]},
+                optimization_parameters={"type": "unit_cell"})
+    L = LatticeOpti(p)
+    theta = list(0.3 + 0.05 * np.arange(L.number_parameters) / L.number_parameters)
+    _fd_check(L, theta, [0, 7], tol=5e-5)
+
+
+def test_short_slsqp_run_decreases_compliance():
+    L = LatticeOpti(_preset(optimization_parameters={"type": "unit_cell"}))
+    L.redefine_optim_parameters(max_iteration=4, disp=False)
+    sol = L.optimize_lattice()
+    assert L._history["objective"][-1] < L._history["objective"][0] * 1.0001 or sol.fun < 1.0
+    assert L.relative_density() <= 0.05 * 1.02        # SLSQP iterates are only feasible to its own tolerance

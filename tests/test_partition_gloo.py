@@ -75,12 +75,9 @@ def _worker(rank, world, port, case, out):
     dist.all_reduce(ntg)
     f = np.zeros((n, 6))
     f[tgt, 2] = -0.1 / float(ntg[0])
-    diag = np.zeros((n, 6))
-    for k in range(6):
-        e = np.zeros((n, 6))
-        e[:, k] = 1.0
-    # Jacobi diagonal by probing is expensive; use the C oracle's PCG pieces through repeated products instead:
-    # plain CG is enough for this small check
+    # plain CG is enough for this small check.  As in libpylattice_hip's RCCL path, p.(A p) is formed from the LOCAL
+    # partial products without multiplicity weights and rides in the same all-reduce as the interface rows; only
+    # the dots of assembled vectors (r.r) use the 1/multiplicity weights.
     m = (~fixed).astype(float)
     r = m * f
     p = r.copy()
@@ -88,8 +85,13 @@ def _worker(rank, world, port, case, out):
     rr = wdot(r, r)
     bb = rr
     for it in range(5000):
-        Ap = m * A(p)
-        alpha = rr / wdot(p, Ap)
+        Ap = m * c_oracle.spmv(slab.node_xyz, slab.beam_conn, sc, p)         # local partial product
+        pack = torch.zeros(nsg * 6 + 1, dtype=torch.float64)
+        pack[:nsg * 6].view(nsg, 6)[gid] = torch.from_numpy(Ap[loc])
+        pack[-1] = float((p * Ap).sum())
+        dist.all_reduce(pack)                                                  # ONE collective: rows + scalar
+        Ap[loc] = pack[:nsg * 6].view(nsg, 6)[gid].numpy()
+        alpha = rr / float(pack[-1])
         u += alpha * p
         r -= alpha * Ap
         rr_new = wdot(r, r)
