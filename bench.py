@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
+    ap.add_argument("--precond", type=int, default=1, help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space")
     ap.add_argument("--kernels-only", action="store_true", help="skip the timed steps, only time the kernels")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
@@ -120,7 +121,7 @@ def main():
     log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
 
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder, lanes_per_node=args.lpn)
+                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond)
     n_beams_total = len(conn)
     if world > 1:
         keys = [None] * world
@@ -191,7 +192,8 @@ def main():
                    "struts": n_beams_total, "struts_per_gpu": len(conn), "nodes_per_gpu": len(xyz),
                    "partition": "single GPU" if world == 1 else f"{world} y-slabs, RCCL interface all-reduce",
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
-                   "rel_residual": st["rel_residual"], "preconditioner": "Jacobi",
+                   "rel_residual": st["rel_residual"],
+                   "preconditioner": "Jacobi" if args.precond == 1 else "two-level (Jacobi + rigid-body coarse space)",
                    "step": "records + Jacobi diag" + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),

@@ -58,11 +58,13 @@ typedef struct {
   int32_t device;        /* HIP device ordinal */
   int32_t spmv_kernel;   /* 0 = auto (3 if reorder else 2), 1 = per-strut + f64 global atomics, 2 = per-node gather
                             (sliced ELL), 3 = per-strut with LDS tile accumulators */
-  int32_t precond;       /* 0 = none, 1 = Jacobi (diagonal), 2 = 6x6 block Jacobi */
+  int32_t precond;       /* 1 = Jacobi (diagonal); 2 = two-level: Jacobi + rigid-body-mode coarse space (needs reorder) */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
   int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
   int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
-  int32_t reserved[6];
+  int32_t tile_nodes;    /* target nodes per brick/tile of the spatial reordering, <= 512 (0 -> 256) */
+  int32_t coarse_max_dofs; /* precond = 2: upper bound on 6 * (number of aggregates) (0 -> 3072) */
+  int32_t reserved[4];
 } pl_opts_t;
 
 typedef struct {
@@ -143,6 +145,11 @@ int pl_get_records(pl_handle h, double *rec);
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
 /* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr. */
 int pl_algorithmic_bytes(pl_handle h, double *out3);
+
+/* Test hook for the device dense SPD solver behind the two-level preconditioner (blocked Cholesky + inverse factor):
+ * solves A x = b for a host SPD matrix A[n*n] (row-major) on `device`; quad (may be NULL) gets b^T A^-1 b.
+ * Returns PL_ERR_ARG if A is not positive definite. */
+int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad);
 
 /* ---- multi-GPU (slab partition, RCCL) ---------------------------------------------------------------- */
 /* Size of the opaque RCCL unique id the ranks must share (rank 0 fills it with pl_dist_unique_id). */

@@ -18,7 +18,7 @@ PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_N
 EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_schur",
-           "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_dist_unique_id_bytes",
+           "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
            "pl_dist_unique_id", "pl_dist_init"]
 
 
@@ -32,7 +32,7 @@ class PlOpts(C.Structure):
     _fields_ = [("young", C.c_double), ("poisson", C.c_double), ("kappa", C.c_double), ("pen_coef", C.c_double),
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class PlStats(C.Structure):
@@ -71,7 +71,7 @@ def load_library(path: str | None = None):
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
-           "pl_algorithmic_bytes": [V, V], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
+           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
            "pl_dist_init": [V, I32, I32, V, V, V, I32, I32]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
@@ -96,11 +96,23 @@ def _check(lib, rc, allow=()):
     return rc
 
 
+def debug_spd_solve(A, b, device=0):
+    """Device dense SPD solve (test hook of the coarse solver): returns (x, b^T A^-1 b)."""
+    lib = load_library()
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.empty_like(b)
+    q = C.c_double()
+    _check(lib, lib.pl_debug_spd_solve(device, len(b), _ptr(A), _ptr(b), _ptr(x), C.byref(q)))
+    return x, q.value
+
+
 class HipLattice:
     """Owner of one device handle: the condensed lattice operator + its PCG on one MI355X."""
 
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
-                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=32, lanes_per_node=0):
+                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=32, lanes_per_node=0, tile_nodes=0, precond=1,
+                 coarse_max_dofs=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -116,6 +128,8 @@ class HipLattice:
         opts.young, opts.poisson, opts.kappa, opts.pen_coef = young, poisson, kappa, pen_coef
         opts.device, opts.spmv_kernel, opts.reorder, opts.check_every = device, spmv_kernel, reorder, check_every
         opts.lanes_per_node = lanes_per_node
+        opts.tile_nodes = tile_nodes
+        opts.precond, opts.coarse_max_dofs = precond, coarse_max_dofs
         _check(self._lib, self._lib.pl_create(C.byref(mesh), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
 

@@ -13,6 +13,7 @@
 #include "pl_kernels.h"
 #include "pl_tile.h"
 #include "pl_dist.h"
+#include "pl_coarse.h"
 
 namespace {
 
@@ -95,6 +96,10 @@ struct pl_context {
   int hist_cap = 0;
   // LDS-tile operator
   pl::TilePlan tile;
+  DevBuf<int32_t> tile_start_dev_unused;
+  // two-level preconditioner (rigid-body coarse space)
+  pl::Coarse coarse;
+  int coarse_info = 0;
   // multi-GPU
   pl::Dist dist;
 
@@ -236,6 +241,31 @@ int launch_diag(pl_context *c) {
   return PL_OK;
 }
 
+// A_c = Z^T P K P Z on the device, then its Cholesky factor and W = L^-1 (pl_dense.h).
+int build_coarse(pl_context *c) {
+  pl::Coarse &cs = c->coarse;
+  cs.ready = false;
+  if (!cs.enabled || !c->have_bc || c->dist.active) return PL_OK;
+  const int n = cs.ncp;
+  PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
+  hipLaunchKernelGGL(pl::k_coarse_assemble, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
+                     c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n, cs.Ac);
+  if (cs.n_cross > 0)
+    hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
+                       cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
+                       c->fixedbits.p, n, cs.Ac);
+  hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
+  pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, cs.slab, n, n, cs.info, c->stream);
+  PL_HIP(hipGetLastError());
+  int info[2] = {0, 0};
+  PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  c->coarse_info = info[0];
+  cs.ready = (info[0] == 0);   // not SPD -> fall back to Jacobi
+  return PL_OK;
+}
+
 int launch_bsr_fill(pl_context *c, int with_bc) {
   const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
@@ -249,6 +279,24 @@ int launch_bsr_fill(pl_context *c, int with_bc) {
   return PL_OK;
 }
 
+// Everything of a two-level PCG iteration after K*p: update + restriction, coarse solve, new direction.
+int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
+  pl::Coarse &cs = c->coarse;
+  hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, c->dinv.p,
+                     (const double *)nullptr, c->x.p, c->r.p, cur, cs.part);
+  hipLaunchKernelGGL(pl::k_coarse_gather, dim3((unsigned)((cs.nc + pl::kBlock - 1) / pl::kBlock + 1)),
+                     dim3(pl::kBlock), 0, c->stream, cs.n_agg, cs.agg_tile_ptr.p, cs.agg_tile_idx.p, cs.part,
+                     cs.n_tiles, cs.rc, cur);
+  pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
+                  cur + pl::S_RDR * pl::kSlots, c->stream);
+  hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3(grid_stream(c->N)), dim3(pl::kBlock), 0, c->stream, c->N,
+                     c->r.p, c->dinv.p, c->xyz.p, cs.agg_of_node.p, cs.cen.p, cs.yc, c->fixedbits.p, c->p.p, cur, nxt,
+                     c->hist.p, hist_slot);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
 // One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
 int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
@@ -256,6 +304,7 @@ int pcg_iteration(pl_context *c, int k) {
   double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
+  if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
   if (c->dist.active) {
     pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
                                    c->stream);
@@ -287,6 +336,15 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   if (c->dist.active) {
     pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream);
     pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream);
+  }
+  if (c->coarse.ready) {
+    // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
+    // scalar set 1; its direction kernel leaves p = z0 and rz_old = r0.z0 in set 0, where iteration 0 starts.
+    const int set = pl::S_COUNT * pl::kSlots;
+    PL_HIP(hipMemsetAsync(c->p.p, 0, n6 * sizeof(double), c->stream));
+    PL_HIP(hipMemsetAsync(c->Ap.p, 0, n6 * sizeof(double), c->stream));
+    rc = pcg_tail_coarse(c, c->scal.p + set, c->scal.p, max_iter);
+    if (rc) return rc;
   }
   double h_scal[pl::kSlots];
   PL_HIP(hipMemcpyAsync(h_scal, c->scal.p + pl::S_BB * pl::kSlots, sizeof(h_scal), hipMemcpyDeviceToHost,
@@ -494,8 +552,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   c->perm.resize(N);
   std::iota(c->perm.begin(), c->perm.end(), 0);
   std::vector<int32_t> tile_start, tile_of;
+  std::vector<int64_t> tile_brick;
+  int64_t nbrick[3] = {1, 1, 1};
   if (o->reorder == 1) {
-    pl::spatial_order(m->node_xyz, N, c->perm, tile_start);
+    pl::spatial_order(m->node_xyz, N, c->perm, tile_start,
+                      (double)(o->tile_nodes > 0 ? std::min(o->tile_nodes, pl::kTileMaxNodes) : 256), tile_brick,
+                      nbrick);
     c->reordered = true;
   } else {
     pl::chunk_tiles(N, tile_start);
@@ -541,6 +603,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
+  }
+  if (o->precond == 2) {
+    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2 (two-level) needs reorder = 1"));
+    const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
+    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, nbrick, xyz.data(), N, max_dofs, conn);
+    if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
   }
 
   const size_t n6 = (size_t)N * 6;
@@ -594,8 +662,10 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   PL_HIP(hipMemcpy(h->ubar.p, ub.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   h->have_bc = true;
-  if (h->assembled) {   // the Jacobi inverse depends on the mask
+  if (h->assembled) {   // the Jacobi inverse and the coarse operator depend on the mask
     int rc = launch_diag(h);
+    if (rc) return rc;
+    rc = build_coarse(h);
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
   }
@@ -639,6 +709,8 @@ int pl_assemble(pl_handle h) {
   int rc = launch_records(h);
   if (rc) return rc;
   rc = launch_diag(h);
+  if (rc) return rc;
+  rc = build_coarse(h);
   if (rc) return rc;
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
@@ -909,6 +981,57 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   float ms = 0.f;
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *avg_ms = (double)ms / reps;
+  return PL_OK;
+}
+
+int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad) {
+  if (n <= 0 || !A || !b || !x) return fail(PL_ERR_ARG, "pl_debug_spd_solve: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PL_ERR_NODEVICE, "no HIP device visible");
+  PL_HIP(hipSetDevice(device));
+  const int np = (n + pl::kNB - 1) / pl::kNB * pl::kNB;
+  std::vector<double> Ap((size_t)np * np, 0.0), bp(np, 0.0);
+  for (int i = 0; i < np; ++i) {
+    if (i < n) {
+      std::memcpy(&Ap[(size_t)i * np], A + (size_t)i * n, n * sizeof(double));
+      bp[i] = b[i];
+    } else {
+      Ap[(size_t)i * np + i] = 1.0;
+    }
+  }
+  DevBuf<double> dA, dW, dWt, dD, db, dt, dy, dq, dslab;
+  DevBuf<int> dinfo;
+  PL_HIP(dA.alloc(Ap.size()));
+  PL_HIP(dW.alloc(Ap.size()));
+  PL_HIP(dWt.alloc(Ap.size()));
+  PL_HIP(hipMemset(dWt.p, 0, Ap.size() * sizeof(double)));
+  PL_HIP(dD.alloc((size_t)np * pl::kNB));
+  PL_HIP(dslab.alloc((size_t)(np / pl::kNB) * pl::dense_max_chunks(np) * pl::kNB * pl::kNB));
+  PL_HIP(db.alloc(np));
+  PL_HIP(dt.alloc(np));
+  PL_HIP(dy.alloc(np));
+  PL_HIP(dq.alloc(pl::kSlots));
+  PL_HIP(dinfo.alloc(2));
+  PL_HIP(hipMemcpy(dA.p, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(db.p, bp.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemset(dW.p, 0, Ap.size() * sizeof(double)));
+  PL_HIP(hipMemset(dq.p, 0, pl::kSlots * sizeof(double)));
+  PL_HIP(hipMemset(dinfo.p, 0, 2 * sizeof(int)));
+  pl::dense_factor_inverse(dA.p, dW.p, dWt.p, dD.p, dslab.p, np, np, dinfo.p, nullptr);
+  pl::dense_apply(dW.p, dWt.p, np, np, db.p, dt.p, dy.p, dq.p, nullptr, nullptr);
+  PL_HIP(hipGetLastError());
+  PL_HIP(hipDeviceSynchronize());
+  int info[2];
+  PL_HIP(hipMemcpy(info, dinfo.p, sizeof(info), hipMemcpyDeviceToHost));
+  if (info[0] != 0) return fail(PL_ERR_ARG, "pl_debug_spd_solve: matrix is not positive definite");
+  std::vector<double> y(np), q(pl::kSlots);
+  PL_HIP(hipMemcpy(y.data(), dy.p, np * sizeof(double), hipMemcpyDeviceToHost));
+  PL_HIP(hipMemcpy(q.data(), dq.p, pl::kSlots * sizeof(double), hipMemcpyDeviceToHost));
+  std::memcpy(x, y.data(), n * sizeof(double));
+  if (quad) {
+    *quad = 0.0;
+    for (double v : q) *quad += v;
+  }
   return PL_OK;
 }
 

@@ -1,0 +1,469 @@
+// Two-level preconditioner of libpylattice_hip:  M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T   (additive, SPD).
+//
+// D = diag(K) (Jacobi) is the fine level.  The coarse space Z holds the 6 rigid-body modes (3 translations, 3 rotations
+// about the aggregate centroid) of every AGGREGATE = a g x g x g group of the node bricks the K*p tiles are made of,
+// restricted to the aggregate's nodes (plain aggregation, every node in exactly one aggregate) and to the free dofs.
+// Rigid-body modes of a strut carry no energy, so only struts that cross aggregates (or touch Dirichlet dofs)
+// contribute to A_c = Z^T P K P Z, which is small (6 n_agg <= ~3000) and kept as a DENSE inverse on the device
+// (blocked Cholesky + explicit inverse factor, pl_dense.h); applying it is two triangular GEMVs.
+// Effect (CPU experiment + GPU bench): PCG iterations of the n^3 Octet cantilever stop growing with n
+// (263 / 397 / 812 with Jacobi at n = 16 / 24 / 50 -> ~100-180).
+//
+// Per iteration (all device-side, no host round trip):
+//   K*p (+ p.Ap)                                                            k_spmv_tile
+//   x += a p, r -= a Ap, per-tile partials of Z^T r, r.r, r.D^-1 r         k_pcg_update_tile
+//   r_c = sum of tile partials per aggregate, scalars                       k_coarse_gather
+//   y_c = A_c^-1 r_c, r.z = r.D^-1 r + r_c.y_c                              k_tri_gemv, k_tri_gemv_t
+//   p = D^-1 r + P Z y_c + beta p  (z is never stored)                      k_pcg_direction_coarse
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "pl_dense.h"
+#include "pl_kernels.h"
+#include "pl_tile.h"
+
+namespace pl {
+
+enum { S_RDR = 6 };   // scalar id (see S_* in pl_kernels.h): r . D^-1 r
+
+struct Coarse {
+  bool enabled = false;     // topology prepared (pl_create)
+  bool ready = false;       // A_c^-1 valid (pl_assemble)
+  int n_agg = 0, nc = 0, ncp = 0;   // ncp = nc rounded up to the dense block size (padding rows are identity)
+  int64_t n_tiles = 0;
+  TBuf<int32_t> agg_of_node, agg_of_tile, agg_tile_ptr, agg_tile_idx;
+  TBuf<double> cen;
+  TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
+  int64_t n_cross = 0;
+  double *Ac = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *slab = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
+  int *info = nullptr;
+  ~Coarse() {
+    for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)slab, (void *)part, (void *)rc, (void *)yc, (void *)tv,
+                    (void *)info})
+      if (q) (void)hipFree(q);
+  }
+};
+
+// Host: aggregates = groups of g^3 bricks.  brick_coord[t] = integer brick coordinates of tile t, nbrick = grid size.
+inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const std::vector<int64_t> &tile_brick,
+                        const int64_t nbrick[3], const double *xyz_dev_order, int64_t N, int max_dofs,
+                        const std::vector<int32_t> &conn) {
+  const int64_t T = (int64_t)tile_start.size() - 1;
+  int g = 2;
+  int64_t na[3];
+  for (;; ++g) {
+    for (int k = 0; k < 3; ++k) na[k] = (nbrick[k] + g - 1) / g;
+    if (na[0] * na[1] * na[2] * 6 <= max_dofs || g > 64) break;
+  }
+  std::vector<int64_t> raw(T);
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t key = tile_brick[t];
+    const int64_t b2 = key % nbrick[2], b1 = (key / nbrick[2]) % nbrick[1], b0 = key / (nbrick[2] * nbrick[1]);
+    raw[t] = ((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g);
+  }
+  std::vector<int64_t> uq(raw);
+  std::sort(uq.begin(), uq.end());
+  uq.erase(std::unique(uq.begin(), uq.end()), uq.end());
+  const int n_agg = (int)uq.size();
+  std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
+  std::vector<double> cen((size_t)n_agg * 3, 0.0), cnt(n_agg, 0.0);
+  for (int64_t t = 0; t < T; ++t) {
+    const int a = (int)(std::lower_bound(uq.begin(), uq.end(), raw[t]) - uq.begin());
+    agg_of_tile[t] = a;
+    for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) {
+      agg_of_node[i] = a;
+      for (int k = 0; k < 3; ++k) cen[3 * a + k] += xyz_dev_order[3 * (size_t)i + k];
+      cnt[a] += 1.0;
+    }
+  }
+  for (int a = 0; a < n_agg; ++a)
+    for (int k = 0; k < 3; ++k) cen[3 * a + k] /= std::max(cnt[a], 1.0);
+  std::vector<int32_t> ptr(n_agg + 1, 0), idx(T);
+  for (int64_t t = 0; t < T; ++t) ptr[agg_of_tile[t] + 1]++;
+  for (int a = 0; a < n_agg; ++a) ptr[a + 1] += ptr[a];
+  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t t = 0; t < T; ++t) idx[fill[agg_of_tile[t]]++] = (int32_t)t;
+  c.n_agg = n_agg;
+  c.nc = 6 * n_agg;
+  c.n_tiles = T;
+  {
+    // aggregate-crossing struts, grouped by ordered aggregate pair: a wave of the assembly kernel then works on ONE
+    // coarse block and can reduce in registers before touching memory
+    const int64_t B = (int64_t)conn.size() / 2;
+    std::vector<std::pair<int64_t, int32_t>> cross;
+    for (int64_t b = 0; b < B; ++b) {
+      const int I = agg_of_node[conn[2 * b]], J = agg_of_node[conn[2 * b + 1]];
+      if (I != J) cross.push_back({(int64_t)I * n_agg + J, (int32_t)b});
+    }
+    std::sort(cross.begin(), cross.end());
+    std::vector<int32_t> idx2(cross.size());
+    for (size_t q = 0; q < cross.size(); ++q) idx2[q] = cross[q].second;
+    c.n_cross = (int64_t)idx2.size();
+    if (c.cross_idx.upload(idx2) != hipSuccess) return 1;
+  }
+  if (c.agg_of_node.upload(agg_of_node) != hipSuccess || c.agg_of_tile.upload(agg_of_tile) != hipSuccess ||
+      c.agg_tile_ptr.upload(ptr) != hipSuccess || c.agg_tile_idx.upload(idx) != hipSuccess ||
+      c.cen.upload(cen) != hipSuccess)
+    return 1;
+  c.ncp = (c.nc + kNB - 1) / kNB * kNB;
+  const size_t n2 = (size_t)c.ncp * c.ncp;
+  if (hipMalloc((void **)&c.Ac, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.W, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.Wt, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.slab, (size_t)(c.ncp / kNB) * dense_max_chunks(c.ncp) * kNB * kNB * sizeof(double)) !=
+      hipSuccess)
+    return 2;
+  if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.rc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
+  if (hipMemset(c.rc, 0, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.W, 0, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.Wt, 0, n2 * sizeof(double)) != hipSuccess) return 2;
+  c.enabled = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A_c = Z^T P K P Z : one thread per strut, only aggregate-crossing or Dirichlet-touching struts contribute.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void coarse_block_add(const double *K, unsigned frow, unsigned fcol, const double *relp,
+                                                 const double *relq, double *dst, int nc) {
+  // C = Zp^T (mask K mask) Zq,  Z = [[I, -S(rel)], [0, I]],  S(v) w = v x w
+  double Km[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Km[i * 6 + j] = (((frow >> i) & 1u) || ((fcol >> j) & 1u)) ? 0.0 : K[i * 6 + j];
+  const double Sq[3][3] = {{0, -relq[2], relq[1]}, {relq[2], 0, -relq[0]}, {-relq[1], relq[0], 0}};
+  const double Sp[3][3] = {{0, -relp[2], relp[1]}, {relp[2], 0, -relp[0]}, {-relp[1], relp[0], 0}};
+  double M[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[i * 6 + j] = Km[i * 6 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double acc = Km[i * 6 + 3 + j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc -= Km[i * 6 + k] * Sq[k][j];
+      M[i * 6 + 3 + j] = acc;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) unsafeAtomicAdd(dst + (size_t)i * nc + j, M[i * 6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double acc = M[(3 + i) * 6 + j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += Sp[i][k] * M[k * 6 + j];
+      unsafeAtomicAdd(dst + (size_t)(3 + i) * nc + j, acc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_coarse_assemble(int64_t B, const int32_t *__restrict__ conn,
+                                                            const Record *__restrict__ rec,
+                                                            const int32_t *__restrict__ agg,
+                                                            const double *__restrict__ cen,
+                                                            const double *__restrict__ xyz,
+                                                            const uint8_t *__restrict__ fixedbits, int nc,
+                                                            double *__restrict__ Ac) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  const int I = agg[ia], J = agg[ib];
+  const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
+  if (I != J) return;                           // crossing struts: k_coarse_assemble_cross
+  if (fa == 0u && fb == 0u) return;             // a rigid motion of the whole strut: no energy
+  const Record r = load_record(rec, b);
+  double rela[3], relb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rela[k] = xyz[3 * (int64_t)ia + k] - cen[3 * I + k];
+    relb[k] = xyz[3 * (int64_t)ib + k] - cen[3 * J + k];
+  }
+  // the Cholesky reads only the lower triangle (row >= col) of A_c: off-diagonal coarse blocks are added once, on
+  // the side with the larger aggregate index (for I == J both orientations land in the same diagonal block)
+  double Kss[36], Kso[36];
+  tip_blocks(r, Kss, Kso);                                   // K_bb, K_ba
+  coarse_block_add(Kss, fb, fb, relb, relb, Ac + ((size_t)6 * J) * nc + 6 * J, nc);
+  if (J >= I) coarse_block_add(Kso, fb, fa, relb, rela, Ac + ((size_t)6 * J) * nc + 6 * I, nc);
+  tip_blocks(reversed(r), Kss, Kso);                         // K_aa, K_ab
+  coarse_block_add(Kss, fa, fa, rela, rela, Ac + ((size_t)6 * I) * nc + 6 * I, nc);
+  if (I >= J) coarse_block_add(Kso, fa, fb, rela, relb, Ac + ((size_t)6 * I) * nc + 6 * J, nc);
+}
+
+// Coarse block C = Zp^T (mask K mask) Zq into registers (no memory traffic).
+__device__ __forceinline__ void coarse_block(const double *K, unsigned frow, unsigned fcol, const double *relp,
+                                             const double *relq, double *C) {
+  double Km[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Km[i * 6 + j] = (((frow >> i) & 1u) || ((fcol >> j) & 1u)) ? 0.0 : K[i * 6 + j];
+  const double Sq[3][3] = {{0, -relq[2], relq[1]}, {relq[2], 0, -relq[0]}, {-relq[1], relq[0], 0}};
+  const double Sp[3][3] = {{0, -relp[2], relp[1]}, {relp[2], 0, -relp[0]}, {-relp[1], relp[0], 0}};
+  double M[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[i * 6 + j] = Km[i * 6 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double acc = Km[i * 6 + 3 + j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc -= Km[i * 6 + k] * Sq[k][j];
+      M[i * 6 + 3 + j] = acc;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) C[i * 6 + j] = M[i * 6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double acc = M[(3 + i) * 6 + j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += Sp[i][k] * M[k * 6 + j];
+      C[(3 + i) * 6 + j] = acc;
+    }
+  }
+}
+
+// Aggregate-crossing struts in (I, J)-sorted order: when the whole wave works on one ordered pair (the common case,
+// a pair has hundreds of struts) the three 6 x 6 contributions are summed across the wave with shuffles and ONE lane
+// issues the atomics; mixed waves fall back to per-lane atomics.
+__global__ __launch_bounds__(kBlock) void k_coarse_assemble_cross(int64_t n_cross, const int32_t *__restrict__ cross,
+                                                                  const int32_t *__restrict__ conn,
+                                                                  const Record *__restrict__ rec,
+                                                                  const int32_t *__restrict__ agg,
+                                                                  const double *__restrict__ cen,
+                                                                  const double *__restrict__ xyz,
+                                                                  const uint8_t *__restrict__ fixedbits, int nc,
+                                                                  double *__restrict__ Ac) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = q < n_cross;
+  const int64_t b = live ? cross[q] : cross[n_cross - 1];
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  const int I = agg[ia], J = agg[ib];
+  const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
+  const Record r = load_record(rec, b);
+  double rela[3], relb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rela[k] = xyz[3 * (int64_t)ia + k] - cen[3 * I + k];
+    relb[k] = xyz[3 * (int64_t)ib + k] - cen[3 * J + k];
+  }
+  double Kss[36], Kso[36], Cjj[36], Cii[36], Cx[36];
+  tip_blocks(r, Kss, Kso);                                   // K_bb, K_ba
+  coarse_block(Kss, fb, fb, relb, relb, Cjj);
+  if (J > I) coarse_block(Kso, fb, fa, relb, rela, Cx);      // lower block (J, I)
+  tip_blocks(reversed(r), Kss, Kso);                         // K_aa, K_ab
+  coarse_block(Kss, fa, fa, rela, rela, Cii);
+  if (I > J) coarse_block(Kso, fa, fb, rela, relb, Cx);      // lower block (I, J)
+  const int hi = I > J ? I : J, lo = I > J ? J : I;
+  double *dII = Ac + ((size_t)6 * I) * nc + 6 * I, *dJJ = Ac + ((size_t)6 * J) * nc + 6 * J;
+  double *dX = Ac + ((size_t)6 * hi) * nc + 6 * lo;
+  const int I0 = __shfl(I, 0, 64), J0 = __shfl(J, 0, 64);
+  const bool uniform = __all(I == I0 && J == J0);            // dead lanes replicate the last strut's pair
+  if (uniform) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) {
+      const double a = wave_sum(live ? Cii[e] : 0.0), c = wave_sum(live ? Cjj[e] : 0.0), x = wave_sum(live ? Cx[e] : 0.0);
+      if ((threadIdx.x & 63) == 0) {
+        const int i = e / 6, j = e - 6 * i;
+        unsafeAtomicAdd(dII + (size_t)i * nc + j, a);
+        unsafeAtomicAdd(dJJ + (size_t)i * nc + j, c);
+        unsafeAtomicAdd(dX + (size_t)i * nc + j, x);
+      }
+    }
+  } else if (live) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) {
+      const int i = e / 6, j = e - 6 * i;
+      unsafeAtomicAdd(dII + (size_t)i * nc + j, Cii[e]);
+      unsafeAtomicAdd(dJJ + (size_t)i * nc + j, Cjj[e]);
+      unsafeAtomicAdd(dX + (size_t)i * nc + j, Cx[e]);
+    }
+  }
+}
+
+// Rows/cols with a zero diagonal (aggregate without free support for that mode) -> identity; symmetrise round-off.
+__global__ void k_coarse_regularize(int nc, double *__restrict__ Ac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  if (!(Ac[(size_t)i * nc + i] > 0.0)) Ac[(size_t)i * nc + i] = 1.0;
+}
+// ---------------------------------------------------------------------------------------------------------------
+// x += alpha p ; r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
+                                                            const int32_t *__restrict__ agg_of_tile,
+                                                            const double *__restrict__ cen,
+                                                            const double *__restrict__ xyz,
+                                                            const double *__restrict__ p,
+                                                            const double *__restrict__ Ap,
+                                                            const double *__restrict__ dinv,
+                                                            const double *__restrict__ w /* may be null */,
+                                                            double *__restrict__ x, double *__restrict__ r,
+                                                            const double *__restrict__ scal,
+                                                            double *__restrict__ part) {
+  __shared__ double red[8][kBlock / kWave];
+  const int t = blockIdx.x;
+  const double pap = scalar_read(scal, S_PAP);
+  const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
+  const int n0 = tile_start[t], n1 = tile_start[t + 1];
+  const int a = agg_of_tile[t];
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
+    double pv[6], av[6], dv[6], xv[6], rv[6];
+    const double2 *p2 = reinterpret_cast<const double2 *>(p + 6 * (int64_t)i);
+    const double2 *a2 = reinterpret_cast<const double2 *>(Ap + 6 * (int64_t)i);
+    const double2 *d2 = reinterpret_cast<const double2 *>(dinv + 6 * (int64_t)i);
+    double2 *x2 = reinterpret_cast<double2 *>(x + 6 * (int64_t)i);
+    double2 *r2 = reinterpret_cast<double2 *>(r + 6 * (int64_t)i);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double2 pp = p2[k], aa = a2[k], dd = d2[k], xx = x2[k], rr = r2[k];
+      pv[2 * k] = pp.x; pv[2 * k + 1] = pp.y; av[2 * k] = aa.x; av[2 * k + 1] = aa.y;
+      dv[2 * k] = dd.x; dv[2 * k + 1] = dd.y; xv[2 * k] = xx.x; xv[2 * k + 1] = xx.y;
+      rv[2 * k] = rr.x; rv[2 * k + 1] = rr.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      xv[k] += alpha * pv[k];
+      rv[k] -= alpha * av[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x2[k] = {xv[2 * k], xv[2 * k + 1]};
+      r2[k] = {rv[2 * k], rv[2 * k + 1]};
+    }
+    double wt[6] = {1, 1, 1, 1, 1, 1};
+    if (w) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wt[k] = w[6 * (int64_t)i + k];
+    }
+    const double rx = xyz[3 * (int64_t)i] - c0, ry = xyz[3 * (int64_t)i + 1] - c1, rz = xyz[3 * (int64_t)i + 2] - c2;
+    const double ru[3] = {wt[0] * rv[0], wt[1] * rv[1], wt[2] * rv[2]};
+    acc[0] += ru[0];
+    acc[1] += ru[1];
+    acc[2] += ru[2];
+    acc[3] += wt[3] * rv[3] + (ry * ru[2] - rz * ru[1]);
+    acc[4] += wt[4] * rv[4] + (rz * ru[0] - rx * ru[2]);
+    acc[5] += wt[5] * rv[5] + (rx * ru[1] - ry * ru[0]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      acc[6] += wt[k] * rv[k] * rv[k];
+      acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[k][wv] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
+    part[8 * (int64_t)t + threadIdx.x] = s;
+  }
+}
+
+// r_c[6 I + k] = sum over the tiles of aggregate I; last block: rr and r.D^-1 r totals into the scalar set.
+__global__ __launch_bounds__(kBlock) void k_coarse_gather(int n_agg, const int32_t *__restrict__ ptr,
+                                                          const int32_t *__restrict__ idx,
+                                                          const double *__restrict__ part, int64_t T,
+                                                          double *__restrict__ rc, double *__restrict__ scal) {
+  __shared__ double red[2][kBlock / kWave];
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < 6 * n_agg) {
+      const int I = e / 6, k = e - 6 * I;
+      double s = 0.0;
+      for (int q = ptr[I]; q < ptr[I + 1]; ++q) s += part[8 * (int64_t)idx[q] + k];
+      rc[e] = s;
+    }
+    return;
+  }
+  double rr = 0.0, rdr = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += kBlock) {
+    rr += part[8 * t + 6];
+    rdr += part[8 * t + 7];
+  }
+  rr = wave_sum(rr);
+  rdr = wave_sum(rdr);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = rr; red[1][wv] = rdr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int q = 0; q < kBlock / kWave; ++q) { a += red[0][q]; b += red[1][q]; }
+    scal[S_RR * kSlots] = a;          // the set's accumulators were zeroed by the previous direction kernel
+    scal[S_RDR * kSlots] = b;
+  }
+}
+
+// p = D^-1 r + P Z y_c + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
+__global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(int64_t N, const double *__restrict__ r,
+                                                                 const double *__restrict__ dinv,
+                                                                 const double *__restrict__ xyz,
+                                                                 const int32_t *__restrict__ agg,
+                                                                 const double *__restrict__ cen,
+                                                                 const double *__restrict__ yc,
+                                                                 const uint8_t *__restrict__ fixedbits,
+                                                                 double *__restrict__ p,
+                                                                 const double *__restrict__ scal,
+                                                                 double *__restrict__ scal_next,
+                                                                 double *__restrict__ hist, int k) {
+  const double old = scalar_read(scal, S_RZ_OLD);
+  const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < kWave) {
+    const double rr = scalar_read(scal, S_RR);
+    const int s = threadIdx.x;
+    if (s == 0) hist[k] = rr;
+    if (s < kSlots) {
+      scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
+      scal_next[S_RZ_NEW * kSlots + s] = 0.0;
+      scal_next[S_RR * kSlots + s] = 0.0;
+      scal_next[S_PAP * kSlots + s] = 0.0;
+      scal_next[S_RDR * kSlots + s] = 0.0;
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    const int a = agg[i];
+    const double *y = yc + 6 * a;
+    const double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
+    const double rx = xyz[3 * i] - cen[3 * a], ry = xyz[3 * i + 1] - cen[3 * a + 1], rz = xyz[3 * i + 2] - cen[3 * a + 2];
+    double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
+    const unsigned fb = fixedbits[i];
+    const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);
+    const double2 *d2 = reinterpret_cast<const double2 *>(dinv + 6 * i);
+    double2 *p2 = reinterpret_cast<double2 *>(p + 6 * i);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double2 rr = r2[q], dd = d2[q];
+      double2 pp = p2[q];
+      const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
+      const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);
+      pp.x = z0 + beta * pp.x;
+      pp.y = z1 + beta * pp.y;
+      p2[q] = pp;
+    }
+  }
+}
+
+}  // namespace pl

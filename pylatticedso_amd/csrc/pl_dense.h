@@ -1,0 +1,286 @@
+// Small dense SPD solver on the device for the coarse operator of the two-level preconditioner (n <= a few thousand).
+//
+// Blocked right-looking Cholesky A = L L^T (64 x 64 blocks, lower triangle of a row-major matrix), then the explicit
+// inverse factor W = L^-1 (blocked, anti-diagonal by anti-diagonal), so that applying A^-1 is two triangular GEMVs
+//     t = W r ,  y = W^T t ,  r.A^-1 r = t.t
+// with the same traffic as one full GEMV (W^T is stored explicitly so both are row-per-wave, coalesced).  Hand-written because vendor BLAS/LAPACK libraries loaded into a process
+// that already holds PyTorch's bundled ROCm libraries resolve against the wrong versions (observed: minutes of
+// start-up or a crash); it is ~1 % of a solve, so simple LDS-tiled fp64 VALU kernels are enough.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pl_kernels.h"
+
+namespace pl {
+
+constexpr int kNB = 64;          // block size
+constexpr int kLdT = kNB + 2;    // LDS row pitch (doubles) of the staged tiles
+
+// acc[4][4] += sum_k At[k][4*ty + a] * Bt[k][4*tx + b]   (both tiles staged k-major in LDS)
+__device__ __forceinline__ void tile_fma(const double *At, const double *Bt, int tx, int ty, double acc[4][4]) {
+#pragma unroll 8
+  for (int k = 0; k < kNB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = At[k * kLdT + 4 * ty + q];
+      b[q] = Bt[k * kLdT + 4 * tx + q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+  }
+}
+
+// stage a 64 x 64 global tile into LDS as T[k][row] = G[row][k]  (i.e. k-major: the GEMM's inner index first)
+__device__ __forceinline__ void stage_rows_as_k_minor(const double *G, int ld, double *T) {
+  for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
+    const int row = e / kNB, k = e % kNB;
+    T[k * kLdT + row] = G[(size_t)row * ld + k];
+  }
+}
+// stage as T[k][col] = G[k][col]
+__device__ __forceinline__ void stage_rows_as_k_major(const double *G, int ld, double *T) {
+  for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
+    const int k = e / kNB, col = e % kNB;
+    T[k * kLdT + col] = G[(size_t)k * ld + col];
+  }
+}
+
+// Diagonal block: L_kk and its inverse, ONE WAVE, everything in registers: lane i owns row i of the 64 x 64 block;
+// pivots and multipliers travel by wave broadcast (readlane), so there is no LDS round trip and no barrier in the
+// 2 x 2016-step dependency chains.  info[0] != 0 if a pivot is not positive.
+// v_readlane_b32 x2: the source lane is a compile-time constant after unrolling, so the value lands in SGPRs with a
+// few cycles of latency (a ds_bpermute shuffle would put ~100 cycles into every step of the dependency chain).
+__device__ __forceinline__ double bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(kWave) void k_chol_diag(double *__restrict__ A, int ld, int kb,
+                                                     double *__restrict__ Dinv, int *__restrict__ info) {
+  const int lane = threadIdx.x;
+  double *Akk = A + ((size_t)kb * kNB) * ld + (size_t)kb * kNB;
+  double a[kNB];
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) a[c] = Akk[(size_t)lane * ld + c];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kNB; ++j) {
+    const double d = bcast(a[j], j);
+    if (!(d > 0.0)) bad = true;
+    const double ljj = sqrt(d > 0.0 ? d : 1.0);
+    if (lane == j) a[j] = ljj;
+    if (lane > j) a[j] /= ljj;
+#pragma unroll
+    for (int c = j + 1; c < kNB; ++c) {
+      const double lcj = bcast(a[j], c);          // L[c][j]
+      if (lane >= c) a[c] -= a[j] * lcj;
+    }
+  }
+  if (bad && lane == 0) info[0] = kb * kNB + 1;
+  // X = L^-1: lane c owns column c; L[i][m] is broadcast from lane i
+  double x[kNB];
+#pragma unroll
+  for (int i = 0; i < kNB; ++i) {
+    double sacc = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < i; ++m) sacc -= bcast(a[m], i) * x[m];
+    x[i] = sacc / bcast(a[i], i);
+  }
+  double *Dk = Dinv + (size_t)kb * kNB * kNB;
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) {
+    Akk[(size_t)lane * ld + c] = (c <= lane) ? a[c] : 0.0;     // row `lane` of L
+    Dk[(size_t)c * kNB + lane] = x[c];                          // X[c][lane]: column `lane`, row c
+  }
+}
+
+// Panel: A_ik <- A_ik * L_kk^-T = A_ik * Dinv_k^T for block rows i > kb.  grid.x = nb - kb - 1.
+__global__ __launch_bounds__(kBlock) void k_chol_panel(double *__restrict__ A, int ld, int kb,
+                                                       const double *__restrict__ Dinv) {
+  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
+  const int ib = kb + 1 + blockIdx.x;
+  double *Aik = A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB;
+  stage_rows_as_k_minor(Aik, ld, At);                                   // At[k][row] = A_ik[row][k]
+  stage_rows_as_k_minor(Dinv + (size_t)kb * kNB * kNB, kNB, Bt);        // Bt[k][col] = Dinv[col][k]  (C = A * Dinv^T)
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4] = {};
+  tile_fma(At, Bt, tx, ty, acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Aik[(size_t)(4 * ty + i) * ld + 4 * tx + j] = acc[i][j];
+}
+
+// Trailing update: A_ij -= A_ik * A_jk^T for kb < j <= i.  grid = (nb-kb-1, nb-kb-1), blocks with j > i exit.
+__global__ __launch_bounds__(kBlock) void k_chol_trail(double *__restrict__ A, int ld, int kb) {
+  const int ib = kb + 1 + blockIdx.x, jb = kb + 1 + blockIdx.y;
+  if (jb > ib) return;
+  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
+  stage_rows_as_k_minor(A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB, ld, At);
+  stage_rows_as_k_minor(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, Bt);
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4] = {};
+  tile_fma(At, Bt, tx, ty, acc);
+  double *Aij = A + ((size_t)ib * kNB) * ld + (size_t)jb * kNB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] -= acc[i][j];
+}
+
+// W = L^-1, block (i = k + d, k):  W_ik = - Dinv_i * sum_{j=k}^{i-1} L_ij W_jk, anti-diagonal d by anti-diagonal.
+// The j-sum is cut into chunks of kTrChunk tile products computed by separate workgroups (slabs, no atomics) so the
+// late anti-diagonals (few blocks, long sums) still fill the chip; k_trtri_final adds the slabs and applies -Dinv_i.
+constexpr int kTrChunk = 4;
+
+__global__ __launch_bounds__(kBlock) void k_trtri_partial(const double *__restrict__ L, const double *__restrict__ W,
+                                                          int ld, int d, double *__restrict__ slab, int maxchunk) {
+  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
+  const int kb = blockIdx.x, ib = kb + d, ch = blockIdx.y;
+  const int j0 = kb + ch * kTrChunk, j1 = min(ib, j0 + kTrChunk);
+  if (j0 >= ib) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4] = {};
+  for (int jb = j0; jb < j1; ++jb) {
+    __syncthreads();
+    stage_rows_as_k_minor(L + ((size_t)ib * kNB) * ld + (size_t)jb * kNB, ld, At);    // At[m][row] = L_ij[row][m]
+    stage_rows_as_k_major(W + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, Bt);    // Bt[m][col] = W_jk[m][col]
+    __syncthreads();
+    tile_fma(At, Bt, tx, ty, acc);
+  }
+  double *out = slab + ((size_t)kb * maxchunk + ch) * kNB * kNB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(4 * ty + i) * kNB + 4 * tx + j] = acc[i][j];
+}
+
+// d = 0: copy Dinv into the diagonal blocks of W and W^T.  d > 0: W_ik = -Dinv_i * (sum of slabs).
+__global__ __launch_bounds__(kBlock) void k_trtri_final(double *__restrict__ W, double *__restrict__ Wt, int ld, int d,
+                                                        const double *__restrict__ Dinv,
+                                                        const double *__restrict__ slab, int maxchunk) {
+  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
+  const int kb = blockIdx.x, ib = kb + d;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double *Wik = W + ((size_t)ib * kNB) * ld + (size_t)kb * kNB;
+  double *Wtki = Wt + ((size_t)kb * kNB) * ld + (size_t)ib * kNB;      // transposed copy: W^T block (k, i)
+  if (d == 0) {
+    for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
+      const double v = Dinv[(size_t)kb * kNB * kNB + e];
+      Wik[(size_t)(e / kNB) * ld + e % kNB] = v;
+      Wtki[(size_t)(e % kNB) * ld + e / kNB] = v;
+    }
+    return;
+  }
+  const int nch = (d + kTrChunk - 1) / kTrChunk;
+  for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
+    double sacc = 0.0;
+    for (int c = 0; c < nch; ++c) sacc += slab[((size_t)kb * maxchunk + c) * kNB * kNB + e];
+    Bt[(e / kNB) * kLdT + e % kNB] = sacc;                                             // Bt[m][col] = S[m][col]
+  }
+  stage_rows_as_k_minor(Dinv + (size_t)ib * kNB * kNB, kNB, At);                      // At[m][row] = Dinv_i[row][m]
+  __syncthreads();
+  double out[4][4] = {};
+  tile_fma(At, Bt, tx, ty, out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Wik[(size_t)(4 * ty + i) * ld + 4 * tx + j] = -out[i][j];
+      Wtki[(size_t)(4 * tx + j) * ld + 4 * ty + i] = -out[i][j];
+    }
+}
+
+// t = W r (W lower triangular, one wave per row); dot_out[slot] += t.t
+__global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const double *__restrict__ W, int ld,
+                                                     const double *__restrict__ r, double *__restrict__ t,
+                                                     double *__restrict__ dot_out, const double *__restrict__ add0) {
+  __shared__ double red[kBlock / kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * (kBlock / kWave) + wv;
+  double sq = 0.0;
+  if (row < n) {
+    const double2 *Wr = reinterpret_cast<const double2 *>(W + (size_t)row * ld);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    double s = 0.0;
+    const int n2 = (row >> 1) + 1;                 // double2 pairs covering columns 0..row (W is zero above the diagonal)
+#pragma unroll 4
+    for (int j = lane; j < n2; j += 64) {
+      const double2 w = Wr[j], v = r2[j];
+      s += w.x * v.x + w.y * v.y;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      t[row] = s;
+      sq = s * s;
+    }
+  }
+  if (dot_out) {
+    if (lane == 0) red[wv] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int q = 0; q < kBlock / kWave; ++q) s += red[q];
+      if (blockIdx.x == 0 && add0) s += *add0;
+      unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+    }
+  }
+}
+
+// y = W^T t with the explicitly stored transpose (upper triangular rows, one wave per row).
+__global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const double *__restrict__ Wt, int ld,
+                                                           const double *__restrict__ t, double *__restrict__ y) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * (kBlock / kWave) + wv;
+  if (row >= n) return;
+  const double2 *Wr = reinterpret_cast<const double2 *>(Wt + (size_t)row * ld);
+  const double2 *t2 = reinterpret_cast<const double2 *>(t);
+  double s = 0.0;
+  const int n2 = n >> 1;                           // n is a multiple of 64; W^T is zero below the diagonal
+#pragma unroll 4
+  for (int j = (row >> 1) + lane; j < n2; j += 64) {
+    const double2 w = Wr[j], v = t2[j];
+    s += w.x * v.x + w.y * v.y;
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[row] = s;
+}
+
+// Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used, overwritten by L) and build W = L^-1.
+// slab: scratch of (n/kNB) * dense_max_chunks(n) tiles of kNB*kNB doubles.
+inline int dense_max_chunks(int n) { return (n / kNB + kTrChunk - 1) / kTrChunk; }
+
+inline void dense_factor_inverse(double *A, double *W, double *Wt, double *Dinv, double *slab, int n, int ld,
+                                 int *info, hipStream_t s) {
+  const int nb = n / kNB;
+  const int maxchunk = dense_max_chunks(n);
+  for (int k = 0; k < nb; ++k) {
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kWave), 0, s, A, ld, k, Dinv, info);
+    const int rest = nb - k - 1;
+    if (rest > 0) {
+      hipLaunchKernelGGL(k_chol_panel, dim3(rest), dim3(kBlock), 0, s, A, ld, k, Dinv);
+      hipLaunchKernelGGL(k_chol_trail, dim3(rest, rest), dim3(kBlock), 0, s, A, ld, k);
+    }
+  }
+  for (int d = 0; d < nb; ++d) {
+    if (d > 0)
+      hipLaunchKernelGGL(k_trtri_partial, dim3(nb - d, (d + kTrChunk - 1) / kTrChunk), dim3(kBlock), 0, s, A, W, ld, d,
+                         slab, maxchunk);
+    hipLaunchKernelGGL(k_trtri_final, dim3(nb - d), dim3(kBlock), 0, s, W, Wt, ld, d, Dinv, slab, maxchunk);
+  }
+}
+
+// y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
+inline void dense_apply(const double *W, const double *Wt, int n, int ld, const double *r, double *t, double *y,
+                        double *dot_out, const double *add0, hipStream_t s) {
+  hipLaunchKernelGGL(k_tri_gemv, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, W, ld, r, t, dot_out, add0);
+  hipLaunchKernelGGL(k_tri_gemv_upper, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, Wt, ld, t, y);
+}
+
+}  // namespace pl

@@ -23,6 +23,12 @@
 
 namespace pl {
 
+#ifndef PL_TILE_NT_HOME
+#define PL_TILE_NT_HOME false
+#endif
+#ifndef PL_TILE_NT_FOREIGN
+#define PL_TILE_NT_FOREIGN false
+#endif
 constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 24 KiB per workgroup
 
 // Spatial order of the nodes: the bounding box is cut into cubic bricks holding ~nodes_per_brick nodes, bricks are
@@ -30,7 +36,7 @@ constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 2
 // of one brick are contiguous.  perm[new] = old.  tile_start gets the brick boundaries (bricks larger than
 // kTileMaxNodes are cut), ending with N.
 inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &perm, std::vector<int32_t> &tile_start,
-                          double nodes_per_brick = 256.0) {
+                          double nodes_per_brick, std::vector<int64_t> &tile_brick, int64_t nbrick[3]) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int64_t i = 0; i < N; ++i)
     for (int k = 0; k < 3; ++k) {
@@ -45,7 +51,7 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
       ++dims;
     }
   const double side = dims ? std::pow(vol * nodes_per_brick / (double)std::max<int64_t>(N, 1), 1.0 / dims) : 1.0;
-  int64_t nb[3];
+  int64_t *nb = nbrick;
   for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / side));
   std::vector<int64_t> key(N);
   for (int64_t i = 0; i < N; ++i) {
@@ -56,13 +62,17 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
   }
   std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
   tile_start.clear();
+  tile_brick.clear();
   int64_t run0 = 0;
   for (int64_t i = 0; i <= N; ++i) {
     if (i == N || (i > 0 && key[perm[i]] != key[perm[i - 1]])) {
       // close run [run0, i): cut into equal pieces of at most kTileMaxNodes
       const int64_t len = i - run0;
       const int64_t pieces = (len + kTileMaxNodes - 1) / kTileMaxNodes;
-      for (int64_t q = 0; q < pieces; ++q) tile_start.push_back((int32_t)(run0 + q * len / pieces));
+      for (int64_t q = 0; q < pieces; ++q) {
+        tile_start.push_back((int32_t)(run0 + q * len / pieces));
+        tile_brick.push_back(key[perm[run0]]);
+      }
       run0 = i;
     }
   }
@@ -171,11 +181,12 @@ __device__ __forceinline__ void lds_add6(double *dst, V3 f, V3 m) {
   unsafeAtomicAdd(dst + 5, m.z);
 }
 
+template <bool NT>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const double *__restrict__ x,
                                            double *ys) {
   const int2 c = conn2[b];
-  const Record r = load_record(rec, b);
+  const Record r = NT ? load_record_nt(rec, b) : load_record(rec, b);
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
@@ -205,10 +216,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 2
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut(b, n0, n1, conn2, rec, x, ys);
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PL_TILE_NT_HOME>(b, n0, n1, conn2, rec, x, ys);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 2
-  for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock) tile_strut(foreign_idx[k], n0, n1, conn2, rec, x, ys);
+  for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock)
+    tile_strut<PL_TILE_NT_FOREIGN>(foreign_idx[k], n0, n1, conn2, rec, x, ys);
   __syncthreads();
   double acc = 0.0;
   const double2 *ys2 = reinterpret_cast<const double2 *>(ys);

@@ -154,14 +154,17 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     P2 = tmpl[None, :, 3:6] * size[:, None, :] + coord[:, None, :]
     pts = np.stack([P1, P2], axis=2).reshape(-1, 3)             # creation order: cell, strut, end
     key = np.round(pts, 9) + 0.0                                 # +0.0 folds -0.0
-    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    # rows -> one int64 per point through per-axis ranks; lexicographic (x,y,z) order == order of the combined key
+    ranks, sizes = [], []
+    for ax in range(3):
+        uq, inv_ax = np.unique(key[:, ax], return_inverse=True)
+        ranks.append(inv_ax.ravel().astype(np.int64))
+        sizes.append(len(uq))
+    comb = (ranks[0] * sizes[1] + ranks[1]) * sizes[2] + ranks[2]
+    _, first, inv = np.unique(comb, return_index=True, return_inverse=True)
     inv = inv.ravel()
-    xyz_first = pts[first]
-    order = np.lexsort((xyz_first[:, 2], xyz_first[:, 1], xyz_first[:, 0]))   # node index = sort by (x,y,z)
-    rank = np.empty(len(order), np.int64)
-    rank[order] = np.arange(len(order))
-    node_xyz = xyz_first[order]
-    pid = rank[inv].reshape(C, nb, 2)
+    node_xyz = pts[first]                                        # first creator's coordinates, sorted by (x,y,z)
+    pid = inv.reshape(C, nb, 2)
 
     N = len(node_xyz)
     lo = np.minimum(pid[..., 0], pid[..., 1]).ravel()

@@ -327,3 +327,36 @@ def test_full_size_properties_config2():
                 dev.set_bc(fixed, None, f)
                 u2, _ = dev.solve(rtol=1e-8, max_iter=20000)
                 assert _rel(u2, u_ref) < 1e-6                                    # two independent kernels agree
+
+
+@pytest.mark.parametrize("name", ["bcc_4x4x4", "bcc_6x3x3_flexion"])
+def test_two_level_preconditioner_same_solution_fewer_iterations(golden_dir, name):
+    """precond = 2 (Jacobi + rigid-body coarse space) must give the same displacements as Jacobi-PCG."""
+    _, L = _sim(golden_dir, name)
+    f = np.zeros((L.lattice.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    res = {}
+    for pc in (1, 2):
+        with _device(L, precond=pc, tile_nodes=32, coarse_max_dofs=600) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            res[pc] = dev.solve(rtol=1e-11)
+    (u1, s1), (u2, s2) = res[1], res[2]
+    assert s2["converged"] == 1
+    assert _rel(u2, u1) < 1e-8
+    assert s2["iterations"] < s1["iterations"]
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 700])
+def test_device_dense_spd_solver(n):
+    """Blocked Cholesky + inverse factor on the device (coarse solver of the two-level preconditioner) vs numpy."""
+    rng = np.random.default_rng(n)
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    x, quad = _capi.debug_spd_solve(A, b)
+    ref = np.linalg.solve(A, b)
+    assert _rel(x, ref) < 1e-11
+    assert abs(quad - b @ ref) < 1e-11 * abs(b @ ref)
+    with pytest.raises(_capi.PlError):
+        _capi.debug_spd_solve(-A, b)

@@ -20,6 +20,7 @@ ap.add_argument("--geom", default="Octet")
 ap.add_argument("--radius", type=float, default=0.03)
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--precond", type=int, default=1)
 args = ap.parse_args()
 n = args.cells
 lat = LA.generate((1, 1, 1), (n, n, n), [args.geom], [args.radius])
@@ -29,8 +30,9 @@ fixed[lat.node_xyz[:, 0] == 0.0] = 1
 f = np.zeros((lat.n_nodes, 6))
 f[lat.node_xyz[:, 0] == float(n), 2] = -0.1
 d = _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
-                     spmv_kernel=args.kernel)
+                     spmv_kernel=args.kernel, precond=args.precond)
 d.set_bc(fixed, None, f)
+d.assemble()
 d.assemble()
 d.assemble_bsr(False)
 out = {"spmv_ms": d.time_kernel(0, args.reps), "pcg_iter_ms": d.time_kernel(3, args.reps),
