@@ -10,8 +10,9 @@ For N > 1 GPUs the lattice is 50 x (50 N) x 50 cut into N y-slabs of 50 layers (
 GPU; growing along y keeps the cantilever's aspect ratio, hence its conditioning, fixed); interface forces and
 PCG dot products are all-reduced with RCCL inside libpylattice_hip.
 
-One "step" = per-strut stiffness build (condensed records + Jacobi diagonal) + explicit BSR(6x6) global-K
-assembly + matrix-free Jacobi-PCG solve to ||r|| <= rtol ||b|| — all on data already resident in HBM.
+One "step" = per-strut stiffness build (condensed records + Jacobi diagonal + coarse operator of the two-level
+preconditioner and its dense factorisation) + explicit BSR(6x6) global-K assembly + matrix-free PCG solve to
+||r|| <= rtol ||b|| — all on data already resident in HBM.
 value = struts of the whole job * steps / time.  The roofline object prices the dominant kernel (K*p) with the
 algorithmic bytes of SURVEY.md 8(d) and a HIP-event timing taken on the library's own stream; cpu_baseline is the
 plain-C oracle (oracle/beam_pcg.c, 1 thread) on a bounded sample of the same workload.
@@ -81,7 +82,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
-    ap.add_argument("--precond", type=int, default=1, help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space")
+    ap.add_argument("--precond", type=int, default=2, help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space")
     ap.add_argument("--kernels-only", action="store_true", help="skip the timed steps, only time the kernels")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
@@ -120,8 +121,14 @@ def main():
         xyz, conn, rad, seg_len, seg_nsub = slab.node_xyz, slab.beam_conn, slab.beam_radius, slab.seg_len, slab.seg_nsub
     log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
 
+    grid = None
+    if world > 1:
+        # every rank must cut the same brick / aggregate grid: hand over the box and node count of the whole lattice
+        nn = torch.tensor([float(len(xyz))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn)
+        grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond)
+                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid)
     n_beams_total = len(conn)
     if world > 1:
         keys = [None] * world
@@ -194,7 +201,8 @@ def main():
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"],
                    "preconditioner": "Jacobi" if args.precond == 1 else "two-level (Jacobi + rigid-body coarse space)",
-                   "step": "records + Jacobi diag" + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
+                   "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond == 2 else "")
+                           + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -65,6 +65,11 @@ typedef struct {
   int32_t tile_nodes;    /* target nodes per brick/tile of the spatial reordering, <= 512 (0 -> 256) */
   int32_t coarse_max_dofs; /* precond = 2: upper bound on 6 * (number of aggregates) (0 -> 3072) */
   int32_t reserved[4];
+  /* Multi-GPU only: bounding box and node count of the WHOLE lattice, so that every rank cuts the same brick /
+   * aggregate grid (all zero -> derived from this handle's own nodes). */
+  double grid_lo[3];
+  double grid_hi[3];
+  int64_t grid_nodes;
 } pl_opts_t;
 
 typedef struct {

@@ -245,7 +245,7 @@ int launch_diag(pl_context *c) {
 int build_coarse(pl_context *c) {
   pl::Coarse &cs = c->coarse;
   cs.ready = false;
-  if (!cs.enabled || !c->have_bc || c->dist.active) return PL_OK;
+  if (!cs.enabled || !c->have_bc) return PL_OK;
   const int n = cs.ncp;
   PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
   PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
@@ -255,6 +255,10 @@ int build_coarse(pl_context *c) {
     hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
                        cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
                        c->fixedbits.p, n, cs.Ac);
+  if (c->dist.active) {   // every rank holds the contribution of ITS struts; all ranks then factor the same matrix
+    if (pl::dist_sum_scalars(c->dist, cs.Ac, n * n, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
+  }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
   pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, cs.slab, n, n, cs.info, c->stream);
   PL_HIP(hipGetLastError());
@@ -284,10 +288,16 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   pl::Coarse &cs = c->coarse;
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, c->dinv.p,
-                     (const double *)nullptr, c->x.p, c->r.p, cur, cs.part);
+                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
+                     cs.part);
   hipLaunchKernelGGL(pl::k_coarse_gather, dim3((unsigned)((cs.nc + pl::kBlock - 1) / pl::kBlock + 1)),
                      dim3(pl::kBlock), 0, c->stream, cs.n_agg, cs.agg_tile_ptr.p, cs.agg_tile_idx.p, cs.part,
-                     cs.n_tiles, cs.rc, cur);
+                     cs.n_tiles, cs.rc, cur, cs.ncp);
+  if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
+    if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
+    hipLaunchKernelGGL(pl::k_coarse_scalars_from_rc, dim3(1), dim3(64), 0, c->stream, cs.rc, cs.ncp, cur);
+  }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cur + pl::S_RDR * pl::kSlots, c->stream);
   hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3(grid_stream(c->N)), dim3(pl::kBlock), 0, c->stream, c->N,
@@ -549,15 +559,17 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreate(&c->ev1));
 
   // node ordering on the device
+  const double global_grid[7] = {o->grid_lo[0], o->grid_lo[1], o->grid_lo[2], o->grid_hi[0], o->grid_hi[1],
+                                 o->grid_hi[2], (double)o->grid_nodes};
   c->perm.resize(N);
   std::iota(c->perm.begin(), c->perm.end(), 0);
   std::vector<int32_t> tile_start, tile_of;
   std::vector<int64_t> tile_brick;
-  int64_t nbrick[3] = {1, 1, 1};
+  pl::BrickGrid grid;
   if (o->reorder == 1) {
     pl::spatial_order(m->node_xyz, N, c->perm, tile_start,
                       (double)(o->tile_nodes > 0 ? std::min(o->tile_nodes, pl::kTileMaxNodes) : 256), tile_brick,
-                      nbrick);
+                      grid, o->grid_nodes > 0 ? global_grid : nullptr);
     c->reordered = true;
   } else {
     pl::chunk_tiles(N, tile_start);
@@ -607,7 +619,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (o->precond == 2) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2 (two-level) needs reorder = 1"));
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
-    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, nbrick, xyz.data(), N, max_dofs, conn);
+    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
   }
 

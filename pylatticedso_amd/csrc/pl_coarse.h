@@ -48,40 +48,38 @@ struct Coarse {
   }
 };
 
-// Host: aggregates = groups of g^3 bricks.  brick_coord[t] = integer brick coordinates of tile t, nbrick = grid size.
+// Host: aggregates = groups of g^3 bricks of the (global) brick grid; ids are dense over the whole aggregate grid so
+// that all ranks of a multi-GPU run agree (aggregates without nodes give identity rows).  The reference point of an
+// aggregate's rigid-body modes is the geometric centre of its cell (any point spans the same space).
 inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const std::vector<int64_t> &tile_brick,
-                        const int64_t nbrick[3], const double *xyz_dev_order, int64_t N, int max_dofs,
+                        const BrickGrid &grid, const double *xyz_dev_order, int64_t N, int max_dofs,
                         const std::vector<int32_t> &conn) {
   const int64_t T = (int64_t)tile_start.size() - 1;
+  const int64_t *nbrick = grid.nb;
   int g = 2;
   int64_t na[3];
   for (;; ++g) {
     for (int k = 0; k < 3; ++k) na[k] = (nbrick[k] + g - 1) / g;
     if (na[0] * na[1] * na[2] * 6 <= max_dofs || g > 64) break;
   }
-  std::vector<int64_t> raw(T);
+  const int n_agg = (int)(na[0] * na[1] * na[2]);
+  std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
+  std::vector<double> cen((size_t)n_agg * 3, 0.0);
+  for (int64_t a0 = 0; a0 < na[0]; ++a0)
+    for (int64_t a1 = 0; a1 < na[1]; ++a1)
+      for (int64_t a2 = 0; a2 < na[2]; ++a2) {
+        const int64_t a = (a0 * na[1] + a1) * na[2] + a2;
+        const int64_t ai[3] = {a0, a1, a2};
+        for (int k = 0; k < 3; ++k) cen[3 * a + k] = grid.lo[k] + (ai[k] + 0.5) * g * grid.side;
+      }
   for (int64_t t = 0; t < T; ++t) {
     const int64_t key = tile_brick[t];
     const int64_t b2 = key % nbrick[2], b1 = (key / nbrick[2]) % nbrick[1], b0 = key / (nbrick[2] * nbrick[1]);
-    raw[t] = ((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g);
-  }
-  std::vector<int64_t> uq(raw);
-  std::sort(uq.begin(), uq.end());
-  uq.erase(std::unique(uq.begin(), uq.end()), uq.end());
-  const int n_agg = (int)uq.size();
-  std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
-  std::vector<double> cen((size_t)n_agg * 3, 0.0), cnt(n_agg, 0.0);
-  for (int64_t t = 0; t < T; ++t) {
-    const int a = (int)(std::lower_bound(uq.begin(), uq.end(), raw[t]) - uq.begin());
+    const int a = (int)(((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g));
     agg_of_tile[t] = a;
-    for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) {
-      agg_of_node[i] = a;
-      for (int k = 0; k < 3; ++k) cen[3 * a + k] += xyz_dev_order[3 * (size_t)i + k];
-      cnt[a] += 1.0;
-    }
+    for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) agg_of_node[i] = a;
   }
-  for (int a = 0; a < n_agg; ++a)
-    for (int k = 0; k < 3; ++k) cen[3 * a + k] /= std::max(cnt[a], 1.0);
+  (void)xyz_dev_order;
   std::vector<int32_t> ptr(n_agg + 1, 0), idx(T);
   for (int64_t t = 0; t < T; ++t) ptr[agg_of_tile[t] + 1]++;
   for (int a = 0; a < n_agg; ++a) ptr[a + 1] += ptr[a];
@@ -119,11 +117,11 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
       hipSuccess)
     return 2;
   if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.rc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;   // + rr, r.D^-1 r
   if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
-  if (hipMemset(c.rc, 0, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.W, 0, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.Wt, 0, n2 * sizeof(double)) != hipSuccess) return 2;
   c.enabled = true;
@@ -387,7 +385,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
 __global__ __launch_bounds__(kBlock) void k_coarse_gather(int n_agg, const int32_t *__restrict__ ptr,
                                                           const int32_t *__restrict__ idx,
                                                           const double *__restrict__ part, int64_t T,
-                                                          double *__restrict__ rc, double *__restrict__ scal) {
+                                                          double *__restrict__ rc, double *__restrict__ scal,
+                                                          int ncp) {
   __shared__ double red[2][kBlock / kWave];
   if (blockIdx.x + 1 < gridDim.x) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -414,6 +413,16 @@ __global__ __launch_bounds__(kBlock) void k_coarse_gather(int n_agg, const int32
     for (int q = 0; q < kBlock / kWave; ++q) { a += red[0][q]; b += red[1][q]; }
     scal[S_RR * kSlots] = a;          // the set's accumulators were zeroed by the previous direction kernel
     scal[S_RDR * kSlots] = b;
+    rc[ncp] = a;                      // multi-GPU: the two scalars ride in the tail of the r_c all-reduce
+    rc[ncp + 1] = b;
+  }
+}
+
+// multi-GPU: after the all-reduce of [r_c | rr | r.D^-1 r] put the global scalars back into the scalar set
+__global__ void k_coarse_scalars_from_rc(const double *__restrict__ rc, int ncp, double *__restrict__ scal) {
+  if (threadIdx.x == 0) {
+    scal[S_RR * kSlots] = rc[ncp];
+    scal[S_RDR * kSlots] = rc[ncp + 1];
   }
 }
 

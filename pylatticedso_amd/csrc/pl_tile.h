@@ -35,14 +35,33 @@ constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 2
 // walked x-slab by x-slab (an XCD's contiguous share of the tile range is then a slab of the lattice) and the nodes
 // of one brick are contiguous.  perm[new] = old.  tile_start gets the brick boundaries (bricks larger than
 // kTileMaxNodes are cut), ending with N.
+struct BrickGrid {
+  double lo[3] = {0, 0, 0};
+  double side = 1.0;
+  int64_t nb[3] = {1, 1, 1};
+};
+
+// If `global` is non-null it holds {lo[3], hi[3], node count} of the WHOLE lattice (multi-GPU: every rank must cut
+// the same grid); otherwise the grid is derived from these nodes.
 inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &perm, std::vector<int32_t> &tile_start,
-                          double nodes_per_brick, std::vector<int64_t> &tile_brick, int64_t nbrick[3]) {
+                          double nodes_per_brick, std::vector<int64_t> &tile_brick, BrickGrid &grid,
+                          const double *global = nullptr) {
+  int64_t *nbrick = grid.nb;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  for (int64_t i = 0; i < N; ++i)
+  int64_t Ntot = N;
+  if (global) {
     for (int k = 0; k < 3; ++k) {
-      lo[k] = std::min(lo[k], xyz[3 * i + k]);
-      hi[k] = std::max(hi[k], xyz[3 * i + k]);
+      lo[k] = global[k];
+      hi[k] = global[3 + k];
     }
+    Ntot = (int64_t)global[6];
+  } else {
+    for (int64_t i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(lo[k], xyz[3 * i + k]);
+        hi[k] = std::max(hi[k], xyz[3 * i + k]);
+      }
+  }
   double vol = 1.0;
   int dims = 0;
   for (int k = 0; k < 3; ++k)
@@ -50,7 +69,9 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
       vol *= hi[k] - lo[k];
       ++dims;
     }
-  const double side = dims ? std::pow(vol * nodes_per_brick / (double)std::max<int64_t>(N, 1), 1.0 / dims) : 1.0;
+  const double side = dims ? std::pow(vol * nodes_per_brick / (double)std::max<int64_t>(Ntot, 1), 1.0 / dims) : 1.0;
+  grid.side = side;
+  for (int k = 0; k < 3; ++k) grid.lo[k] = lo[k];
   int64_t *nb = nbrick;
   for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / side));
   std::vector<int64_t> key(N);

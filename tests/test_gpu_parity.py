@@ -280,6 +280,14 @@ def test_rccl_path_with_single_rank_communicator(golden_dir):
         u1, st1 = dev.solve(rtol=1e-11)
         x = np.random.default_rng(0).standard_normal(6 * lat.n_nodes)
         y1 = dev.spmv(x)
+    # same with the two-level preconditioner and an explicit global grid (what bench.py passes for N > 1)
+    grid = (lat.bbox[0::2], lat.bbox[1::2], lat.n_nodes)
+    with _device(L, precond=2, tile_nodes=32, coarse_max_dofs=600, grid=grid) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        u2, st2 = dev.solve(rtol=1e-11)
+    assert _rel(u2, u0) < 1e-8 and st2["iterations"] < st0["iterations"]
     with _device(L) as ref:
         ref.assemble()
         y0 = ref.spmv(x)
