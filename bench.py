@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
     ap.add_argument("--precond", type=int, default=2, help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space")
-    ap.add_argument("--kernels-only", action="store_true", help="skip the timed steps, only time the kernels")
+    ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     args = ap.parse_args()
@@ -128,7 +128,7 @@ def main():
         dist.all_reduce(nn)
         grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid)
+                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette)
     n_beams_total = len(conn)
     if world > 1:
         keys = [None] * world
@@ -187,7 +187,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
     if world == 1 and n == 50 and args.geom == "Octet" and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
-        if pmc.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder):
+        if pmc.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder) and \
+                pmc.get("record_palette", 0) == args.palette:
             traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
 
     out = {
@@ -203,7 +204,7 @@ def main():
                    "preconditioner": "Jacobi" if args.precond == 1 else "two-level (Jacobi + rigid-body coarse space)",
                    "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond == 2 else "")
                            + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
-                   "spmv_kernel": args.kernel, "reorder": args.reorder},
+                   "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},

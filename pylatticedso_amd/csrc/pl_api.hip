@@ -14,6 +14,7 @@
 #include "pl_tile.h"
 #include "pl_dist.h"
 #include "pl_coarse.h"
+#include "pl_palette.h"
 
 namespace {
 
@@ -97,6 +98,13 @@ struct pl_context {
   // LDS-tile operator
   pl::TilePlan tile;
   DevBuf<int32_t> tile_start_dev_unused;
+  // record palette (pl_palette.h)
+  DevBuf<unsigned long long> pal_keys;
+  DevBuf<int> pal_owner, pal_flags;
+  DevBuf<uint16_t> pal_id;
+  DevBuf<pl::Record> palette;
+  bool pal_ready = false;
+  int pal_entries = 0;
   // two-level preconditioner (rigid-body coarse space)
   pl::Coarse coarse;
   int coarse_info = 0;
@@ -192,7 +200,12 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
       hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
   } else if (kind == 3 && c->tile.ready) {
-    pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream);
+    if (c->pal_ready)
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
+                           dot_dev, c->stream);
+    else
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y, dot_dev,
+                           c->stream);
   } else {
     int rc = dispatch_gather(c, x, y, masked, dot_dev);
     if (rc) return rc;
@@ -219,6 +232,37 @@ int launch_records(pl_context *c) {
   hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
                      c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mat, c->rec.p);
   PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// Try to replace the per-strut records by palette ids (periodic lattices); leaves pal_ready = false otherwise.
+int build_palette(pl_context *c) {
+  c->pal_ready = false;
+  if (!c->opt.palette) return PL_OK;
+  if (!c->pal_keys.p) {
+    PL_HIP(c->pal_keys.alloc(pl::kPalSize));
+    PL_HIP(c->pal_owner.alloc(pl::kPalSize));
+    PL_HIP(c->pal_flags.alloc(2));
+    PL_HIP(c->pal_id.alloc(c->B));
+    PL_HIP(c->palette.alloc(pl::kPalSize));
+  }
+  PL_HIP(hipMemsetAsync(c->pal_keys.p, 0xFF, pl::kPalSize * sizeof(unsigned long long), c->stream));
+  PL_HIP(hipMemsetAsync(c->pal_owner.p, 0x7F, pl::kPalSize * sizeof(int), c->stream));
+  PL_HIP(hipMemsetAsync(c->pal_flags.p, 0, 2 * sizeof(int), c->stream));
+  PL_HIP(hipMemsetAsync(c->palette.p, 0, pl::kPalSize * sizeof(pl::Record), c->stream));
+  const dim3 g(grid_for(c->B)), blk(pl::kBlock);
+  hipLaunchKernelGGL(pl::k_pal_insert, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_keys.p, c->pal_owner.p,
+                     c->pal_id.p, c->pal_flags.p);
+  hipLaunchKernelGGL(pl::k_pal_publish, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_owner.p, c->pal_id.p,
+                     c->palette.p);
+  hipLaunchKernelGGL(pl::k_pal_verify, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_id.p, c->palette.p,
+                     c->pal_owner.p, c->pal_flags.p);
+  PL_HIP(hipGetLastError());
+  int flags[2] = {1, 0};
+  PL_HIP(hipMemcpyAsync(flags, c->pal_flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  c->pal_entries = flags[1];
+  c->pal_ready = (flags[0] == 0);
   return PL_OK;
 }
 
@@ -720,6 +764,8 @@ int pl_assemble(pl_handle h) {
   PL_HIP(hipEventRecord(h->ev0, h->stream));
   int rc = launch_records(h);
   if (rc) return rc;
+  rc = build_palette(h);
+  if (rc) return rc;
   rc = launch_diag(h);
   if (rc) return rc;
   rc = build_coarse(h);
@@ -969,7 +1015,10 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   auto one = [&](int k) -> int {
     switch (which) {
       case 0: return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots);
-      case 1: return launch_records(h);
+      case 1: {
+        int r1 = launch_records(h);
+        return r1 ? r1 : build_palette(h);
+      }
       case 2: return launch_bsr_fill(h, 0);
       case 3: return pcg_iteration(h, k);
       case 4:

@@ -67,18 +67,6 @@ __device__ __forceinline__ Record load_record(const Record *__restrict__ rec, in
   return r;
 }
 
-// Streaming (read-once) variant: non-temporal loads keep the 64-B records out of the way of the x rows that the
-// same XCD's L2 should retain for the halo gathers.
-__device__ __forceinline__ Record load_record_nt(const Record *__restrict__ rec, int64_t i) {
-  const double *q = reinterpret_cast<const double *>(rec + i);
-  Record r;
-  r.a = __builtin_nontemporal_load(q + 0); r.c = __builtin_nontemporal_load(q + 1);
-  r.e1 = __builtin_nontemporal_load(q + 2); r.e2 = __builtin_nontemporal_load(q + 3);
-  r.e3 = __builtin_nontemporal_load(q + 4); r.dx = __builtin_nontemporal_load(q + 5);
-  r.dy = __builtin_nontemporal_load(q + 6); r.dz = __builtin_nontemporal_load(q + 7);
-  return r;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Record build: one thread per strut ("local stiffness build").
 // ---------------------------------------------------------------------------------------------------------

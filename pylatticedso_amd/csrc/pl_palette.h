@@ -1,0 +1,83 @@
+// Record palette: periodic lattices repeat a handful of distinct strut records millions of times.  After the record
+// build, struts are hashed (record quantised to 40 mantissa bits) into a 65 536-slot open-addressing table; if every
+// strut finds a slot within a few probes and no two different records share one, K*p reads a 2-byte palette id per
+// strut instead of its 64-byte record (the table itself, 4 MiB, stays in L2).  Graded / optimised lattices with more
+// distinct records than the table holds simply keep the plain path (ok flag = 0).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pl_kernels.h"
+
+namespace pl {
+
+constexpr int kPalBits = 16;
+constexpr int kPalSize = 1 << kPalBits;
+constexpr int kPalProbes = 32;
+constexpr unsigned long long kPalEmpty = ~0ull;
+
+__device__ __forceinline__ unsigned long long pal_quant(double v) {
+  return (unsigned long long)__double_as_longlong(v + 0.0) & ~0xFFFull;       // drop 12 of 52 mantissa bits
+}
+__device__ __forceinline__ unsigned long long pal_hash(const Record &r) {
+  const double f[8] = {r.a, r.c, r.e1, r.e2, r.e3, r.dx, r.dy, r.dz};
+  unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    h ^= pal_quant(f[k]) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+  }
+  return h == kPalEmpty ? 0 : h;
+}
+
+// pass 1: claim a slot per distinct hash; owner[slot] = smallest strut id that uses it; flags[0] = 1 on overflow
+__global__ __launch_bounds__(kBlock) void k_pal_insert(int64_t B, const Record *__restrict__ rec,
+                                                       unsigned long long *__restrict__ keys,
+                                                       int *__restrict__ owner, uint16_t *__restrict__ pal,
+                                                       int *__restrict__ flags) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long h = pal_hash(load_record(rec, b));
+  unsigned slot = (unsigned)(h >> (64 - kPalBits));
+  for (int probe = 0; probe < kPalProbes; ++probe) {
+    unsigned long long cur = keys[slot];
+    if (cur == kPalEmpty) cur = atomicCAS(keys + slot, kPalEmpty, h);
+    if (cur == kPalEmpty || cur == h) {
+      // owner = smallest strut id of the slot.  It only decreases, so a (possibly stale) read that is already
+      // smaller lets almost every thread skip the atomic: millions of struts share a few hundred slots.
+      if ((int)b < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(owner + slot, (int)b);
+      pal[b] = (uint16_t)slot;
+      return;
+    }
+    slot = (slot + 1) & (kPalSize - 1);
+  }
+  flags[0] = 1;
+}
+// pass 2: the owner publishes its record
+__global__ __launch_bounds__(kBlock) void k_pal_publish(int64_t B, const Record *__restrict__ rec,
+                                                        const int *__restrict__ owner,
+                                                        const uint16_t *__restrict__ pal,
+                                                        Record *__restrict__ palette) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const unsigned slot = pal[b];
+  if (owner[slot] == (int)b) palette[slot] = rec[b];
+}
+// pass 3: every strut checks that its slot really holds its (quantised) record; counts the distinct entries
+__global__ __launch_bounds__(kBlock) void k_pal_verify(int64_t B, const Record *__restrict__ rec,
+                                                       const uint16_t *__restrict__ pal,
+                                                       const Record *__restrict__ palette,
+                                                       const int *__restrict__ owner, int *__restrict__ flags) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const Record r = load_record(rec, b), q = load_record(palette, pal[b]);
+  const bool same = pal_quant(r.a) == pal_quant(q.a) && pal_quant(r.c) == pal_quant(q.c) &&
+                    pal_quant(r.e1) == pal_quant(q.e1) && pal_quant(r.e2) == pal_quant(q.e2) &&
+                    pal_quant(r.e3) == pal_quant(q.e3) && pal_quant(r.dx) == pal_quant(q.dx) &&
+                    pal_quant(r.dy) == pal_quant(q.dy) && pal_quant(r.dz) == pal_quant(q.dz);
+  if (!same) flags[0] = 1;
+  if (owner[pal[b]] == (int)b) atomicAdd(flags + 1, 1);
+}
+
+}  // namespace pl

@@ -23,12 +23,6 @@
 
 namespace pl {
 
-#ifndef PL_TILE_NT_HOME
-#define PL_TILE_NT_HOME false
-#endif
-#ifndef PL_TILE_NT_FOREIGN
-#define PL_TILE_NT_FOREIGN false
-#endif
 constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 24 KiB per workgroup
 
 // Spatial order of the nodes: the bounding box is cut into cubic bricks holding ~nodes_per_brick nodes, bricks are
@@ -202,12 +196,13 @@ __device__ __forceinline__ void lds_add6(double *dst, V3 f, V3 m) {
   unsafeAtomicAdd(dst + 5, m.z);
 }
 
-template <bool NT>
+// PAL: the record comes from the palette table through a 2-byte id (pl_palette.h) instead of rec[b].
+template <bool PAL>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
-                                           const Record *__restrict__ rec, const double *__restrict__ x,
-                                           double *ys) {
+                                           const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
+                                           const double *__restrict__ x, double *ys) {
   const int2 c = conn2[b];
-  const Record r = NT ? load_record_nt(rec, b) : load_record(rec, b);
+  const Record r = PAL ? load_record(rec, pal[b]) : load_record(rec, b);
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
@@ -219,12 +214,13 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
   }
 }
 
-template <bool MASK, bool DOT>
+template <bool MASK, bool DOT, bool PAL>
 __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ home_ptr,
                                                       const int64_t *__restrict__ foreign_ptr,
                                                       const int32_t *__restrict__ foreign_idx,
                                                       const int2 *__restrict__ conn2, const Record *__restrict__ rec,
+                                                      const uint16_t *__restrict__ pal,
                                                       const uint8_t *__restrict__ fixedbits,
                                                       const double *__restrict__ x, double *__restrict__ y,
                                                       double *__restrict__ dot_out) {
@@ -237,11 +233,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 2
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PL_TILE_NT_HOME>(b, n0, n1, conn2, rec, x, ys);
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 2
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock)
-    tile_strut<PL_TILE_NT_FOREIGN>(foreign_idx[k], n0, n1, conn2, rec, x, ys);
+    tile_strut<PAL>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys);
   __syncthreads();
   double acc = 0.0;
   const double2 *ys2 = reinterpret_cast<const double2 *>(ys);
@@ -267,17 +263,25 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
   }
 }
 
-inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint8_t *fixedbits,
-                             const double *x, double *y, double *dot_dev, hipStream_t s) {
+// pal != nullptr: `rec` is the palette table and pal[b] the strut's entry.
+inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
+                             const uint8_t *fixedbits, const double *x, double *y, double *dot_dev, hipStream_t s) {
   const dim3 g((unsigned)plan.n_tiles), blk(kBlock);
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
-#define PL_T(M, D)                                                                                          \
-  hipLaunchKernelGGL((k_spmv_tile<M, D>), g, blk, 0, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
-                     plan.foreign_idx.p, conn2, rec, fixedbits, x, y, dot_dev)
-  if (fixedbits && dot_dev) PL_T(true, true);
-  else if (fixedbits) PL_T(true, false);
-  else if (dot_dev) PL_T(false, true);
-  else PL_T(false, false);
+#define PL_T(M, D, P)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_tile<M, D, P>), g, blk, 0, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
+                     plan.foreign_idx.p, conn2, rec, pal, fixedbits, x, y, dot_dev)
+  if (pal) {
+    if (fixedbits && dot_dev) PL_T(true, true, true);
+    else if (fixedbits) PL_T(true, false, true);
+    else if (dot_dev) PL_T(false, true, true);
+    else PL_T(false, false, true);
+  } else {
+    if (fixedbits && dot_dev) PL_T(true, true, false);
+    else if (fixedbits) PL_T(true, false, false);
+    else if (dot_dev) PL_T(false, true, false);
+    else PL_T(false, false, false);
+  }
 #undef PL_T
 }
 

@@ -368,3 +368,22 @@ def test_device_dense_spd_solver(n):
     assert abs(quad - b @ ref) < 1e-11 * abs(b @ ref)
     with pytest.raises(_capi.PlError):
         _capi.debug_spd_solve(-A, b)
+
+
+@pytest.mark.parametrize("name", ["bcc_4x4x4", "octet_3x2x2_size", "bcc_3x2x2_gradradius"])
+def test_record_palette_matches_plain_records(golden_dir, name):
+    """palette = 1 (2-byte ids into a table of distinct records, compared on 40 mantissa bits) vs per-strut records."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    x = np.random.default_rng(4).standard_normal(6 * lat.n_nodes)
+    with _device(L, spmv_kernel=3) as dev:
+        dev.assemble()
+        y0 = dev.spmv(x)
+    with _device(L, spmv_kernel=3, palette=1) as dev:
+        dev.assemble()
+        y1 = dev.spmv(x)
+        dev.update_radii(lat.beam_radius * 1.1)      # palette is rebuilt with the records
+        dev.assemble()
+        y2 = dev.spmv(x)
+    assert _rel(y1, y0) < 1e-11
+    assert _rel(y2, y0) > 1e-3

@@ -20,7 +20,8 @@ ap.add_argument("--geom", default="Octet")
 ap.add_argument("--radius", type=float, default=0.03)
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--precond", type=int, default=1)
+ap.add_argument("--precond", type=int, default=2)
+ap.add_argument("--palette", type=int, default=1)
 args = ap.parse_args()
 n = args.cells
 lat = LA.generate((1, 1, 1), (n, n, n), [args.geom], [args.radius])
@@ -30,7 +31,7 @@ fixed[lat.node_xyz[:, 0] == 0.0] = 1
 f = np.zeros((lat.n_nodes, 6))
 f[lat.node_xyz[:, 0] == float(n), 2] = -0.1
 d = _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
-                     spmv_kernel=args.kernel, precond=args.precond)
+                     spmv_kernel=args.kernel, precond=args.precond, palette=args.palette)
 d.set_bc(fixed, None, f)
 d.assemble()
 d.assemble()

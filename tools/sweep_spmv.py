@@ -30,7 +30,7 @@ for v in args.variants.split(","):
     opt = dict(tok[0] and (tok[0], int(tok[1:])) for tok in v.split(":"))
     d = _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
                          spmv_kernel=opt.get("k", 0), lanes_per_node=opt.get("l", 0), reorder=opt.get("r", 1),
-                         tile_nodes=opt.get("t", 0))
+                         tile_nodes=opt.get("t", 0), palette=opt.get("p", 0))
     d.set_bc(fixed, None, f)
     d.assemble()
     devs[v] = d
