@@ -1,0 +1,41 @@
+"""The reference's import paths resolve (src/pyLatticeSim, src/pyLatticeDesign, src/pyLatticeOpti) and presets are
+looked up under data/inputs/preset_lattice like utils.open_lattice_parameters does (utils.py:111-130)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "src"))
+
+
+def test_imports_and_preset_lookup():
+    from pyLatticeSim.lattice_sim import LatticeSim
+    from pyLatticeSim.utils_simulation import solve_FEM_FenicsX          # noqa: F401
+    from pyLatticeSim.utils_schur import get_schur_complement            # noqa: F401
+    from pyLatticeSim.export_simulation_results import exportSimulationResults   # noqa: F401
+    from pyLatticeDesign.plotting_lattice import LatticePlotting         # noqa: F401
+    from pyLatticeOpti.lattice_opti import LatticeOpti                   # noqa: F401
+    L = LatticeSim("simulation/simulation_beam_flexion")
+    assert (L.get_number_cells(), L.get_number_beams(), L.get_number_nodes()) == (54, 432, 166)
+    assert L.material_name == "VeroClear" and L.is_penalized
+    # 432 struts -> 1 288 penalised segments, as in the reference
+    assert int((L.penalized.seg_len > 0).sum()) == 1288
+    with pytest.raises(FileNotFoundError):
+        LatticeSim("simulation/does_not_exist")
+
+
+@pytest.mark.gpu
+def test_simulation_example_end_to_end(tmp_path):
+    from pyLatticeSim.lattice_sim import LatticeSim
+    from pyLatticeSim.utils_simulation import solve_FEM_FenicsX
+    from pyLatticeSim.export_simulation_results import exportSimulationResults
+    L = LatticeSim("simulation/simulation_beam_flexion")
+    sol, model = solve_FEM_FenicsX(L)
+    assert len(sol) == 572 and np.isfinite(sol).all()
+    # prescribed displacement is honoured and the loaded edge moves in +Y
+    assert np.allclose(L.displacement_vector[L.fixed_DOF], np.where(L.fixed_DOF, model._ubar, 0)[L.fixed_DOF])
+    ex = exportSimulationResults(model, "t", out_dir=str(tmp_path))
+    ex.export_displacement_rotation()
+    assert os.path.getsize(ex.export_finalize()) > 1000
