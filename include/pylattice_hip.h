@@ -67,6 +67,7 @@ typedef struct {
   int32_t palette;       /* 1: K*p (LDS-tile kernel) reads 2-byte palette ids instead of 64-byte records when the lattice
                             has <= ~30 000 distinct records (compared on 40 mantissa bits, i.e. to 1e-12) */
   int32_t reserved[3];
+  double alpha_max;      /* > 0: clamp the CG step like conjugate_gradient_solver.py:79 (DDM solves use 100) */
   /* Multi-GPU only: bounding box and node count of the WHOLE lattice, so that every rank cuts the same brick /
    * aggregate grid (all zero -> derived from this handle's own nodes). */
   double grid_lo[3];
@@ -93,6 +94,14 @@ const char *pl_version(void);
  * latticeGeneration (beam_model.py:57-105, lattice_generation.py:64-175). */
 int pl_create(const pl_mesh_t *mesh, const pl_opts_t *opts, pl_handle *out);
 void pl_destroy(pl_handle h);
+
+/* Domain-decomposition operator (LatticeSim.solve_DDM, lattice_sim.py:1111-1252): unknowns are the n_nodes
+ * cell-boundary nodes; every cell c couples its nb boundary nodes cell_nodes[c*nb..] (order of
+ * Cell.define_node_order_to_simulate, cell.py:611-680) through the dense Schur complement S[cell_S[c]] ((6nb)^2,
+ * row-major).  The handle then serves pl_set_bc / pl_assemble / pl_spmv / pl_spmv_free / pl_solve / pl_reactions with
+ * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (no preconditioner, as the reference) with opts->alpha_max. */
+int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S, const double *S,
+                  const int32_t *cell_S, const pl_opts_t *opts, pl_handle *out);
 
 /* Dirichlet / load data per dof.  fixed[6N] (0/1), ubar[6N] prescribed values (read where fixed), f[6N] nodal
  * loads.  Replaces apply_displacement_all_nodes_with_lattice_data / apply_force_on_all_nodes_with_lattice_data

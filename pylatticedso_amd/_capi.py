@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpylattice_hip.so")
 PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
-EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_destroy", "pl_set_bc",
+EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_create_ddm", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
@@ -34,7 +34,8 @@ class PlOpts(C.Structure):
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
                 ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("palette", C.c_int32),
                 ("reserved", C.c_int32 * 3),
-                ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3), ("grid_nodes", C.c_int64)]
+                ("alpha_max", C.c_double), ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3),
+                ("grid_nodes", C.c_int64)]
 
 
 class PlStats(C.Structure):
@@ -67,7 +68,7 @@ def load_library(path: str | None = None):
     lib.pl_destroy.restype = None
     lib.pl_default_opts.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
-    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
+    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
            "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
@@ -140,6 +141,26 @@ class HipLattice:
             opts.grid_nodes = int(nn)
         _check(self._lib, self._lib.pl_create(C.byref(mesh), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
+
+    @classmethod
+    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1):
+        """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm)."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
+        Sm = np.ascontiguousarray(S, dtype=np.float64)
+        if Sm.ndim == 2:
+            Sm = Sm[None]
+        cs = np.ascontiguousarray(cell_S, dtype=np.int32)
+        self.n_nodes, self.n_beams = int(n_nodes), 0
+        opts = PlOpts()
+        self._lib.pl_default_opts(C.byref(opts))
+        opts.device, opts.alpha_max, opts.check_every = device, alpha_max, check_every
+        _check(self._lib, self._lib.pl_create_ddm(self.n_nodes, cn.shape[0], cn.shape[1], _ptr(cn), Sm.shape[0],
+                                                  _ptr(Sm), _ptr(cs), C.byref(opts), C.byref(self._h)))
+        self.last_stats = None
+        return self
 
     # -- lifetime ---------------------------------------------------------------------------------------
     def close(self):

@@ -15,6 +15,7 @@
 #include "pl_dist.h"
 #include "pl_coarse.h"
 #include "pl_palette.h"
+#include "pl_ddm.h"
 
 namespace {
 
@@ -98,6 +99,12 @@ struct pl_context {
   // LDS-tile operator
   pl::TilePlan tile;
   DevBuf<int32_t> tile_start_dev_unused;
+  // DDM operator (pl_ddm.h): opkind = 1 replaces the strut operator by sum_c B^T S B
+  int opkind = 0;
+  int64_t ddm_cells = 0;
+  int ddm_nb = 0;
+  DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
+  DevBuf<double> ddm_St;
   // record palette (pl_palette.h)
   DevBuf<unsigned long long> pal_keys;
   DevBuf<int> pal_owner, pal_flags;
@@ -192,6 +199,16 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
   const int kind = choose_kernel(c);
   const int64_t n6 = c->N * 6;
+  if (c->opkind == 1) {
+    PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(pl::k_ddm_apply, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock), 0,
+                       c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, y);
+    if (masked || dot_dev)
+      hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
   if (kind == 1) {
     PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
     hipLaunchKernelGGL(pl::k_spmv_atomic, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
@@ -365,7 +382,7 @@ int pcg_iteration(pl_context *c, int k) {
     pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);
   } else {
     hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur);
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max);
   }
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
                      c->p.p, cur, nxt, c->hist.p, k);
@@ -686,6 +703,73 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   return PL_OK;
 }
 
+int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S,
+                  const double *S, const int32_t *cell_S, const pl_opts_t *o, pl_handle *out) {
+  if (!cell_nodes || !S || !cell_S || !o || !out) return fail(PL_ERR_ARG, "pl_create_ddm: null argument");
+  if (n_nodes <= 0 || n_cells <= 0 || nb <= 0 || n_S <= 0) return fail(PL_ERR_ARG, "pl_create_ddm: empty problem");
+  if (6 * nb > pl::kDdmMaxM) return fail(PL_ERR_ARG, "pl_create_ddm: more than 27 boundary nodes per cell");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PL_ERR_NODEVICE, "pl_create_ddm: no HIP device visible (libpylattice_hip has no CPU fallback)");
+  if (o->device < 0 || o->device >= ndev) return fail(PL_ERR_ARG, "pl_create_ddm: bad device ordinal");
+  for (int64_t k = 0; k < n_cells * nb; ++k)
+    if (cell_nodes[k] < 0 || cell_nodes[k] >= n_nodes) return fail(PL_ERR_ARG, "pl_create_ddm: node id out of range");
+  for (int64_t c = 0; c < n_cells; ++c)
+    if (cell_S[c] < 0 || cell_S[c] >= n_S) return fail(PL_ERR_ARG, "pl_create_ddm: matrix id out of range");
+  PL_HIP(hipSetDevice(o->device));
+  pl_context *c = new pl_context();
+  c->opt = *o;
+  c->opt.precond = 0;
+  c->opkind = 1;
+  c->N = n_nodes;
+  c->B = 0;
+  c->ddm_cells = n_cells;
+  c->ddm_nb = nb;
+  auto bail = [&](int rc) {
+    delete c;
+    return rc;
+  };
+#define PL_HIPC(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PL_HIPC(hipEventCreate(&c->ev0));
+  PL_HIPC(hipEventCreate(&c->ev1));
+  c->perm.resize(n_nodes);
+  std::iota(c->perm.begin(), c->perm.end(), 0);
+  c->iperm = c->perm;
+  const int m = 6 * nb;
+  std::vector<double> St((size_t)n_S * m * m);
+  for (int s = 0; s < n_S; ++s)
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) St[((size_t)s * m + j) * m + i] = S[((size_t)s * m + i) * m + j];
+  PL_HIPC(c->ddm_cell_nodes.alloc((size_t)n_cells * nb));
+  PL_HIPC(c->ddm_cell_S.alloc(n_cells));
+  PL_HIPC(c->ddm_St.alloc(St.size()));
+  PL_HIPC(hipMemcpy(c->ddm_cell_nodes.p, cell_nodes, (size_t)n_cells * nb * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->ddm_cell_S.p, cell_S, n_cells * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIPC(hipMemcpy(c->ddm_St.p, St.data(), St.size() * sizeof(double), hipMemcpyHostToDevice));
+  const size_t n6 = (size_t)n_nodes * 6;
+  PL_HIPC(c->fixed.alloc(n6));
+  PL_HIPC(c->fixedbits.alloc(n_nodes));
+  PL_HIPC(c->ubar.alloc(n6));
+  PL_HIPC(c->f.alloc(n6));
+  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
+    PL_HIPC(v->alloc(n6));
+  PL_HIPC(c->scal.alloc(2 * pl::S_COUNT * pl::kSlots));
+  PL_HIPC(hipMemset(c->fixed.p, 0, n6));
+  PL_HIPC(hipMemset(c->fixedbits.p, 0, n_nodes));
+  PL_HIPC(hipMemset(c->ubar.p, 0, n6 * sizeof(double)));
+  PL_HIPC(hipMemset(c->f.p, 0, n6 * sizeof(double)));
+  PL_HIPC(hipDeviceSynchronize());
+#undef PL_HIPC
+  *out = c;
+  return PL_OK;
+}
+
 void pl_destroy(pl_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
@@ -718,7 +802,10 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   PL_HIP(hipMemcpy(h->ubar.p, ub.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   h->have_bc = true;
-  if (h->assembled) {   // the Jacobi inverse and the coarse operator depend on the mask
+  if (h->assembled && h->opkind == 1) {
+    pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
+    PL_HIP(hipStreamSynchronize(h->stream));
+  } else if (h->assembled) {   // the Jacobi inverse and the coarse operator depend on the mask
     int rc = launch_diag(h);
     if (rc) return rc;
     rc = build_coarse(h);
@@ -730,6 +817,7 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
 
 int pl_update_radii(pl_handle h, const double *beam_radius) {
   if (!valid(h) || !beam_radius) return fail(PL_ERR_ARG, "pl_update_radii: null argument");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_update_radii: not available on a DDM handle");
   for (int64_t b = 0; b < h->B; ++b)
     if (!(beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_update_radii: non-positive radius");
   PL_HIP(hipSetDevice(h->opt.device));
@@ -761,6 +849,14 @@ int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_ns
 int pl_assemble(pl_handle h) {
   if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble: null handle");
   PL_HIP(hipSetDevice(h->opt.device));
+  if (h->opkind == 1) {   // DDM operator: nothing to build; no preconditioner (the reference runs plain CG here)
+    pl::launch_fill(h->N * 6, 1.0, h->diag.p, h->stream);
+    pl::launch_invert_diag(h->N * 6, h->diag.p, h->have_bc ? h->fixed.p : nullptr, h->dinv.p, h->stream);
+    PL_HIP(hipStreamSynchronize(h->stream));
+    h->ms_assembly = 0.0;
+    h->assembled = true;
+    return PL_OK;
+  }
   PL_HIP(hipEventRecord(h->ev0, h->stream));
   int rc = launch_records(h);
   if (rc) return rc;
@@ -781,6 +877,7 @@ int pl_assemble(pl_handle h) {
 
 int pl_assemble_bsr(pl_handle h, int with_bc, int64_t *n_block_rows, int64_t *n_blocks) {
   if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble_bsr: null handle");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_assemble_bsr: not available on a DDM handle");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_assemble_bsr: call pl_assemble first");
   if (with_bc && !h->have_bc) return fail(PL_ERR_STATE, "pl_assemble_bsr: with_bc needs pl_set_bc");
   PL_HIP(hipSetDevice(h->opt.device));
@@ -909,6 +1006,7 @@ int pl_reactions(pl_handle h, const double *u, double *R) { return spmv_common(h
 
 int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
   if (!valid(h) || !u || !dCdr) return fail(PL_ERR_ARG, "pl_sens: null argument");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_sens: not available on a DDM handle");
   PL_HIP(hipSetDevice(h->opt.device));
   std::vector<double> stage;
   int rc = upload6(h, u, h->tmp.p, stage);
@@ -933,6 +1031,7 @@ int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
 
 int pl_energy(pl_handle h, const double *u, double *energy) {
   if (!valid(h) || !u || !energy) return fail(PL_ERR_ARG, "pl_energy: null argument");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_energy: not available on a DDM handle");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_energy: call pl_assemble first");
   PL_HIP(hipSetDevice(h->opt.device));
   std::vector<double> stage;
@@ -1003,6 +1102,7 @@ int pl_algorithmic_bytes(pl_handle h, double *out3) {
 
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   if (!valid(h) || !avg_ms || reps <= 0) return fail(PL_ERR_ARG, "pl_time_kernel: bad argument");
+  if (h->opkind != 0 && which != 0 && which != 3) return fail(PL_ERR_STATE, "pl_time_kernel: DDM handles time K*p / PCG only");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_assemble first");
   if ((which == 0 || which == 3) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
   if ((which == 2 || which == 4) && !h->have_bsr) return fail(PL_ERR_STATE, "pl_time_kernel: needs pl_assemble_bsr");

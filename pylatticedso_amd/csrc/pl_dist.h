@@ -241,6 +241,9 @@ inline void launch_pcg_init_weighted(int64_t n6, const double *f, const double *
   hipLaunchKernelGGL(k_pcg_init_w, dim3(stream_grid(n6)), dim3(kBlock), 0, s, n6, f, Kubar, fixed, dinv, w, x, r, z,
                      p, scal);
 }
+inline void launch_fill(int64_t n, double v, double *x, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, v, x);
+}
 inline void launch_invert_diag(int64_t n6, const double *diag, const uint8_t *fixed, double *dinv, hipStream_t s) {
   hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, s, n6, diag, fixed, dinv);
 }

@@ -323,14 +323,16 @@ __global__ __launch_bounds__(kBlock) void k_bsr_spmv(int64_t N, const int64_t *_
 enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_AUX = 5, S_COUNT = 8 };
 
 // x += alpha p ; r -= alpha Ap ; z = dinv r ; rz_new += r.z ; rr += r.r      (alpha = rz_old / pAp)
+// alpha_max > 0 clamps the step like the reference's conjugate_gradient_solver.py:79 (used by the DDM solve).
 __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double *__restrict__ p,
                                                        const double *__restrict__ Ap,
                                                        const double *__restrict__ dinv, double *__restrict__ x,
                                                        double *__restrict__ r, double *__restrict__ z,
-                                                       double *__restrict__ scal) {
+                                                       double *__restrict__ scal, double alpha_max) {
   __shared__ double red[2][kBlock / kWave];
   const double pap = scalar_read(scal, S_PAP);
-  const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
+  double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
+  if (alpha_max > 0.0 && alpha > alpha_max) alpha = alpha_max;
   double rz = 0.0, rr = 0.0;
   const int64_t n2 = n6 >> 1;   // n6 is even (6 per node)
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {

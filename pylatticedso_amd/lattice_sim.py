@@ -82,7 +82,10 @@ class LatticeSim:
         self.applied_force = np.zeros((N, 6))
         self.reaction_force_vector = np.zeros((N, 6))
         self.penalized = None
-        if self.enable_simulation_properties and not self.domain_decomposition_solver:
+        # lattice_sim.py:119-122: joints are penalised for the FEM path and for DDM with exact Schur complements;
+        # with a surrogate the penalisation lives inside the stored Schur matrices
+        if self.enable_simulation_properties and (not self.domain_decomposition_solver
+                                                  or self.type_schur_complement_computation == "exact"):
             self.define_angles_between_beams()
             self.set_penalized_beams()
         else:
@@ -91,6 +94,12 @@ class LatticeSim:
         self.define_node_index_boundary()
         self.set_boundary_conditions()
         self._device = None
+        self._ddm_device = None
+        self.cell_schur_index = None       # (C,) index into self.schur_complements
+        self.schur_complements = None      # (n_S, 6 n_b, 6 n_b)
+        self.iteration = 0
+        if self.domain_decomposition_solver and self.type_schur_complement_computation == "exact":
+            self.calculate_schur_complement_cells()
 
     # ------------------------------------------------------------------------------------------------
     def _extract_geometry(self, p):
@@ -134,7 +143,27 @@ class LatticeSim:
         self.enable_simulation_properties = bool(sim.get("enable", False))
         self.material_name = sim.get("material", "VeroClear")
         self.enable_periodicity = sim.get("periodicity", False)
-        if sim.get("DDM") is None and self.domain_decomposition_solver:
+        ddm = sim.get("DDM", None)
+        self.enable_preconditioner = None
+        self.preconditioner_type = None
+        self.number_iteration_max = None
+        self.type_schur_complement_computation = None
+        self.precision_greedy = None
+        if ddm is not None:
+            self.enable_preconditioner = ddm.get("enable_preconditioner", False)
+            self.preconditioner_type = ddm.get("preconditioner_type", None)
+            if self.preconditioner_type is None and self.enable_preconditioner:
+                raise ValueError("Preconditioner type must be defined in the input file.")
+            self.number_iteration_max = ddm.get("max_iterations", 1000)
+            comp = ddm.get("schur_complement_computation", None)
+            if comp is None:
+                raise ValueError("Schur complement computation method must be defined in the input file.")
+            self.type_schur_complement_computation = comp.get("type", None)
+            if self.type_schur_complement_computation not in ["exact", "FE2"]:
+                self.precision_greedy = comp.get("precision_greedy", None)
+                if self.precision_greedy is None:
+                    raise ValueError("Precision for greedy algorithm must be defined in the input file.")
+        elif self.domain_decomposition_solver:
             raise ValueError("Schur complement computation method must be defined in the input file.")
         self.boundary_conditions = p.get("boundary_conditions", {})
         self.young_modulus, self.poisson_ratio = material_properties(self.material_name)
@@ -301,3 +330,104 @@ class LatticeSim:
                                       pen.seg_len, pen.seg_nsub, self.young_modulus, self.poisson_ratio,
                                       pen_coef=self.penalization_coefficient, **kw)
         return self._device
+
+    # ------------------------------------------------------------------------------------------------
+    # Domain decomposition (lattice_sim.py:846-919, 1111-1252)
+    # ------------------------------------------------------------------------------------------------
+    def cell_boundary_nodes(self):
+        """(C, n_b) node ids of every cell in the order of Cell.define_node_order_to_simulate (cell.py:611-680)."""
+        from .utils_schur import node_order_to_simulate
+        rows = [node_order_to_simulate(self, c) for c in range(self.lattice.n_cells)]
+        nb = {len(r) for r in rows}
+        if len(nb) != 1:
+            raise NotImplementedError("cells with different numbers of boundary nodes")
+        return np.asarray(rows, dtype=np.int64)
+
+    def set_schur_complements(self, S, cell_index=None):
+        """Install cell Schur complements: one (6n_b)^2 matrix for every cell, or a stack plus a per-cell index.
+        (The reference fills Cell.schur_complement from dolfinx or from its reduced-basis surrogates,
+        lattice_sim.py:846-978; the surrogate files are outside this repository.)"""
+        S = np.asarray(S, dtype=np.float64)
+        if S.ndim == 2:
+            S = S[None]
+        self.schur_complements = S
+        self.cell_schur_index = (np.zeros(self.lattice.n_cells, np.int32) if cell_index is None
+                                 else np.asarray(cell_index, np.int32))
+        if self._ddm_device is not None:
+            self._ddm_device.close()
+            self._ddm_device = None
+
+    def calculate_schur_complement_cells(self):
+        """Exact Schur complement of one representative cell per (geometry, radii) group (lattice_sim.py:846-919),
+        condensed on the device (pl_schur) from that cell's own struts with their penalised segments."""
+        from ._capi import HipLattice
+        if self.type_schur_complement_computation not in ("exact",):
+            raise NotImplementedError("surrogate Schur complements (reduced basis / RBF) need the reference's data "
+                                      "files; install matrices with set_schur_complements()")
+        lat, pen = self.lattice, self.penalized
+        cb = self.cell_boundary_nodes()
+        keys = [tuple(np.round(lat.cell_radii[c], 8)) for c in range(lat.n_cells)]
+        groups, mats, idx = {}, [], np.zeros(lat.n_cells, np.int32)
+        for c, k in enumerate(keys):
+            if k not in groups:
+                beams = lat.cell_beam_idx[lat.cell_beam_ptr[c]:lat.cell_beam_ptr[c + 1]]
+                nodes = np.unique(lat.beam_conn[beams])
+                remap = np.full(lat.n_nodes, -1, np.int64)
+                remap[nodes] = np.arange(len(nodes))
+                with HipLattice(lat.node_xyz[nodes], remap[lat.beam_conn[beams]], lat.beam_radius[beams],
+                                pen.seg_len[beams], pen.seg_nsub[beams], self.young_modulus, self.poisson_ratio,
+                                pen_coef=self.penalization_coefficient, reorder=0) as dev:
+                    dev.assemble()
+                    mats.append(dev.schur(remap[cb[c]], rtol=1e-13, max_iter=200000))
+                groups[k] = len(mats) - 1
+            idx[c] = groups[k]
+        self.set_schur_complements(np.stack(mats), idx)
+
+    def ddm_model(self):
+        from ._capi import HipLattice
+        if self.schur_complements is None:
+            raise ValueError("Schur complements are not defined: call calculate_schur_complement_cells() or "
+                             "set_schur_complements()")
+        if self._ddm_device is None:
+            cb = self.cell_boundary_nodes()
+            self._ddm_device = HipLattice.ddm(self.max_index_boundary + 1, self.index_boundary[cb],
+                                              self.schur_complements, self.cell_schur_index)
+        return self._ddm_device
+
+    def solve_DDM(self):
+        """Domain-decomposition solve on the cell-boundary nodes (lattice_sim.py:1111-1176): right-hand side
+        b = f_free - (S u_imposed)_free, plain CG with the reference's parameters (tol 1e-6, alpha clamp 100,
+        max_iterations from the preset), results written back to displacement_vector; returns
+        (xsol, info, global_displacement_index, b) or four None when b == 0."""
+        if not self.domain_decomposition_solver:
+            raise ValueError("LatticeSim was not created with enable_domain_decomposition_solver=True")
+        if self.enable_preconditioner:
+            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not accelerated; running "
+                  "plain CG")
+        dev = self.ddm_model()
+        bn = self._boundary_nodes_by_index()
+        fixed = self.fixed_DOF[bn]
+        if (~fixed).sum() == 0:
+            raise ValueError("No free DOF in the lattice. Process aborted.")
+        ubar = np.where(fixed, self.displacement_vector[bn], 0.0)
+        f = self.applied_force[bn]
+        dev.set_bc(fixed, ubar, f)
+        dev.assemble()
+        b = np.where(fixed, 0.0, f - dev.spmv(ubar))
+        if np.linalg.norm(b) == 0:
+            print("No external forces or imposed displacements in the lattice. Process aborted.")
+            return None, None, None, None
+        maxit = self.number_iteration_max or 1000
+        u, st = dev.solve(rtol=1e-6, max_iter=maxit, raise_on_noconv=False)
+        self.iteration = st["iterations"]
+        info = 0 if st["converged"] else 1
+        self.displacement_vector[bn] = u
+        self.reaction_force_vector[bn] = dev.reactions(u)
+        xsol, idx = self.get_global_displacement()
+        return xsol, info, self.global_displacement_index, b[~fixed]
+
+    def _boundary_nodes_by_index(self):
+        bn = np.empty(self.max_index_boundary + 1, np.int64)
+        nodes = np.flatnonzero(self.index_boundary >= 0)
+        bn[self.index_boundary[nodes]] = nodes
+        return bn
