@@ -36,7 +36,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cantilever_bc(xyz, x_max, n_targets_global=None, weight=None):
+def cantilever_bc(xyz, x_max, n_targets_global=None):
     """fixed / ubar / f arrays of the cantilever: clamp Xmin, total Fz = -0.1 spread over the Xmax nodes."""
     n = len(xyz)
     fixed = np.zeros((n, 6), np.uint8)

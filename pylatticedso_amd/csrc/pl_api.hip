@@ -98,7 +98,6 @@ struct pl_context {
   int hist_cap = 0;
   // LDS-tile operator
   pl::TilePlan tile;
-  DevBuf<int32_t> tile_start_dev_unused;
   // DDM operator (pl_ddm.h): opkind = 1 replaces the strut operator by sum_c B^T S B
   int opkind = 0;
   int64_t ddm_cells = 0;
@@ -350,20 +349,18 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, c->dinv.p,
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
-                     cs.part);
-  hipLaunchKernelGGL(pl::k_coarse_gather, dim3((unsigned)((cs.nc + pl::kBlock - 1) / pl::kBlock + 1)),
-                     dim3(pl::kBlock), 0, c->stream, cs.n_agg, cs.agg_tile_ptr.p, cs.agg_tile_idx.p, cs.part,
-                     cs.n_tiles, cs.rc, cur, cs.ncp);
+                     cs.rc);
   if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
+    hipLaunchKernelGGL(pl::k_coarse_tail_from_scal, dim3(1), dim3(pl::kWave), 0, c->stream, cur, cs.rc, cs.ncp);
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
-    hipLaunchKernelGGL(pl::k_coarse_scalars_from_rc, dim3(1), dim3(64), 0, c->stream, cs.rc, cs.ncp, cur);
+    hipLaunchKernelGGL(pl::k_coarse_scalars_from_rc, dim3(1), dim3(pl::kWave), 0, c->stream, cs.rc, cs.ncp, cur);
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cur + pl::S_RDR * pl::kSlots, c->stream);
   hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3(grid_stream(c->N)), dim3(pl::kBlock), 0, c->stream, c->N,
                      c->r.p, c->dinv.p, c->xyz.p, cs.agg_of_node.p, cs.cen.p, cs.yc, c->fixedbits.p, c->p.p, cur, nxt,
-                     c->hist.p, hist_slot);
+                     c->hist.p, hist_slot, cs.rc, cs.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }

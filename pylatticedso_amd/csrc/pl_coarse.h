@@ -11,8 +11,7 @@
 //
 // Per iteration (all device-side, no host round trip):
 //   K*p (+ p.Ap)                                                            k_spmv_tile
-//   x += a p, r -= a Ap, per-tile partials of Z^T r, r.r, r.D^-1 r         k_pcg_update_tile
-//   r_c = sum of tile partials per aggregate, scalars                       k_coarse_gather
+//   x += a p, r -= a Ap, r_c += Z^T r (tile partial sums, atomics), r.r, r.D^-1 r   k_pcg_update_tile
 //   y_c = A_c^-1 r_c, r.z = r.D^-1 r + r_c.y_c                              k_tri_gemv, k_tri_gemv_t
 //   p = D^-1 r + P Z y_c + beta p  (z is never stored)                      k_pcg_direction_coarse
 #pragma once
@@ -313,8 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const double *__restrict__ dinv,
                                                             const double *__restrict__ w /* may be null */,
                                                             double *__restrict__ x, double *__restrict__ r,
-                                                            const double *__restrict__ scal,
-                                                            double *__restrict__ part) {
+                                                            double *__restrict__ scal, double *__restrict__ rc) {
   __shared__ double red[8][kBlock / kWave];
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -377,52 +375,27 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
-    part[8 * (int64_t)t + threadIdx.x] = s;
+    // r_c is zeroed by the previous direction kernel; ~8 tiles add into each aggregate's six entries
+    if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
+    else if (threadIdx.x == 6) scalar_add(scal, S_RR, s);
+    else scalar_add(scal, S_RDR, s);
   }
 }
 
-// r_c[6 I + k] = sum over the tiles of aggregate I; last block: rr and r.D^-1 r totals into the scalar set.
-__global__ __launch_bounds__(kBlock) void k_coarse_gather(int n_agg, const int32_t *__restrict__ ptr,
-                                                          const int32_t *__restrict__ idx,
-                                                          const double *__restrict__ part, int64_t T,
-                                                          double *__restrict__ rc, double *__restrict__ scal,
-                                                          int ncp) {
-  __shared__ double red[2][kBlock / kWave];
-  if (blockIdx.x + 1 < gridDim.x) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e < 6 * n_agg) {
-      const int I = e / 6, k = e - 6 * I;
-      double s = 0.0;
-      for (int q = ptr[I]; q < ptr[I + 1]; ++q) s += part[8 * (int64_t)idx[q] + k];
-      rc[e] = s;
-    }
-    return;
-  }
-  double rr = 0.0, rdr = 0.0;
-  for (int64_t t = threadIdx.x; t < T; t += kBlock) {
-    rr += part[8 * t + 6];
-    rdr += part[8 * t + 7];
-  }
-  rr = wave_sum(rr);
-  rdr = wave_sum(rdr);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wv] = rr; red[1][wv] = rdr; }
-  __syncthreads();
+// multi-GPU: the local r.r and r.D^-1 r (32 slots each) go to the tail of r_c before its all-reduce ...
+__global__ void k_coarse_tail_from_scal(const double *__restrict__ scal, double *__restrict__ rc, int ncp) {
+  const double rr = scalar_read(scal, S_RR), rdr = scalar_read(scal, S_RDR);
   if (threadIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int q = 0; q < kBlock / kWave; ++q) { a += red[0][q]; b += red[1][q]; }
-    scal[S_RR * kSlots] = a;          // the set's accumulators were zeroed by the previous direction kernel
-    scal[S_RDR * kSlots] = b;
-    rc[ncp] = a;                      // multi-GPU: the two scalars ride in the tail of the r_c all-reduce
-    rc[ncp + 1] = b;
+    rc[ncp] = rr;
+    rc[ncp + 1] = rdr;
   }
 }
-
-// multi-GPU: after the all-reduce of [r_c | rr | r.D^-1 r] put the global scalars back into the scalar set
+// ... and come back as global values (slot 0 holds the total, the other slots are cleared)
 __global__ void k_coarse_scalars_from_rc(const double *__restrict__ rc, int ncp, double *__restrict__ scal) {
-  if (threadIdx.x == 0) {
-    scal[S_RR * kSlots] = rc[ncp];
-    scal[S_RDR * kSlots] = rc[ncp + 1];
+  const int s = threadIdx.x;
+  if (s < kSlots) {
+    scal[S_RR * kSlots + s] = (s == 0) ? rc[ncp] : 0.0;
+    scal[S_RDR * kSlots + s] = (s == 0) ? rc[ncp + 1] : 0.0;
   }
 }
 
@@ -437,9 +410,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(int64_t N, cons
                                                                  double *__restrict__ p,
                                                                  const double *__restrict__ scal,
                                                                  double *__restrict__ scal_next,
-                                                                 double *__restrict__ hist, int k) {
+                                                                 double *__restrict__ hist, int k,
+                                                                 double *__restrict__ rc, int ncp) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
+  if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
+    for (int e = threadIdx.x; e < ncp + 2; e += kBlock) rc[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
     const double rr = scalar_read(scal, S_RR);
     const int s = threadIdx.x;

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const double *__rest
     if (threadIdx.x == 0) {
       double s = 0.0;
       for (int q = 0; q < kBlock / kWave; ++q) s += red[q];
-      if (blockIdx.x == 0 && add0) s += *add0;
+      if (blockIdx.x == 0 && add0)
+        for (int q = 0; q < kSlots; ++q) s += add0[q];     // add0 = a slotted scalar (e.g. r.D^-1 r)
       unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
     }
   }

@@ -485,20 +485,4 @@ __global__ __launch_bounds__(kBlock) void k_energy(int64_t B, const int32_t *__r
   if (threadIdx.x == 0) unsafeAtomicAdd(out + (blockIdx.x & (kSlots - 1)), t);
 }
 
-// gather / scatter helpers for the node permutation and interface packing
-__global__ void k_gather6(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ src,
-                          double *__restrict__ dst) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * 6) return;
-  const int64_t node = i / 6, k = i - node * 6;
-  dst[i] = src[6 * (int64_t)idx[node] + k];
-}
-__global__ void k_scatter6(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ src,
-                           double *__restrict__ dst) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * 6) return;
-  const int64_t node = i / 6, k = i - node * 6;
-  dst[6 * (int64_t)idx[node] + k] = src[i];
-}
-
 }  // namespace pl
