@@ -86,7 +86,14 @@ def main():
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (slab build, RCCL communicator) even with one rank (rehearsal)")
     args = ap.parse_args()
+
+    # Libraries (RCCL prints a version banner) write to the C-level stdout: keep fd 1 for the ONE JSON line only.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,8 +106,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from pylatticedso_amd import _capi, lattice_arrays as LA, partition as PT
@@ -111,7 +120,7 @@ def main():
     n = args.cells
     ncell = (n, n * world, n)
     t0 = time.perf_counter()
-    if world == 1:
+    if not multi:
         lat = LA.generate((1, 1, 1), ncell, [args.geom], [args.radius])
         pen = LA.penalize(lat, LA.compute_lzone(lat))
         xyz, conn, rad, seg_len, seg_nsub = lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub
@@ -122,7 +131,7 @@ def main():
     log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
 
     grid = None
-    if world > 1:
+    if multi:
         # every rank must cut the same brick / aggregate grid: hand over the box and node count of the whole lattice
         nn = torch.tensor([float(len(xyz))], dtype=torch.float64, device="cuda")
         dist.all_reduce(nn)
@@ -130,7 +139,7 @@ def main():
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette)
     n_beams_total = len(conn)
-    if world > 1:
+    if multi:
         keys = [None] * world
         dist.all_gather_object(keys, slab.iface_key)
         ok, gid, nsg = PT.global_interface_ids(keys, rank)
@@ -156,7 +165,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -168,7 +177,7 @@ def main():
         st = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -219,8 +228,8 @@ def main():
         out["cpu_baseline"] = None
     dev.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
