@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
-    ap.add_argument("--precond", type=int, default=2, help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space")
+    ap.add_argument("--precond", type=int, default=3,
+                    help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
@@ -210,8 +211,9 @@ def main():
                    "partition": "single GPU" if world == 1 else f"{world} y-slabs, RCCL interface all-reduce",
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"],
-                   "preconditioner": "Jacobi" if args.precond == 1 else "two-level (Jacobi + rigid-body coarse space)",
-                   "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond == 2 else "")
+                   "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
+                                      3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)"}[args.precond],
+                   "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond >= 2 else "")
                            + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),

@@ -58,12 +58,14 @@ typedef struct {
   int32_t device;        /* HIP device ordinal */
   int32_t spmv_kernel;   /* 0 = auto (3 if reorder else 2), 1 = per-strut + f64 global atomics, 2 = per-node gather
                             (sliced ELL), 3 = per-strut with LDS tile accumulators */
-  int32_t precond;       /* 1 = Jacobi (diagonal); 2 = two-level: Jacobi + rigid-body-mode coarse space (needs reorder) */
+  int32_t precond;       /* 1 = Jacobi (diagonal); 2 = two-level: Jacobi + rigid-body-mode coarse space on brick
+                            aggregates, dense solve; 3 = 2 plus a tile level (rigid-body modes of every K*p tile,
+                            6 x 6 block solves).  2 and 3 need reorder = 1 */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
   int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
   int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
   int32_t tile_nodes;    /* target nodes per brick/tile of the spatial reordering, <= 512 (0 -> 256) */
-  int32_t coarse_max_dofs; /* precond = 2: upper bound on 6 * (number of aggregates) (0 -> 3072) */
+  int32_t coarse_max_dofs; /* precond = 2/3: upper bound on 6 * (number of aggregates) (0 -> 3072) */
   int32_t palette;       /* 1: K*p (LDS-tile kernel) reads 2-byte palette ids instead of 64-byte records when the lattice
                             has <= ~30 000 distinct records (compared on 40 mantissa bits, i.e. to 1e-12) */
   int32_t reserved[3];

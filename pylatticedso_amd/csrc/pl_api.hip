@@ -320,6 +320,11 @@ int build_coarse(pl_context *c) {
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
+  if (cs.tile_level)
+    hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+                       c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
+                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                       c->fixedbits.p, cs.tile_on.p, cs.Bt_inv);
   pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, cs.slab, n, n, cs.info, c->stream);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
@@ -349,7 +354,7 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, c->dinv.p,
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
-                     cs.rc);
+                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt);
   if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
     hipLaunchKernelGGL(pl::k_coarse_tail_from_scal, dim3(1), dim3(pl::kWave), 0, c->stream, cur, cs.rc, cs.ncp);
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2, c->stream))
@@ -358,8 +363,9 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cur + pl::S_RDR * pl::kSlots, c->stream);
-  hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3(grid_stream(c->N)), dim3(pl::kBlock), 0, c->stream, c->N,
-                     c->r.p, c->dinv.p, c->xyz.p, cs.agg_of_node.p, cs.cen.p, cs.yc, c->fixedbits.p, c->p.p, cur, nxt,
+  hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+                     c->tile.tile_start.p, c->r.p, c->dinv.p, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, cur, nxt,
                      c->hist.p, hist_slot, cs.rc, cs.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
@@ -674,8 +680,9 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
-  if (o->precond == 2) {
-    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2 (two-level) needs reorder = 1"));
+  if (o->precond == 2 || o->precond == 3) {
+    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3 (multi-level) needs reorder = 1"));
+    c->coarse.tile_level = (o->precond == 3);
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
@@ -1214,6 +1221,15 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   int rc = pl::dist_init(h->dist, rank, world, unique_id, loc.data(), shared_global, n_shared, n_shared_global, h->N,
                          h->stream);
   if (rc) return fail(PL_ERR_HIP, "pl_dist_init: RCCL communicator setup failed (" + std::to_string(rc) + ")");
+  if (h->coarse.enabled) {   // tiles holding a shared node get no tile-level term (their block would span two ranks)
+    const std::vector<int32_t> &ts = h->coarse.h_tile_start;
+    std::vector<uint8_t> on(ts.size() - 1, 1);
+    for (int i = 0; i < n_shared; ++i) {
+      const size_t t = (size_t)(std::upper_bound(ts.begin(), ts.end(), loc[i]) - ts.begin()) - 1;
+      on[t] = 0;
+    }
+    if (h->coarse.tile_on.upload(on) != hipSuccess) return fail(PL_ERR_HIP, "pl_dist_init: tile flags upload failed");
+  }
   h->assembled = false;
   return PL_OK;
 }

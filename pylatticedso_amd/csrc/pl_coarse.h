@@ -1,4 +1,6 @@
-// Two-level preconditioner of libpylattice_hip:  M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T   (additive, SPD).
+// Multi-level additive preconditioner of libpylattice_hip (SPD):
+//     M^-1 = D^-1 + sum_t Z_t (Z_t^T K Z_t)^-1 Z_t^T + Z (Z^T K Z)^-1 Z^T
+// (Jacobi level, tile level: the 6 rigid-body modes of every K*p tile with a 6 x 6 block solve, dense level).
 //
 // D = diag(K) (Jacobi) is the fine level.  The coarse space Z holds the 6 rigid-body modes (3 translations, 3 rotations
 // about the aggregate centroid) of every AGGREGATE = a g x g x g group of the node bricks the K*p tiles are made of,
@@ -11,9 +13,10 @@
 //
 // Per iteration (all device-side, no host round trip):
 //   K*p (+ p.Ap)                                                            k_spmv_tile
-//   x += a p, r -= a Ap, r_c += Z^T r (tile partial sums, atomics), r.r, r.D^-1 r   k_pcg_update_tile
+//   x += a p, r -= a Ap, r_c += Z^T r (tile partial sums, atomics), r.r, r.D^-1 r,
+//   y_t = B_t^-1 Z_t^T r and r.D^-1 r += r_t.y_t (tile level)                k_pcg_update_tile
 //   y_c = A_c^-1 r_c, r.z = r.D^-1 r + r_c.y_c                              k_tri_gemv, k_tri_gemv_t
-//   p = D^-1 r + P Z y_c + beta p  (z is never stored)                      k_pcg_direction_coarse
+//   p = D^-1 r + P Z (y_c + y_t) + beta p  (z is never stored)              k_pcg_direction_coarse
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,9 +43,15 @@ struct Coarse {
   int64_t n_cross = 0;
   double *Ac = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *slab = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
+  // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
+  bool tile_level = true;
+  TBuf<int32_t> tile_of_node;
+  TBuf<uint8_t> tile_on;          // 0: the tile holds nodes shared with another rank (multi-GPU) -> no tile-level term
+  std::vector<int32_t> h_tile_start;
+  double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)slab, (void *)part, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info})
+                    (void *)info, (void *)Bt_inv, (void *)yt})
       if (q) (void)hipFree(q);
   }
 };
@@ -120,6 +129,18 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
+  {
+    std::vector<int32_t> tile_of(N);
+    for (int64_t t = 0; t < T; ++t)
+      for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of[i] = (int32_t)t;
+    std::vector<uint8_t> on((size_t)T, 1);
+    c.h_tile_start = tile_start;
+    if (c.tile_of_node.upload(tile_of) != hipSuccess || c.tile_on.upload(on) != hipSuccess) return 1;
+    if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMalloc((void **)&c.yt, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMemset(c.yt, 0, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
+  }
   if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.W, 0, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.Wt, 0, n2 * sizeof(double)) != hipSuccess) return 2;
@@ -301,6 +322,154 @@ __global__ void k_coarse_regularize(int nc, double *__restrict__ Ac) {
   if (!(Ac[(size_t)i * nc + i] > 0.0)) Ac[(size_t)i * nc + i] = 1.0;
 }
 // ---------------------------------------------------------------------------------------------------------------
+// Tile level: B_t = Z_t^T P K P Z_t (6 x 6) for the rigid-body modes of tile t about its aggregate's centre, inverted
+// in place.  One workgroup per tile walks the tile's home + foreign strut lists (pl_tile.h), every lane keeps a
+// 6 x 6 partial in registers, so there are no atomics.  Modes without stiffness (all their dofs fixed) are dropped.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void spd6_inverse(double *A /* 36, in/out */) {
+  double dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dmax = fmax(dmax, A[i * 6 + i]);
+  double L[36];
+  bool keep[6];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) L[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < j) s -= L[j * 6 + k] * L[j * 6 + k];
+    keep[j] = s > 1e-12 * dmax;
+    if (!keep[j]) {            // identity row/column
+#pragma unroll
+      for (int k = 0; k < 6; ++k) L[j * 6 + k] = 0.0;
+      L[j * 6 + j] = 1.0;
+      continue;
+    }
+    const double d = sqrt(s);
+    L[j * 6 + j] = d;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i > j) {
+        double v = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (k < j) v -= L[i * 6 + k] * L[j * 6 + k];
+        L[i * 6 + j] = v / d;
+      }
+  }
+  // W = L^-1 (lower), then A^-1 = W^T W
+  double W[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) W[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    W[j * 6 + j] = 1.0 / L[j * 6 + j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i > j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (k >= j && k < i) v -= L[i * 6 + k] * W[k * 6 + j];
+        W[i * 6 + j] = v / L[i * 6 + i];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (k >= i && k >= j) v += W[k * 6 + i] * W[k * 6 + j];
+      A[i * 6 + j] = (keep[i] && keep[j]) ? v : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restrict__ tile_start,
+                                                        const int64_t *__restrict__ home_ptr,
+                                                        const int64_t *__restrict__ foreign_ptr,
+                                                        const int32_t *__restrict__ foreign_idx,
+                                                        const int2 *__restrict__ conn2, const Record *__restrict__ rec,
+                                                        const int32_t *__restrict__ agg_of_tile,
+                                                        const double *__restrict__ cen, const double *__restrict__ xyz,
+                                                        const uint8_t *__restrict__ fixedbits,
+                                                        const uint8_t *__restrict__ tile_on,
+                                                        double *__restrict__ Bt_inv) {
+  __shared__ double red[36][kBlock / kWave];
+  __shared__ double A[36];
+  const int t = blockIdx.x;
+  if (!tile_on[t]) {
+    if (threadIdx.x < 36) Bt_inv[(size_t)t * 36 + threadIdx.x] = 0.0;
+    return;
+  }
+  const int n0 = tile_start[t], n1 = tile_start[t + 1];
+  const int a = agg_of_tile[t];
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+  const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1], f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
+  const int64_t total = (h1 - h0) + (f1 - f0);
+  for (int64_t q = threadIdx.x; q < total; q += kBlock) {
+    const int64_t b = q < (h1 - h0) ? h0 + q : (int64_t)foreign_idx[f0 + (q - (h1 - h0))];
+    const int2 cn = conn2[b];
+    const bool ina = cn.x >= n0 && cn.x < n1, inb = cn.y >= n0 && cn.y < n1;
+    const unsigned fa = fixedbits ? fixedbits[cn.x] : 0u, fb = fixedbits ? fixedbits[cn.y] : 0u;
+    if (ina && inb && fa == 0u && fb == 0u) continue;       // rigid motion of the whole strut
+    const Record r = load_record(rec, b);
+    const double rela[3] = {xyz[3 * (int64_t)cn.x] - c0, xyz[3 * (int64_t)cn.x + 1] - c1, xyz[3 * (int64_t)cn.x + 2] - c2};
+    const double relb[3] = {xyz[3 * (int64_t)cn.y] - c0, xyz[3 * (int64_t)cn.y + 1] - c1, xyz[3 * (int64_t)cn.y + 2] - c2};
+    double Kss[36], Kso[36], C[36];
+    if (inb) {
+      tip_blocks(r, Kss, Kso);                               // K_bb, K_ba
+      coarse_block(Kss, fb, fb, relb, relb, C);
+#pragma unroll
+      for (int e = 0; e < 36; ++e) acc[e] += C[e];
+      if (ina) {
+        coarse_block(Kso, fb, fa, relb, rela, C);
+#pragma unroll
+        for (int e = 0; e < 36; ++e) acc[e] += C[e];
+      }
+    }
+    if (ina) {
+      tip_blocks(reversed(r), Kss, Kso);                     // K_aa, K_ab
+      coarse_block(Kss, fa, fa, rela, rela, C);
+#pragma unroll
+      for (int e = 0; e < 36; ++e) acc[e] += C[e];
+      if (inb) {
+        coarse_block(Kso, fa, fb, rela, relb, C);
+#pragma unroll
+        for (int e = 0; e < 36; ++e) acc[e] += C[e];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 36; ++e) {
+    const double s = wave_sum(acc[e]);
+    if (lane == 0) red[e][wv] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
+    A[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double M[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) M[e] = A[e];
+    spd6_inverse(M);
+#pragma unroll
+    for (int e = 0; e < 36; ++e) Bt_inv[(size_t)t * 36 + e] = M[e];
+  }
+}
+// ---------------------------------------------------------------------------------------------------------------
 // x += alpha p ; r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
@@ -312,7 +481,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const double *__restrict__ dinv,
                                                             const double *__restrict__ w /* may be null */,
                                                             double *__restrict__ x, double *__restrict__ r,
-                                                            double *__restrict__ scal, double *__restrict__ rc) {
+                                                            double *__restrict__ scal, double *__restrict__ rc,
+                                                            const double *__restrict__ Bt_inv /* may be null */,
+                                                            double *__restrict__ yt) {
   __shared__ double red[8][kBlock / kWave];
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -320,6 +491,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double bi[6] = {0, 0, 0, 0, 0, 0};   // row threadIdx.x of B_t^-1, fetched early: it is needed at the very end
+  if (Bt_inv && threadIdx.x < 6) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bi[j] = Bt_inv[(size_t)t * 36 + 6 * threadIdx.x + j];
+  }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
     double pv[6], av[6], dv[6], xv[6], rv[6];
@@ -378,7 +554,23 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     // r_c is zeroed by the previous direction kernel; ~8 tiles add into each aggregate's six entries
     if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
     else if (threadIdx.x == 6) scalar_add(scal, S_RR, s);
-    else scalar_add(scal, S_RDR, s);
+    if (!Bt_inv) {
+      if (threadIdx.x == 7) scalar_add(scal, S_RDR, s);
+    } else {
+      // tile level: y_t = B_t^-1 (Z_t^T r); its share r_t . y_t of r.z joins r.D^-1 r (lanes 0..7 of wave 0)
+      double tj[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) tj[j] = __shfl(s, j, 8);
+      double y = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) y += bi[j] * tj[j];
+      if (threadIdx.x < 6) yt[6 * (size_t)t + threadIdx.x] = y;
+      double v = threadIdx.x < 6 ? y * s : (threadIdx.x == 7 ? s : 0.0);
+      v += __shfl_xor(v, 1, 8);
+      v += __shfl_xor(v, 2, 8);
+      v += __shfl_xor(v, 4, 8);
+      if (threadIdx.x == 0) scalar_add(scal, S_RDR, v);
+    }
   }
 }
 
@@ -399,13 +591,16 @@ __global__ void k_coarse_scalars_from_rc(const double *__restrict__ rc, int ncp,
   }
 }
 
-// p = D^-1 r + P Z y_c + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
-__global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(int64_t N, const double *__restrict__ r,
+// p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
+// One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
+__global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *__restrict__ tile_start,
+                                                                 const double *__restrict__ r,
                                                                  const double *__restrict__ dinv,
                                                                  const double *__restrict__ xyz,
-                                                                 const int32_t *__restrict__ agg,
+                                                                 const int32_t *__restrict__ agg_of_tile,
                                                                  const double *__restrict__ cen,
                                                                  const double *__restrict__ yc,
+                                                                 const double *__restrict__ yt /* may be null */,
                                                                  const uint8_t *__restrict__ fixedbits,
                                                                  double *__restrict__ p,
                                                                  const double *__restrict__ scal,
@@ -428,11 +623,18 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(int64_t N, cons
       scal_next[S_RDR * kSlots + s] = 0.0;
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
-    const int a = agg[i];
-    const double *y = yc + 6 * a;
-    const double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
-    const double rx = xyz[3 * i] - cen[3 * a], ry = xyz[3 * i + 1] - cen[3 * a + 1], rz = xyz[3 * i + 2] - cen[3 * a + 2];
+  const int t = blockIdx.x;
+  const int n0 = tile_start[t], n1 = tile_start[t + 1];
+  const int a = agg_of_tile[t];
+  const double *y = yc + 6 * a;
+  double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
+  if (yt) {   // the tile's modes use the same reference point, so the two rigid motions just add
+    const double *q = yt + 6 * (size_t)t;
+    U0 += q[0]; U1 += q[1]; U2 += q[2]; W0 += q[3]; W1 += q[4]; W2 += q[5];
+  }
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
+    const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     const unsigned fb = fixedbits[i];
     const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);

