@@ -309,8 +309,23 @@ int build_coarse(pl_context *c) {
   const int n = cs.ncp;
   PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
   PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
-  hipLaunchKernelGGL(pl::k_coarse_assemble, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
-                     c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n, cs.Ac);
+  if (cs.n_fix < 0) {   // Dirichlet set changed: list the in-aggregate struts that touch it
+    if (!cs.fix_list) {
+      PL_HIP(hipMalloc((void **)&cs.fix_list, (size_t)std::max<int64_t>(c->B, 1) * sizeof(int32_t)));
+      PL_HIP(hipMalloc((void **)&cs.fix_count, sizeof(int)));
+    }
+    PL_HIP(hipMemsetAsync(cs.fix_count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(pl::k_list_fixed_struts, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
+                       cs.agg_of_node.p, c->fixedbits.p, cs.fix_list, cs.fix_count);
+    int cnt = 0;
+    PL_HIP(hipMemcpyAsync(&cnt, cs.fix_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    cs.n_fix = cnt;
+  }
+  if (cs.n_fix > 0)
+    hipLaunchKernelGGL(pl::k_coarse_assemble, dim3(grid_for(cs.n_fix)), dim3(pl::kBlock), 0, c->stream, cs.n_fix,
+                       cs.fix_list, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n,
+                       cs.Ac);
   if (cs.n_cross > 0)
     hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
                        cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
@@ -325,7 +340,7 @@ int build_coarse(pl_context *c) {
                        c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                        reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
                        c->fixedbits.p, cs.tile_on.p, cs.Bt_inv);
-  pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, cs.slab, n, n, cs.info, c->stream);
+  pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
@@ -806,6 +821,7 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   PL_HIP(hipMemcpy(h->ubar.p, ub.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   h->have_bc = true;
+  h->coarse.n_fix = -1;
   if (h->assembled && h->opkind == 1) {
     pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
     PL_HIP(hipStreamSynchronize(h->stream));
@@ -1164,14 +1180,13 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
       Ap[(size_t)i * np + i] = 1.0;
     }
   }
-  DevBuf<double> dA, dW, dWt, dD, db, dt, dy, dq, dslab;
+  DevBuf<double> dA, dW, dWt, dD, db, dt, dy, dq;
   DevBuf<int> dinfo;
   PL_HIP(dA.alloc(Ap.size()));
   PL_HIP(dW.alloc(Ap.size()));
   PL_HIP(dWt.alloc(Ap.size()));
   PL_HIP(hipMemset(dWt.p, 0, Ap.size() * sizeof(double)));
   PL_HIP(dD.alloc((size_t)np * pl::kNB));
-  PL_HIP(dslab.alloc((size_t)(np / pl::kNB) * pl::dense_max_chunks(np) * pl::kNB * pl::kNB));
   PL_HIP(db.alloc(np));
   PL_HIP(dt.alloc(np));
   PL_HIP(dy.alloc(np));
@@ -1182,7 +1197,7 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
   PL_HIP(hipMemset(dW.p, 0, Ap.size() * sizeof(double)));
   PL_HIP(hipMemset(dq.p, 0, pl::kSlots * sizeof(double)));
   PL_HIP(hipMemset(dinfo.p, 0, 2 * sizeof(int)));
-  pl::dense_factor_inverse(dA.p, dW.p, dWt.p, dD.p, dslab.p, np, np, dinfo.p, nullptr);
+  pl::dense_factor_inverse(dA.p, dW.p, dWt.p, dD.p, np, np, dinfo.p, 0, nullptr);
   pl::dense_apply(dW.p, dWt.p, np, np, db.p, dt.p, dy.p, dq.p, nullptr, nullptr);
   PL_HIP(hipGetLastError());
   PL_HIP(hipDeviceSynchronize());

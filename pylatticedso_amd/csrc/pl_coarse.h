@@ -36,12 +36,13 @@ struct Coarse {
   bool enabled = false;     // topology prepared (pl_create)
   bool ready = false;       // A_c^-1 valid (pl_assemble)
   int n_agg = 0, nc = 0, ncp = 0;   // ncp = nc rounded up to the dense block size (padding rows are identity)
+  int bw_blocks = 0;                // block bandwidth of A_c (aggregates couple to their 26 neighbours only)
   int64_t n_tiles = 0;
   TBuf<int32_t> agg_of_node, agg_of_tile, agg_tile_ptr, agg_tile_idx;
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
-  double *Ac = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *slab = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
+  double *Ac = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
@@ -49,9 +50,14 @@ struct Coarse {
   TBuf<uint8_t> tile_on;          // 0: the tile holds nodes shared with another rank (multi-GPU) -> no tile-level term
   std::vector<int32_t> h_tile_start;
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
+  // struts inside one aggregate that touch a Dirichlet dof (the only non-crossing struts with coarse energy);
+  // rebuilt on the device after every pl_set_bc
+  int32_t *fix_list = nullptr;
+  int *fix_count = nullptr;
+  int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
-    for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)slab, (void *)part, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt})
+    for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_list, (void *)fix_count})
       if (q) (void)hipFree(q);
   }
 };
@@ -105,9 +111,22 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
       const int I = agg_of_node[conn[2 * b]], J = agg_of_node[conn[2 * b + 1]];
       if (I != J) cross.push_back({(int64_t)I * n_agg + J, (int32_t)b});
     }
+    // struts join neighbouring bricks only, so aggregates couple to their 26 neighbours: a bound from the aggregate
+    // grid alone (identical on every rank of a multi-GPU run, whatever struts this rank holds)
+    const int64_t max_diff = std::min<int64_t>(n_agg - 1, na[1] * na[2] + na[2] + 1);
+    c.bw_blocks = (int)((6 * (max_diff + 1) + kNB - 1) / kNB + 1);
+    for (const auto &pr : cross)   // struts longer than an aggregate (degenerate tiling): no band assumption
+      if (std::abs(pr.first / n_agg - pr.first % n_agg) > max_diff) c.bw_blocks = 0;
     std::sort(cross.begin(), cross.end());
-    std::vector<int32_t> idx2(cross.size());
-    for (size_t q = 0; q < cross.size(); ++q) idx2[q] = cross[q].second;
+    // every ordered pair starts at a wave boundary (padding = -1), so no wave mixes two coarse blocks
+    std::vector<int32_t> idx2;
+    idx2.reserve(cross.size() + cross.size() / 2);
+    for (size_t q = 0; q < cross.size(); ++q) {
+      if (q > 0 && cross[q].first != cross[q - 1].first)
+        while (idx2.size() % kWave) idx2.push_back(-1);
+      idx2.push_back(cross[q].second);
+    }
+    while (idx2.size() % kWave) idx2.push_back(-1);
     c.n_cross = (int64_t)idx2.size();
     if (c.cross_idx.upload(idx2) != hipSuccess) return 1;
   }
@@ -121,9 +140,6 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.W, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Wt, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.slab, (size_t)(c.ncp / kNB) * dense_max_chunks(c.ncp) * kNB * kNB * sizeof(double)) !=
-      hipSuccess)
-    return 2;
   if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;   // + rr, r.D^-1 r
   if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
@@ -149,7 +165,8 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A_c = Z^T P K P Z : one thread per strut, only aggregate-crossing or Dirichlet-touching struts contribute.
+// A_c = Z^T P K P Z : one thread per strut, only aggregate-crossing or Dirichlet-touching struts contribute
+// (k_coarse_assemble_cross over the sorted crossing list, k_coarse_assemble over the device-built fixed list).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void coarse_block_add(const double *K, unsigned frow, unsigned fcol, const double *relp,
                                                  const double *relq, double *dst, int nc) {
@@ -188,15 +205,29 @@ __device__ __forceinline__ void coarse_block_add(const double *K, unsigned frow,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_coarse_assemble(int64_t B, const int32_t *__restrict__ conn,
+__global__ __launch_bounds__(kBlock) void k_list_fixed_struts(int64_t B, const int32_t *__restrict__ conn,
+                                                              const int32_t *__restrict__ agg,
+                                                              const uint8_t *__restrict__ fixedbits,
+                                                              int32_t *__restrict__ list, int *__restrict__ count) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  if (agg[ia] != agg[ib]) return;
+  if ((fixedbits[ia] | fixedbits[ib]) == 0u) return;
+  list[atomicAdd(count, 1)] = (int32_t)b;
+}
+
+__global__ __launch_bounds__(kBlock) void k_coarse_assemble(int64_t n_list, const int32_t *__restrict__ list,
+                                                            const int32_t *__restrict__ conn,
                                                             const Record *__restrict__ rec,
                                                             const int32_t *__restrict__ agg,
                                                             const double *__restrict__ cen,
                                                             const double *__restrict__ xyz,
                                                             const uint8_t *__restrict__ fixedbits, int nc,
                                                             double *__restrict__ Ac) {
-  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (b >= B) return;
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n_list) return;
+  const int64_t b = list[q];
   const int ia = conn[2 * b], ib = conn[2 * b + 1];
   const int I = agg[ia], J = agg[ib];
   const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
@@ -269,8 +300,9 @@ __global__ __launch_bounds__(kBlock) void k_coarse_assemble_cross(int64_t n_cros
                                                                   const uint8_t *__restrict__ fixedbits, int nc,
                                                                   double *__restrict__ Ac) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = q < n_cross;
-  const int64_t b = live ? cross[q] : cross[n_cross - 1];
+  if ((q & ~(int64_t)(kWave - 1)) >= n_cross) return;        // whole wave past the end (no block-level sync below)
+  const bool live = cross[q] >= 0;
+  const int64_t b = live ? cross[q] : cross[q & ~(int64_t)(kWave - 1)];   // lane 0 of a wave is never padding
   const int ia = conn[2 * b], ib = conn[2 * b + 1];
   const int I = agg[ia], J = agg[ib];
   const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
@@ -292,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_assemble_cross(int64_t n_cros
   double *dII = Ac + ((size_t)6 * I) * nc + 6 * I, *dJJ = Ac + ((size_t)6 * J) * nc + 6 * J;
   double *dX = Ac + ((size_t)6 * hi) * nc + 6 * lo;
   const int I0 = __shfl(I, 0, 64), J0 = __shfl(J, 0, 64);
-  const bool uniform = __all(I == I0 && J == J0);            // dead lanes replicate the last strut's pair
+  const bool uniform = __all(I == I0 && J == J0);            // always, by the padding; dead lanes replicate lane 0
   if (uniform) {
 #pragma unroll
     for (int e = 0; e < 36; ++e) {

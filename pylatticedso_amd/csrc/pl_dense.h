@@ -1,13 +1,15 @@
 // Small dense SPD solver on the device for the coarse operator of the two-level preconditioner (n <= a few thousand).
 //
 // Blocked right-looking Cholesky A = L L^T (64 x 64 blocks, lower triangle of a row-major matrix), then the explicit
-// inverse factor W = L^-1 (blocked, anti-diagonal by anti-diagonal), so that applying A^-1 is two triangular GEMVs
+// inverse factor W = L^-1 (blocked, all block columns in one launch), so that applying A^-1 is two triangular GEMVs
 //     t = W r ,  y = W^T t ,  r.A^-1 r = t.t
 // with the same traffic as one full GEMV (W^T is stored explicitly so both are row-per-wave, coalesced).  Hand-written because vendor BLAS/LAPACK libraries loaded into a process
 // that already holds PyTorch's bundled ROCm libraries resolve against the wrong versions (observed: minutes of
 // start-up or a crash); it is ~1 % of a solve, so simple LDS-tiled fp64 VALU kernels are enough.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "pl_kernels.h"
 
@@ -134,67 +136,65 @@ __global__ __launch_bounds__(kBlock) void k_chol_trail(double *__restrict__ A, i
     for (int j = 0; j < 4; ++j) Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] -= acc[i][j];
 }
 
-// W = L^-1, block (i = k + d, k):  W_ik = - Dinv_i * sum_{j=k}^{i-1} L_ij W_jk, anti-diagonal d by anti-diagonal.
-// The j-sum is cut into chunks of kTrChunk tile products computed by separate workgroups (slabs, no atomics) so the
-// late anti-diagonals (few blocks, long sums) still fill the chip; k_trtri_final adds the slabs and applies -Dinv_i.
-constexpr int kTrChunk = 4;
+// W = L^-1 column by column: block column k of W depends on nothing but L, so ONE launch computes all of W with
+// no synchronisation between workgroups.  A workgroup owns kCw columns of block column k and walks down the block
+// rows,  W_kk = Dinv_k,  W_ik = -Dinv_i * sum_{j = max(k, i - bw)}^{i-1} L_ij W_jk   (bw = block bandwidth of L:
+// the coarse operator couples only neighbouring aggregates, so L is banded and the sums are short),
+// re-reading its own earlier W_jk slices from global memory (same workgroup: visible after the barrier).
+// W^T is written alongside (the second triangular GEMV wants rows).
+constexpr int kCw = 8;
 
-__global__ __launch_bounds__(kBlock) void k_trtri_partial(const double *__restrict__ L, const double *__restrict__ W,
-                                                          int ld, int d, double *__restrict__ slab, int maxchunk) {
-  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
-  const int kb = blockIdx.x, ib = kb + d, ch = blockIdx.y;
-  const int j0 = kb + ch * kTrChunk, j1 = min(ib, j0 + kTrChunk);
-  if (j0 >= ib) return;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double acc[4][4] = {};
-  for (int jb = j0; jb < j1; ++jb) {
-    __syncthreads();
-    stage_rows_as_k_minor(L + ((size_t)ib * kNB) * ld + (size_t)jb * kNB, ld, At);    // At[m][row] = L_ij[row][m]
-    stage_rows_as_k_major(W + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, Bt);    // Bt[m][col] = W_jk[m][col]
-    __syncthreads();
-    tile_fma(At, Bt, tx, ty, acc);
+__global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict__ L, int ld, int nb, int bw,
+                                                       const double *__restrict__ Dinv, double *__restrict__ W,
+                                                       double *__restrict__ Wt) {
+  __shared__ double At[kNB * kLdT];
+  __shared__ double Ws[kNB * kCw], S[kNB * kCw];
+  constexpr int kSl = kNB / kCw;
+  const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCw;
+  const int r = threadIdx.x & (kNB - 1), g = threadIdx.x / kNB;      // row, column pair (2g, 2g+1) of the slice
+  for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
+    const int row = e / kCw, c = e % kCw;
+    const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
+    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = v;
+    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = v;
   }
-  double *out = slab + ((size_t)kb * maxchunk + ch) * kNB * kNB;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[(4 * ty + i) * kNB + 4 * tx + j] = acc[i][j];
-}
-
-// d = 0: copy Dinv into the diagonal blocks of W and W^T.  d > 0: W_ik = -Dinv_i * (sum of slabs).
-__global__ __launch_bounds__(kBlock) void k_trtri_final(double *__restrict__ W, double *__restrict__ Wt, int ld, int d,
-                                                        const double *__restrict__ Dinv,
-                                                        const double *__restrict__ slab, int maxchunk) {
-  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
-  const int kb = blockIdx.x, ib = kb + d;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double *Wik = W + ((size_t)ib * kNB) * ld + (size_t)kb * kNB;
-  double *Wtki = Wt + ((size_t)kb * kNB) * ld + (size_t)ib * kNB;      // transposed copy: W^T block (k, i)
-  if (d == 0) {
-    for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
-      const double v = Dinv[(size_t)kb * kNB * kNB + e];
-      Wik[(size_t)(e / kNB) * ld + e % kNB] = v;
-      Wtki[(size_t)(e % kNB) * ld + e / kNB] = v;
+  for (int ib = kb + 1; ib < nb; ++ib) {
+    double acc0 = 0.0, acc1 = 0.0;
+    const int jlo = max(kb, ib - bw);
+    for (int jb = jlo; jb < ib; ++jb) {
+      __syncthreads();                                                 // previous tile consumed, earlier W rows written
+      stage_rows_as_k_minor(L + ((size_t)ib * kNB) * ld + (size_t)jb * kNB, ld, At);    // At[m][row] = L_ij[row][m]
+      for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
+        const int m = e / kCw, c = e % kCw;
+        Ws[e] = W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int m = 0; m < kNB; ++m) {
+        const double a = At[m * kLdT + r];
+        acc0 += a * Ws[m * kCw + 2 * g];
+        acc1 += a * Ws[m * kCw + 2 * g + 1];
+      }
     }
-    return;
-  }
-  const int nch = (d + kTrChunk - 1) / kTrChunk;
-  for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) {
-    double sacc = 0.0;
-    for (int c = 0; c < nch; ++c) sacc += slab[((size_t)kb * maxchunk + c) * kNB * kNB + e];
-    Bt[(e / kNB) * kLdT + e % kNB] = sacc;                                             // Bt[m][col] = S[m][col]
-  }
-  stage_rows_as_k_minor(Dinv + (size_t)ib * kNB * kNB, kNB, At);                      // At[m][row] = Dinv_i[row][m]
-  __syncthreads();
-  double out[4][4] = {};
-  tile_fma(At, Bt, tx, ty, out);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Wik[(size_t)(4 * ty + i) * ld + 4 * tx + j] = -out[i][j];
-      Wtki[(size_t)(4 * tx + j) * ld + 4 * ty + i] = -out[i][j];
+    __syncthreads();
+    S[r * kCw + 2 * g] = acc0;
+    S[r * kCw + 2 * g + 1] = acc1;
+    stage_rows_as_k_minor(Dinv + (size_t)ib * kNB * kNB, kNB, At);                      // At[m][row] = Dinv_i[row][m]
+    __syncthreads();
+    double o0 = 0.0, o1 = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < kNB; ++m) {
+      const double a = At[m * kLdT + r];
+      o0 += a * S[m * kCw + 2 * g];
+      o1 += a * S[m * kCw + 2 * g + 1];
     }
+    double *Wik = W + ((size_t)ib * kNB + r) * ld + (size_t)kb * kNB + c0 + 2 * g;
+    Wik[0] = -o0;
+    Wik[1] = -o1;
+    double *Wtki = Wt + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
+    Wtki[0] = -o0;
+    Wtki[ld] = -o1;
+  }
 }
 
 // t = W r (W lower triangular, one wave per row); dot_out[slot] += t.t
@@ -254,27 +254,20 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const double *
 }
 
 // Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used, overwritten by L) and build W = L^-1.
-// slab: scratch of (n/kNB) * dense_max_chunks(n) tiles of kNB*kNB doubles.
-inline int dense_max_chunks(int n) { return (n / kNB + kTrChunk - 1) / kTrChunk; }
-
-inline void dense_factor_inverse(double *A, double *W, double *Wt, double *Dinv, double *slab, int n, int ld,
-                                 int *info, hipStream_t s) {
+// bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
+inline void dense_factor_inverse(double *A, double *W, double *Wt, double *Dinv, int n, int ld, int *info, int bw,
+                                 hipStream_t s) {
   const int nb = n / kNB;
-  const int maxchunk = dense_max_chunks(n);
+  if (bw <= 0 || bw > nb) bw = nb;
   for (int k = 0; k < nb; ++k) {
     hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kWave), 0, s, A, ld, k, Dinv, info);
-    const int rest = nb - k - 1;
+    const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
     if (rest > 0) {
       hipLaunchKernelGGL(k_chol_panel, dim3(rest), dim3(kBlock), 0, s, A, ld, k, Dinv);
       hipLaunchKernelGGL(k_chol_trail, dim3(rest, rest), dim3(kBlock), 0, s, A, ld, k);
     }
   }
-  for (int d = 0; d < nb; ++d) {
-    if (d > 0)
-      hipLaunchKernelGGL(k_trtri_partial, dim3(nb - d, (d + kTrChunk - 1) / kTrChunk), dim3(kBlock), 0, s, A, W, ld, d,
-                         slab, maxchunk);
-    hipLaunchKernelGGL(k_trtri_final, dim3(nb - d), dim3(kBlock), 0, s, W, Wt, ld, d, Dinv, slab, maxchunk);
-  }
+  hipLaunchKernelGGL(k_trtri_cols, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, A, ld, nb, bw, Dinv, W, Wt);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
