@@ -65,7 +65,14 @@ struct pl_context {
   int64_t N = 0, B = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pl_assemble overlaps the latency-bound dense factorisation chain (main stream) with the bandwidth-bound fills
+  // (palette, Jacobi diagonal, tile blocks, explicit BSR) on a second stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool assembled = false, have_bc = false, have_bsr = false;
+  int pal_host_flags[2] = {1, 0};
+  bool want_bsr = false;   // pl_assemble_bsr was called once: pl_assemble keeps the explicit matrix current
+  int bsr_with_bc = 0;
 
   // caller numbering <-> device numbering (perm[dev] = caller node)
   std::vector<int32_t> perm, iperm;
@@ -123,6 +130,9 @@ struct pl_context {
   ~pl_context() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -252,8 +262,11 @@ int launch_records(pl_context *c) {
 }
 
 // Try to replace the per-strut records by palette ids (periodic lattices); leaves pal_ready = false otherwise.
-int build_palette(pl_context *c) {
+// launch_palette queues the kernels and the flag read-back on `st`; finish_palette (after a sync) reads the verdict.
+int launch_palette(pl_context *c, hipStream_t st) {
   c->pal_ready = false;
+  c->pal_host_flags[0] = 1;
+  c->pal_host_flags[1] = 0;
   if (!c->opt.palette) return PL_OK;
   if (!c->pal_keys.p) {
     PL_HIP(c->pal_keys.alloc(pl::kPalSize));
@@ -262,42 +275,62 @@ int build_palette(pl_context *c) {
     PL_HIP(c->pal_id.alloc(c->B));
     PL_HIP(c->palette.alloc(pl::kPalSize));
   }
-  PL_HIP(hipMemsetAsync(c->pal_keys.p, 0xFF, pl::kPalSize * sizeof(unsigned long long), c->stream));
-  PL_HIP(hipMemsetAsync(c->pal_owner.p, 0x7F, pl::kPalSize * sizeof(int), c->stream));
-  PL_HIP(hipMemsetAsync(c->pal_flags.p, 0, 2 * sizeof(int), c->stream));
-  PL_HIP(hipMemsetAsync(c->palette.p, 0, pl::kPalSize * sizeof(pl::Record), c->stream));
+  PL_HIP(hipMemsetAsync(c->pal_keys.p, 0xFF, pl::kPalSize * sizeof(unsigned long long), st));
+  PL_HIP(hipMemsetAsync(c->pal_owner.p, 0x7F, pl::kPalSize * sizeof(int), st));
+  PL_HIP(hipMemsetAsync(c->pal_flags.p, 0, 2 * sizeof(int), st));
+  PL_HIP(hipMemsetAsync(c->palette.p, 0, pl::kPalSize * sizeof(pl::Record), st));
   const dim3 g(grid_for(c->B)), blk(pl::kBlock);
-  hipLaunchKernelGGL(pl::k_pal_insert, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_keys.p, c->pal_owner.p,
-                     c->pal_id.p, c->pal_flags.p);
-  hipLaunchKernelGGL(pl::k_pal_publish, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_owner.p, c->pal_id.p,
-                     c->palette.p);
-  hipLaunchKernelGGL(pl::k_pal_verify, g, blk, 0, c->stream, c->B, c->rec.p, c->pal_id.p, c->palette.p,
-                     c->pal_owner.p, c->pal_flags.p);
+  hipLaunchKernelGGL(pl::k_pal_insert, g, blk, 0, st, c->B, c->rec.p, c->pal_keys.p, c->pal_owner.p, c->pal_id.p,
+                     c->pal_flags.p);
+  hipLaunchKernelGGL(pl::k_pal_publish, g, blk, 0, st, c->B, c->rec.p, c->pal_owner.p, c->pal_id.p, c->palette.p);
+  hipLaunchKernelGGL(pl::k_pal_verify, g, blk, 0, st, c->B, c->rec.p, c->pal_id.p, c->palette.p, c->pal_owner.p,
+                     c->pal_flags.p);
   PL_HIP(hipGetLastError());
-  int flags[2] = {1, 0};
-  PL_HIP(hipMemcpyAsync(flags, c->pal_flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipMemcpyAsync(c->pal_host_flags, c->pal_flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  return PL_OK;
+}
+void finish_palette(pl_context *c) {
+  if (!c->opt.palette) return;
+  c->pal_entries = c->pal_host_flags[1];
+  c->pal_ready = (c->pal_host_flags[0] == 0);
+}
+int build_palette(pl_context *c) {
+  int rc = launch_palette(c, c->stream);
+  if (rc) return rc;
   PL_HIP(hipStreamSynchronize(c->stream));
-  c->pal_entries = flags[1];
-  c->pal_ready = (flags[0] == 0);
+  finish_palette(c);
   return PL_OK;
 }
 
-int launch_diag(pl_context *c) {
+int launch_diag(pl_context *c, hipStream_t st) {
   const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
 #define PL_D(L)                                                                                                  \
-  hipLaunchKernelGGL((pl::k_diag_gather<L>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, c->ent.p, \
+  hipLaunchKernelGGL((pl::k_diag_gather<L>), dim3(g), dim3(pl::kBlock), 0, st, c->N, c->slice_ptr.p, c->ent.p, \
                      c->rec.p, fb, c->diag.p, c->dinv.p)
   switch (c->lpn) { case 1: PL_D(1); break; case 2: PL_D(2); break; case 4: PL_D(4); break; case 8: PL_D(8); break;
                     default: PL_D(16); }
 #undef PL_D
   PL_HIP(hipGetLastError());
-  if (c->dist.active) {
-    // the diagonal of shared nodes is the sum over ranks; then invert again
-    int rc = pl::dist_sum_shared(c->dist, c->diag.p, c->stream);
-    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of the Jacobi diagonal failed");
-    pl::launch_invert_diag(c->N * 6, c->diag.p, c->have_bc ? c->fixed.p : nullptr, c->dinv.p, c->stream);
-  }
+  return PL_OK;
+}
+// multi-GPU: the diagonal of shared nodes is the sum over ranks; then invert again (main stream: RCCL)
+int finish_diag_dist(pl_context *c) {
+  if (!c->dist.active) return PL_OK;
+  int rc = pl::dist_sum_shared(c->dist, c->diag.p, c->stream);
+  if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of the Jacobi diagonal failed");
+  pl::launch_invert_diag(c->N * 6, c->diag.p, c->have_bc ? c->fixed.p : nullptr, c->dinv.p, c->stream);
+  return PL_OK;
+}
+
+int launch_tile_blocks(pl_context *c, hipStream_t st) {
+  pl::Coarse &cs = c->coarse;
+  if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
+  hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
+                     c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
+                     reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                     c->fixedbits.p, cs.tile_on.p, cs.Bt_inv);
+  PL_HIP(hipGetLastError());
   return PL_OK;
 }
 
@@ -309,22 +342,41 @@ int build_coarse(pl_context *c) {
   const int n = cs.ncp;
   PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
   PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
-  if (cs.n_fix < 0) {   // Dirichlet set changed: list the in-aggregate struts that touch it
-    if (!cs.fix_list) {
-      PL_HIP(hipMalloc((void **)&cs.fix_list, (size_t)std::max<int64_t>(c->B, 1) * sizeof(int32_t)));
-      PL_HIP(hipMalloc((void **)&cs.fix_count, sizeof(int)));
-    }
-    PL_HIP(hipMemsetAsync(cs.fix_count, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(pl::k_list_fixed_struts, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
-                       cs.agg_of_node.p, c->fixedbits.p, cs.fix_list, cs.fix_count);
+  if (cs.n_fix < 0) {   // Dirichlet set changed: list the in-aggregate struts that touch it, grouped by aggregate
+    if (!cs.fix_count) PL_HIP(hipMalloc((void **)&cs.fix_count, sizeof(int)));
     int cnt = 0;
-    PL_HIP(hipMemcpyAsync(&cnt, cs.fix_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PL_HIP(hipStreamSynchronize(c->stream));
-    cs.n_fix = cnt;
+    DevBuf<int64_t> keys;
+    for (int pass = 0; pass < 2; ++pass) {
+      PL_HIP(hipMemsetAsync(cs.fix_count, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(pl::k_list_fixed_struts, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B,
+                         c->conn.p, cs.agg_of_node.p, c->fixedbits.p, pass ? keys.p : (int64_t *)nullptr, cs.fix_count);
+      if (pass == 0) {
+        PL_HIP(hipMemcpyAsync(&cnt, cs.fix_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PL_HIP(hipStreamSynchronize(c->stream));
+        if (cnt == 0) break;
+        PL_HIP(keys.alloc((size_t)cnt));
+      }
+    }
+    std::vector<int32_t> list;
+    if (cnt > 0) {
+      std::vector<int64_t> hk((size_t)cnt);
+      PL_HIP(hipMemcpyAsync(hk.data(), keys.p, hk.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipStreamSynchronize(c->stream));
+      std::sort(hk.begin(), hk.end());
+      list.reserve(hk.size() + hk.size() / 4 + pl::kWave);
+      for (size_t q = 0; q < hk.size(); ++q) {
+        if (q > 0 && (hk[q] >> 32) != (hk[q - 1] >> 32))
+          while (list.size() % pl::kWave) list.push_back(-1);
+        list.push_back((int32_t)(hk[q] & 0xffffffffLL));
+      }
+      while (list.size() % pl::kWave) list.push_back(-1);
+      PL_HIP(cs.fix_list.upload(list));
+    }
+    cs.n_fix = (int64_t)list.size();
   }
   if (cs.n_fix > 0)
     hipLaunchKernelGGL(pl::k_coarse_assemble, dim3(grid_for(cs.n_fix)), dim3(pl::kBlock), 0, c->stream, cs.n_fix,
-                       cs.fix_list, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n,
+                       cs.fix_list.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n,
                        cs.Ac);
   if (cs.n_cross > 0)
     hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
@@ -335,11 +387,6 @@ int build_coarse(pl_context *c) {
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  if (cs.tile_level)
-    hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                       c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
-                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                       c->fixedbits.p, cs.tile_on.p, cs.Bt_inv);
   pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
@@ -350,11 +397,11 @@ int build_coarse(pl_context *c) {
   return PL_OK;
 }
 
-int launch_bsr_fill(pl_context *c, int with_bc) {
+int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
   const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
 #define PL_B(L)                                                                                                  \
-  hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, c->ent.p,  \
+  hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(g), dim3(pl::kBlock), 0, st, c->N, c->slice_ptr.p, c->ent.p,  \
                      c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p, fb, with_bc, c->bsr_vals.p)
   switch (c->lpn) { case 1: PL_B(1); break; case 2: PL_B(2); break; case 4: PL_B(4); break; case 8: PL_B(8); break;
                     default: PL_B(16); }
@@ -634,8 +681,11 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
       return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
   PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PL_HIPC(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   PL_HIPC(hipEventCreate(&c->ev0));
   PL_HIPC(hipEventCreate(&c->ev1));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 
   // node ordering on the device
   const double global_grid[7] = {o->grid_lo[0], o->grid_lo[1], o->grid_lo[2], o->grid_hi[0], o->grid_hi[1],
@@ -755,8 +805,11 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
       return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
   PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PL_HIPC(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   PL_HIPC(hipEventCreate(&c->ev0));
   PL_HIPC(hipEventCreate(&c->ev1));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   c->perm.resize(n_nodes);
   std::iota(c->perm.begin(), c->perm.end(), 0);
   c->iperm = c->perm;
@@ -826,11 +879,16 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
     PL_HIP(hipStreamSynchronize(h->stream));
   } else if (h->assembled) {   // the Jacobi inverse and the coarse operator depend on the mask
-    int rc = launch_diag(h);
+    int rc = launch_diag(h, h->stream);
+    if (rc) return rc;
+    rc = finish_diag_dist(h);
+    if (rc) return rc;
+    rc = launch_tile_blocks(h, h->stream);
     if (rc) return rc;
     rc = build_coarse(h);
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
+    if (h->bsr_with_bc) h->have_bsr = false;   // an explicit matrix built with the old mask is stale
   }
   return PL_OK;
 }
@@ -880,18 +938,35 @@ int pl_assemble(pl_handle h) {
   PL_HIP(hipEventRecord(h->ev0, h->stream));
   int rc = launch_records(h);
   if (rc) return rc;
-  rc = build_palette(h);
+  // fork: everything that only streams the records runs on the side stream while the main stream walks the
+  // latency-bound chain of the coarse factorisation
+  PL_HIP(hipEventRecord(h->ev_fork, h->stream));
+  PL_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  rc = launch_palette(h, h->side);
   if (rc) return rc;
-  rc = launch_diag(h);
+  rc = launch_diag(h, h->dist.active ? h->stream : h->side);
   if (rc) return rc;
+  rc = finish_diag_dist(h);
+  if (rc) return rc;
+  rc = launch_tile_blocks(h, h->side);
+  if (rc) return rc;
+  const bool refresh_bsr = h->want_bsr && (!h->bsr_with_bc || h->have_bc);
+  if (refresh_bsr) {
+    rc = launch_bsr_fill(h, h->bsr_with_bc, h->side);
+    if (rc) return rc;
+  }
+  PL_HIP(hipEventRecord(h->ev_join, h->side));
   rc = build_coarse(h);
   if (rc) return rc;
+  PL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
+  finish_palette(h);
   float ms = 0.f;
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->ms_assembly = ms;
   h->assembled = true;
+  h->have_bsr = refresh_bsr;
   return PL_OK;
 }
 
@@ -908,8 +983,16 @@ int pl_assemble_bsr(pl_handle h, int with_bc, int64_t *n_block_rows, int64_t *n_
     PL_HIP(hipMemcpy(h->bsr_rowptr.p, h->h_rowptr.data(), (h->N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     PL_HIP(hipMemcpy(h->bsr_col.p, h->h_col.data(), h->nblk * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  const bool fresh = h->have_bsr && h->want_bsr && h->bsr_with_bc == (with_bc ? 1 : 0);
+  h->want_bsr = true;
+  h->bsr_with_bc = with_bc ? 1 : 0;
+  if (fresh) {   // pl_assemble already rebuilt it (overlapped with the coarse factorisation)
+    if (n_block_rows) *n_block_rows = h->N;
+    if (n_blocks) *n_blocks = h->nblk;
+    return PL_OK;
+  }
   PL_HIP(hipEventRecord(h->ev0, h->stream));
-  int rc = launch_bsr_fill(h, with_bc);
+  int rc = launch_bsr_fill(h, with_bc, h->stream);
   if (rc) return rc;
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
@@ -1139,7 +1222,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
         int r1 = launch_records(h);
         return r1 ? r1 : build_palette(h);
       }
-      case 2: return launch_bsr_fill(h, 0);
+      case 2: return launch_bsr_fill(h, 0, h->stream);
       case 3: return pcg_iteration(h, k);
       case 4:
         hipLaunchKernelGGL(pl::k_bsr_spmv, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N,

@@ -52,12 +52,12 @@ struct Coarse {
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
   // struts inside one aggregate that touch a Dirichlet dof (the only non-crossing struts with coarse energy);
   // rebuilt on the device after every pl_set_bc
-  int32_t *fix_list = nullptr;
+  TBuf<int32_t> fix_list;
   int *fix_count = nullptr;
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_list, (void *)fix_count})
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count})
       if (q) (void)hipFree(q);
   }
 };
@@ -168,87 +168,19 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
 // A_c = Z^T P K P Z : one thread per strut, only aggregate-crossing or Dirichlet-touching struts contribute
 // (k_coarse_assemble_cross over the sorted crossing list, k_coarse_assemble over the device-built fixed list).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void coarse_block_add(const double *K, unsigned frow, unsigned fcol, const double *relp,
-                                                 const double *relq, double *dst, int nc) {
-  // C = Zp^T (mask K mask) Zq,  Z = [[I, -S(rel)], [0, I]],  S(v) w = v x w
-  double Km[36];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) Km[i * 6 + j] = (((frow >> i) & 1u) || ((fcol >> j) & 1u)) ? 0.0 : K[i * 6 + j];
-  const double Sq[3][3] = {{0, -relq[2], relq[1]}, {relq[2], 0, -relq[0]}, {-relq[1], relq[0], 0}};
-  const double Sp[3][3] = {{0, -relp[2], relp[1]}, {relp[2], 0, -relp[0]}, {-relp[1], relp[0], 0}};
-  double M[36];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) M[i * 6 + j] = Km[i * 6 + j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double acc = Km[i * 6 + 3 + j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc -= Km[i * 6 + k] * Sq[k][j];
-      M[i * 6 + 3 + j] = acc;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) unsafeAtomicAdd(dst + (size_t)i * nc + j, M[i * 6 + j]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double acc = M[(3 + i) * 6 + j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc += Sp[i][k] * M[k * 6 + j];
-      unsafeAtomicAdd(dst + (size_t)(3 + i) * nc + j, acc);
-    }
-  }
-}
-
+// keys == nullptr: count only.  key = aggregate << 32 | strut, so that the host can group the list by aggregate.
 __global__ __launch_bounds__(kBlock) void k_list_fixed_struts(int64_t B, const int32_t *__restrict__ conn,
                                                               const int32_t *__restrict__ agg,
                                                               const uint8_t *__restrict__ fixedbits,
-                                                              int32_t *__restrict__ list, int *__restrict__ count) {
+                                                              int64_t *__restrict__ keys, int *__restrict__ count) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
   const int ia = conn[2 * b], ib = conn[2 * b + 1];
-  if (agg[ia] != agg[ib]) return;
+  const int I = agg[ia];
+  if (I != agg[ib]) return;
   if ((fixedbits[ia] | fixedbits[ib]) == 0u) return;
-  list[atomicAdd(count, 1)] = (int32_t)b;
-}
-
-__global__ __launch_bounds__(kBlock) void k_coarse_assemble(int64_t n_list, const int32_t *__restrict__ list,
-                                                            const int32_t *__restrict__ conn,
-                                                            const Record *__restrict__ rec,
-                                                            const int32_t *__restrict__ agg,
-                                                            const double *__restrict__ cen,
-                                                            const double *__restrict__ xyz,
-                                                            const uint8_t *__restrict__ fixedbits, int nc,
-                                                            double *__restrict__ Ac) {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= n_list) return;
-  const int64_t b = list[q];
-  const int ia = conn[2 * b], ib = conn[2 * b + 1];
-  const int I = agg[ia], J = agg[ib];
-  const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
-  if (I != J) return;                           // crossing struts: k_coarse_assemble_cross
-  if (fa == 0u && fb == 0u) return;             // a rigid motion of the whole strut: no energy
-  const Record r = load_record(rec, b);
-  double rela[3], relb[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    rela[k] = xyz[3 * (int64_t)ia + k] - cen[3 * I + k];
-    relb[k] = xyz[3 * (int64_t)ib + k] - cen[3 * J + k];
-  }
-  // the Cholesky reads only the lower triangle (row >= col) of A_c: off-diagonal coarse blocks are added once, on
-  // the side with the larger aggregate index (for I == J both orientations land in the same diagonal block)
-  double Kss[36], Kso[36];
-  tip_blocks(r, Kss, Kso);                                   // K_bb, K_ba
-  coarse_block_add(Kss, fb, fb, relb, relb, Ac + ((size_t)6 * J) * nc + 6 * J, nc);
-  if (J >= I) coarse_block_add(Kso, fb, fa, relb, rela, Ac + ((size_t)6 * J) * nc + 6 * I, nc);
-  tip_blocks(reversed(r), Kss, Kso);                         // K_aa, K_ab
-  coarse_block_add(Kss, fa, fa, rela, rela, Ac + ((size_t)6 * I) * nc + 6 * I, nc);
-  if (I >= J) coarse_block_add(Kso, fa, fb, rela, relb, Ac + ((size_t)6 * I) * nc + 6 * J, nc);
+  const int slot = atomicAdd(count, 1);
+  if (keys) keys[slot] = ((int64_t)I << 32) | (int64_t)b;
 }
 
 // Coarse block C = Zp^T (mask K mask) Zq into registers (no memory traffic).
@@ -285,6 +217,58 @@ __device__ __forceinline__ void coarse_block(const double *K, unsigned frow, uns
       for (int k = 0; k < 3; ++k) acc += Sp[i][k] * M[k * 6 + j];
       C[(3 + i) * 6 + j] = acc;
     }
+  }
+}
+
+// In-aggregate struts that touch Dirichlet dofs: all four terms land in the diagonal block (I, I).  The list is
+// grouped by aggregate and padded to wave boundaries (like the crossing list): sum across the wave, one lane issues
+// the 36 atomics.
+__global__ __launch_bounds__(kBlock) void k_coarse_assemble(int64_t n_list, const int32_t *__restrict__ list,
+                                                            const int32_t *__restrict__ conn,
+                                                            const Record *__restrict__ rec,
+                                                            const int32_t *__restrict__ agg,
+                                                            const double *__restrict__ cen,
+                                                            const double *__restrict__ xyz,
+                                                            const uint8_t *__restrict__ fixedbits, int nc,
+                                                            double *__restrict__ Ac) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((q & ~(int64_t)(kWave - 1)) >= n_list) return;         // whole wave past the end (no block-level sync below)
+  const bool live = list[q] >= 0;                            // -1 = padding (aggregates start at wave boundaries)
+  const int64_t b = live ? list[q] : list[q & ~(int64_t)(kWave - 1)];
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  const int I = agg[ia];
+  const unsigned fa = fixedbits[ia], fb = fixedbits[ib];
+  const Record r = load_record(rec, b);
+  double rela[3], relb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rela[k] = xyz[3 * (int64_t)ia + k] - cen[3 * I + k];
+    relb[k] = xyz[3 * (int64_t)ib + k] - cen[3 * I + k];
+  }
+  double Kss[36], Kso[36], C[36], T[36];
+  tip_blocks(r, Kss, Kso);                                   // K_bb, K_ba
+  coarse_block(Kss, fb, fb, relb, relb, T);
+  coarse_block(Kso, fb, fa, relb, rela, C);
+#pragma unroll
+  for (int e = 0; e < 36; ++e) T[e] += C[e];
+  tip_blocks(reversed(r), Kss, Kso);                         // K_aa, K_ab
+  coarse_block(Kss, fa, fa, rela, rela, C);
+#pragma unroll
+  for (int e = 0; e < 36; ++e) T[e] += C[e];
+  coarse_block(Kso, fa, fb, rela, relb, C);
+#pragma unroll
+  for (int e = 0; e < 36; ++e) T[e] += C[e];
+  double *dII = Ac + ((size_t)6 * I) * nc + 6 * I;
+  const bool uniform = __all(I == __shfl(I, 0, 64));
+  if (uniform) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) {
+      const double v = wave_sum(live ? T[e] : 0.0);
+      if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(dII + (size_t)(e / 6) * nc + e % 6, v);
+    }
+  } else if (live) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) unsafeAtomicAdd(dII + (size_t)(e / 6) * nc + e % 6, T[e]);
   }
 }
 

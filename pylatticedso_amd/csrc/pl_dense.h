@@ -50,54 +50,166 @@ __device__ __forceinline__ void stage_rows_as_k_major(const double *G, int ld, d
   }
 }
 
-// Diagonal block: L_kk and its inverse, ONE WAVE, everything in registers: lane i owns row i of the 64 x 64 block;
-// pivots and multipliers travel by wave broadcast (readlane), so there is no LDS round trip and no barrier in the
-// 2 x 2016-step dependency chains.  info[0] != 0 if a pivot is not positive.
-// v_readlane_b32 x2: the source lane is a compile-time constant after unrolling, so the value lands in SGPRs with a
-// few cycles of latency (a ds_bpermute shuffle would put ~100 cycles into every step of the dependency chain).
-__device__ __forceinline__ double bcast(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
+// Diagonal block: L_kk and its inverse by ONE workgroup.
+// Cholesky: right-looking over tile columns of width 4, every thread keeps a 4 x 4 register tile of the block; per
+// step the diagonal tile is factored and inverted by its owner, the tiles below it are solved by theirs and travel
+// through LDS (two barriers per step, 32 in all), the rank-4 update runs in registers.
+// Inverse: X = L^-1 by halves - the two 32 x 32 diagonal sub-blocks are inverted by one wave each (column per lane,
+// L broadcast from LDS), then X21 = -X22 (L21 X11) as two small LDS GEMMs over all 256 threads.
+// info[0] != 0 if a pivot is not positive.
+constexpr int kLdD = kNB + 1;    // LDS pitch of the diagonal block
+constexpr int kHalf = kNB / 2;
 
-__global__ __launch_bounds__(kWave) void k_chol_diag(double *__restrict__ A, int ld, int kb,
+__global__ __launch_bounds__(kBlock) void k_chol_diag(double *__restrict__ A, int ld, int kb,
                                                      double *__restrict__ Dinv, int *__restrict__ info) {
-  const int lane = threadIdx.x;
+  __shared__ double Ls[kNB * kLdD];
+  __shared__ double T[kHalf * (kHalf + 1)];
+  __shared__ double colt[kNB * 4];
+  __shared__ double dm[16];
+  __shared__ int bad_s;
+  static_assert(kNB == 64 && kBlock == 256, "k_chol_diag is written for 64 x 64 blocks and 256 threads");
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // register tile: rows 4 ty + i, columns 4 tx + c
+  const bool act = ty >= tx;                                 // tiles of the lower triangle
   double *Akk = A + ((size_t)kb * kNB) * ld + (size_t)kb * kNB;
-  double a[kNB];
+  double a[4][4];
 #pragma unroll
-  for (int c = 0; c < kNB; ++c) a[c] = Akk[(size_t)lane * ld + c];
-  bool bad = false;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int j = 0; j < kNB; ++j) {
-    const double d = bcast(a[j], j);
-    if (!(d > 0.0)) bad = true;
-    const double ljj = sqrt(d > 0.0 ? d : 1.0);
-    if (lane == j) a[j] = ljj;
-    if (lane > j) a[j] /= ljj;
+    for (int c = 0; c < 4; ++c) a[i][c] = act ? Akk[(size_t)(4 * ty + i) * ld + 4 * tx + c] : 0.0;
+  if (threadIdx.x == 0) bad_s = 0;
+  for (int jt = 0; jt < kNB / 4; ++jt) {                     // four columns (one tile column) per step
+    if (tx == jt && ty == jt) {                              // diagonal tile: 4 x 4 Cholesky + inverse in registers
+      double l[4][4], m[4][4];
+      bool ok = true;
 #pragma unroll
-    for (int c = j + 1; c < kNB; ++c) {
-      const double lcj = bcast(a[j], c);          // L[c][j]
-      if (lane >= c) a[c] -= a[j] * lcj;
+      for (int c = 0; c < 4; ++c) {
+        double d = a[c][c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) d -= l[c][q] * l[c][q];
+        ok = ok && (d > 0.0);
+        const double ri = rsqrt(d > 0.0 ? d : 1.0);
+        l[c][c] = (d > 0.0 ? d : 1.0) * ri;
+        m[c][c] = ri;
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+          double v = a[i][c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v -= l[i][q] * l[c][q];
+          l[i][c] = v * ri;
+        }
+      }
+      if (!ok) bad_s = 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)                            // M = L^-1 (lower), column by column
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+          double v = 0.0;
+#pragma unroll
+          for (int q = c; q < i; ++q) v -= l[i][q] * m[q][c];
+          m[i][c] = v * m[i][i];
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a[i][c] = c <= i ? l[i][c] : 0.0;
+          dm[4 * i + c] = c <= i ? m[i][c] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tx == jt && ty > jt) {                               // tiles below it: L_ik = A_ik M^T, published row-wise
+      double mm[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mm[e] = dm[e];
+      double l[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int q = 0; q <= c; ++q) v += a[i][q] * mm[4 * c + q];
+          l[i][c] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a[i][c] = l[i][c];
+          colt[(4 * ty + i) * 4 + c] = l[i][c];
+        }
+    }
+    __syncthreads();
+    if (act && tx > jt) {                                    // rank-4 update of everything right of the tile column
+      double rv[4][4], cv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rv[i][q] = colt[(4 * ty + i) * 4 + q];
+          cv[i][q] = colt[(4 * tx + i) * 4 + q];
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[i][c] -= rv[i][q] * cv[c][q];
     }
   }
-  if (bad && lane == 0) info[0] = kb * kNB + 1;
-  // X = L^-1: lane c owns column c; L[i][m] is broadcast from lane i
-  double x[kNB];
 #pragma unroll
-  for (int i = 0; i < kNB; ++i) {
-    double sacc = (lane == i) ? 1.0 : 0.0;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int m = 0; m < i; ++m) sacc -= bcast(a[m], i) * x[m];
-    x[i] = sacc / bcast(a[i], i);
+    for (int c = 0; c < 4; ++c) {
+      const int row = 4 * ty + i, cx = 4 * tx + c;
+      const double v = (act && cx <= row) ? a[i][c] : 0.0;
+      Ls[row * kLdD + cx] = v;
+      Akk[(size_t)row * ld + cx] = v;                        // L_kk (upper part zero)
+    }
+  __syncthreads();
+  if (bad_s && threadIdx.x == 0) info[0] = kb * kNB + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv < 2 && lane < kHalf) {                              // X11 (wave 0) and X22 (wave 1), in place
+    const int o = kHalf * wv;
+    double x[kHalf];
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) {
+      double sacc = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < i; ++m) sacc -= Ls[(o + i) * kLdD + o + m] * x[m];
+      x[i] = sacc / Ls[(o + i) * kLdD + o + i];
+    }
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) Ls[(o + i) * kLdD + o + lane] = x[i];
   }
+  __syncthreads();
+  const int r = threadIdx.x & (kHalf - 1), cg = threadIdx.x / kHalf;    // row, group of 4 columns
+  {
+    double t4[4] = {0, 0, 0, 0};                             // T = L21 X11
+#pragma unroll 8
+    for (int m = 0; m < kHalf; ++m) {
+      const double l = Ls[(kHalf + r) * kLdD + m];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t4[q] += l * Ls[m * kLdD + 4 * cg + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[r * (kHalf + 1) + 4 * cg + q] = t4[q];
+  }
+  __syncthreads();
+  {
+    double o4[4] = {0, 0, 0, 0};                             // X21 = -X22 T
+#pragma unroll 8
+    for (int m = 0; m < kHalf; ++m) {
+      const double xv = Ls[(kHalf + r) * kLdD + kHalf + m];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o4[q] += xv * T[m * (kHalf + 1) + 4 * cg + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ls[(kHalf + r) * kLdD + 4 * cg + q] = -o4[q];   // nobody reads L21 any more
+  }
+  __syncthreads();
   double *Dk = Dinv + (size_t)kb * kNB * kNB;
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) {
-    Akk[(size_t)lane * ld + c] = (c <= lane) ? a[c] : 0.0;     // row `lane` of L
-    Dk[(size_t)c * kNB + lane] = x[c];                          // X[c][lane]: column `lane`, row c
-  }
+  for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) Dk[e] = Ls[(e / kNB) * kLdD + e % kNB];
 }
 
 // Panel: A_ik <- A_ik * L_kk^-T = A_ik * Dinv_k^T for block rows i > kb.  grid.x = nb - kb - 1.
@@ -260,7 +372,7 @@ inline void dense_factor_inverse(double *A, double *W, double *Wt, double *Dinv,
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
   for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kWave), 0, s, A, ld, k, Dinv, info);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, k, Dinv, info);
     const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
     if (rest > 0) {
       hipLaunchKernelGGL(k_chol_panel, dim3(rest), dim3(kBlock), 0, s, A, ld, k, Dinv);
