@@ -387,7 +387,7 @@ int build_coarse(pl_context *c) {
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  pl::dense_factor_inverse(cs.Ac, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);
+  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
@@ -1263,10 +1263,11 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
       Ap[(size_t)i * np + i] = 1.0;
     }
   }
-  DevBuf<double> dA, dW, dWt, dD, db, dt, dy, dq;
+  DevBuf<double> dA, dL, dW, dWt, dD, db, dt, dy, dq;
   DevBuf<int> dinfo;
   PL_HIP(dA.alloc(Ap.size()));
   PL_HIP(dW.alloc(Ap.size()));
+  PL_HIP(dL.alloc(Ap.size()));
   PL_HIP(dWt.alloc(Ap.size()));
   PL_HIP(hipMemset(dWt.p, 0, Ap.size() * sizeof(double)));
   PL_HIP(dD.alloc((size_t)np * pl::kNB));
@@ -1280,7 +1281,7 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
   PL_HIP(hipMemset(dW.p, 0, Ap.size() * sizeof(double)));
   PL_HIP(hipMemset(dq.p, 0, pl::kSlots * sizeof(double)));
   PL_HIP(hipMemset(dinfo.p, 0, 2 * sizeof(int)));
-  pl::dense_factor_inverse(dA.p, dW.p, dWt.p, dD.p, np, np, dinfo.p, 0, nullptr);
+  pl::dense_factor_inverse(dA.p, dL.p, dW.p, dWt.p, dD.p, np, np, dinfo.p, 0, nullptr);
   pl::dense_apply(dW.p, dWt.p, np, np, db.p, dt.p, dy.p, dq.p, nullptr, nullptr);
   PL_HIP(hipGetLastError());
   PL_HIP(hipDeviceSynchronize());

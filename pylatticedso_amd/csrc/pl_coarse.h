@@ -42,7 +42,7 @@ struct Coarse {
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
-  double *Ac = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
+  double *Ac = nullptr, *Lf = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
@@ -56,7 +56,7 @@ struct Coarse {
   int *fix_count = nullptr;
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
-    for (void *q : {(void *)Ac, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
+    for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
                     (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count})
       if (q) (void)hipFree(q);
   }
@@ -138,6 +138,8 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   const size_t n2 = (size_t)c.ncp * c.ncp;
   if (hipMalloc((void **)&c.Ac, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.W, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.Lf, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.Lf, 0, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Wt, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;

@@ -1,6 +1,7 @@
 // Small dense SPD solver on the device for the coarse operator of the two-level preconditioner (n <= a few thousand).
 //
-// Blocked right-looking Cholesky A = L L^T (64 x 64 blocks, lower triangle of a row-major matrix), then the explicit
+// Blocked right-looking Cholesky A = L L^T (64 x 64 blocks, lower triangle of a row-major matrix; one kernel launch
+// per block column: panel solve, trailing update and the next diagonal block fused), then the explicit
 // inverse factor W = L^-1 (blocked, all block columns in one launch), so that applying A^-1 is two triangular GEMVs
 //     t = W r ,  y = W^T t ,  r.A^-1 r = t.t
 // with the same traffic as one full GEMV (W^T is stored explicitly so both are row-per-wave, coalesced).  Hand-written because vendor BLAS/LAPACK libraries loaded into a process
@@ -60,23 +61,18 @@ __device__ __forceinline__ void stage_rows_as_k_major(const double *G, int ld, d
 constexpr int kLdD = kNB + 1;    // LDS pitch of the diagonal block
 constexpr int kHalf = kNB / 2;
 
-__global__ __launch_bounds__(kBlock) void k_chol_diag(double *__restrict__ A, int ld, int kb,
-                                                     double *__restrict__ Dinv, int *__restrict__ info) {
-  __shared__ double Ls[kNB * kLdD];
-  __shared__ double T[kHalf * (kHalf + 1)];
-  __shared__ double colt[kNB * 4];
-  __shared__ double dm[16];
-  __shared__ int bad_s;
-  static_assert(kNB == 64 && kBlock == 256, "k_chol_diag is written for 64 x 64 blocks and 256 threads");
+constexpr int kDiagLds = kNB * kLdD + kHalf * (kHalf + 1) + kNB * 4 + 16 + 2;   // doubles of LDS scratch
+
+// `a` = this thread's 4 x 4 tile of the block (rows 4 ty + i, columns 4 tx + c); lds = kDiagLds doubles.
+__device__ __forceinline__ void chol_diag_body(double a[4][4], double *__restrict__ Akk, int ld, int kb,
+                                               double *__restrict__ Dinv, int *__restrict__ info, double *lds) {
+  double *Ls = lds, *T = Ls + kNB * kLdD, *colt = T + kHalf * (kHalf + 1), *dm = colt + kNB * 4;
+  int &bad_s = *reinterpret_cast<int *>(dm + 16);
+  static_assert(kNB == 64 && kBlock == 256, "chol_diag_body is written for 64 x 64 blocks and 256 threads");
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // register tile: rows 4 ty + i, columns 4 tx + c
   const bool act = ty >= tx;                                 // tiles of the lower triangle
-  double *Akk = A + ((size_t)kb * kNB) * ld + (size_t)kb * kNB;
-  double a[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[i][c] = act ? Akk[(size_t)(4 * ty + i) * ld + 4 * tx + c] : 0.0;
   if (threadIdx.x == 0) bad_s = 0;
+  __syncthreads();
   for (int jt = 0; jt < kNB / 4; ++jt) {                     // four columns (one tile column) per step
     if (tx == jt && ty == jt) {                              // diagonal tile: 4 x 4 Cholesky + inverse in registers
       double l[4][4], m[4][4];
@@ -212,40 +208,87 @@ __global__ __launch_bounds__(kBlock) void k_chol_diag(double *__restrict__ A, in
   for (int e = threadIdx.x; e < kNB * kNB; e += kBlock) Dk[e] = Ls[(e / kNB) * kLdD + e % kNB];
 }
 
-// Panel: A_ik <- A_ik * L_kk^-T = A_ik * Dinv_k^T for block rows i > kb.  grid.x = nb - kb - 1.
-__global__ __launch_bounds__(kBlock) void k_chol_panel(double *__restrict__ A, int ld, int kb,
-                                                       const double *__restrict__ Dinv) {
-  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
-  const int ib = kb + 1 + blockIdx.x;
-  double *Aik = A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB;
-  stage_rows_as_k_minor(Aik, ld, At);                                   // At[k][row] = A_ik[row][k]
-  stage_rows_as_k_minor(Dinv + (size_t)kb * kNB * kNB, kNB, Bt);        // Bt[k][col] = Dinv[col][k]  (C = A * Dinv^T)
-  __syncthreads();
+__global__ __launch_bounds__(kBlock) void k_chol_diag(double *__restrict__ A, int ld, int kb,
+                                                     double *__restrict__ Dinv, int *__restrict__ info) {
+  __shared__ double lds[kDiagLds];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double acc[4][4] = {};
-  tile_fma(At, Bt, tx, ty, acc);
+  double *Akk = A + ((size_t)kb * kNB) * ld + (size_t)kb * kNB;
+  double a[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Aik[(size_t)(4 * ty + i) * ld + 4 * tx + j] = acc[i][j];
+    for (int c = 0; c < 4; ++c) a[i][c] = ty >= tx ? Akk[(size_t)(4 * ty + i) * ld + 4 * tx + c] : 0.0;
+  chol_diag_body(a, Akk, ld, kb, Dinv, info, lds);
 }
 
-// Trailing update: A_ij -= A_ik * A_jk^T for kb < j <= i.  grid = (nb-kb-1, nb-kb-1), blocks with j > i exit.
-__global__ __launch_bounds__(kBlock) void k_chol_trail(double *__restrict__ A, int ld, int kb) {
+// One launch per block column k (a dependent chain of tiny kernels costs ~13 us per link on this GPU, whatever
+// the work): workgroup (i, j), k < j <= i <= k + bw, forms L_ik = A_ik L_kk^-T and L_jk itself, applies
+// A_ij -= L_ik L_jk^T, and - for (k+1, k+1) - goes straight on to factor and invert that diagonal block, so the
+// next link can start.  L_ik goes to the separate matrix Lf (written by workgroup (i, i)); column k of A stays
+// readable for everybody.
+__global__ __launch_bounds__(kBlock) void k_chol_step(double *__restrict__ A, double *__restrict__ Lf, int ld, int kb,
+                                                      double *__restrict__ Dinv, int *__restrict__ info) {
+  __shared__ double S[3 * kNB * kLdT];                       // 101 KB of the CU's 160 KB
+  double *X = S, *Y = S + kNB * kLdT, *D = S + 2 * kNB * kLdT;
+  static_assert(kDiagLds <= 2 * kNB * kLdT, "diagonal-block scratch must fit into X|Y");
   const int ib = kb + 1 + blockIdx.x, jb = kb + 1 + blockIdx.y;
   if (jb > ib) return;
-  __shared__ double At[kNB * kLdT], Bt[kNB * kLdT];
-  stage_rows_as_k_minor(A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB, ld, At);
-  stage_rows_as_k_minor(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, Bt);
-  __syncthreads();
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  stage_rows_as_k_minor(Dinv + (size_t)kb * kNB * kNB, kNB, D);                          // D[m][col] = Dinv_k[col][m]
+  stage_rows_as_k_minor(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, X);          // X[m][row] = A_jk[row][m]
+  __syncthreads();
+  {
+    double l[4][4] = {};
+    tile_fma(X, D, tx, ty, l);                                                           // L_jk = A_jk Dinv_k^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Y[(4 * tx + j) * kLdT + 4 * ty + i] = l[i][j];         // Y[m][row] = L_jk[row][m]
+    if (ib == jb) {
+      double *Lg = Lf + ((size_t)ib * kNB) * ld + (size_t)kb * kNB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Lg[(size_t)(4 * ty + i) * ld + 4 * tx + j] = l[i][j];
+    }
+  }
+  __syncthreads();
+  const double *Li = Y;
+  if (ib != jb) {
+    stage_rows_as_k_minor(A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB, ld, X);        // X[m][row] = A_ik[row][m]
+    __syncthreads();
+    double l[4][4] = {};
+    tile_fma(X, D, tx, ty, l);                                                           // L_ik
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) X[(4 * tx + j) * kLdT + 4 * ty + i] = l[i][j];         // X[m][row] = L_ik[row][m]
+    __syncthreads();
+    Li = X;
+  }
   double acc[4][4] = {};
-  tile_fma(At, Bt, tx, ty, acc);
+  tile_fma(Li, Y, tx, ty, acc);                                                          // L_ik L_jk^T
   double *Aij = A + ((size_t)ib * kNB) * ld + (size_t)jb * kNB;
+  double a[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] -= acc[i][j];
+    for (int j = 0; j < 4; ++j) a[i][j] = Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] - acc[i][j];
+  if (ib == kb + 1 && jb == kb + 1) {        // look-ahead: this block is final now - factor it here
+    __syncthreads();                         // X, Y are scratch from here on
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ty < tx) a[i][j] = 0.0;
+    chol_diag_body(a, Aij, ld, kb + 1, Dinv, info, X);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] = a[i][j];
 }
 
 // W = L^-1 column by column: block column k of W depends on nothing but L, so ONE launch computes all of W with
@@ -365,21 +408,19 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const double *
   if (lane == 0) y[row] = s;
 }
 
-// Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used, overwritten by L) and build W = L^-1.
+// Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used; its diagonal blocks end up holding
+// L_kk, the off-diagonal blocks of L go to Lf) and build W = L^-1.
 // bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
-inline void dense_factor_inverse(double *A, double *W, double *Wt, double *Dinv, int n, int ld, int *info, int bw,
-                                 hipStream_t s) {
+inline void dense_factor_inverse(double *A, double *Lf, double *W, double *Wt, double *Dinv, int n, int ld, int *info,
+                                 int bw, hipStream_t s) {
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
-  for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, k, Dinv, info);
+  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, 0, Dinv, info);
+  for (int k = 0; k + 1 < nb; ++k) {
     const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
-    if (rest > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(rest), dim3(kBlock), 0, s, A, ld, k, Dinv);
-      hipLaunchKernelGGL(k_chol_trail, dim3(rest, rest), dim3(kBlock), 0, s, A, ld, k);
-    }
+    hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
   }
-  hipLaunchKernelGGL(k_trtri_cols, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, A, ld, nb, bw, Dinv, W, Wt);
+  hipLaunchKernelGGL(k_trtri_cols, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
