@@ -294,16 +294,35 @@ __global__ __launch_bounds__(kBlock) void k_chol_step(double *__restrict__ A, do
 // W = L^-1 column by column: block column k of W depends on nothing but L, so ONE launch computes all of W with
 // no synchronisation between workgroups.  A workgroup owns kCw columns of block column k and walks down the block
 // rows,  W_kk = Dinv_k,  W_ik = -Dinv_i * sum_{j = max(k, i - bw)}^{i-1} L_ij W_jk   (bw = block bandwidth of L:
-// the coarse operator couples only neighbouring aggregates, so L is banded and the sums are short),
-// re-reading its own earlier W_jk slices from global memory (same workgroup: visible after the barrier).
+// the coarse operator couples only neighbouring aggregates, so L is banded and the sums are short).
+// The walk is a chain of ~bw * nb small tile products per workgroup, so it is latency that counts: the next L (or
+// Dinv) tile is fetched into registers while the current one is multiplied, and (RING) the last kRing W_jk slices
+// stay in LDS; without RING (bw too large) they are re-read from global memory (same workgroup wrote them).
 // W^T is written alongside (the second triangular GEMV wants rows).
 constexpr int kCw = 8;
+constexpr int kRing = 12;
 
+__device__ __forceinline__ void tile_fetch(const double *__restrict__ G, int ld, double regs[kNB * kNB / kBlock]) {
+#pragma unroll
+  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
+    const int e = threadIdx.x + q * kBlock;
+    regs[q] = G[(size_t)(e / kNB) * ld + e % kNB];
+  }
+}
+__device__ __forceinline__ void tile_store_k_minor(const double regs[kNB * kNB / kBlock], double *T) {
+#pragma unroll
+  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
+    const int e = threadIdx.x + q * kBlock;
+    T[(e % kNB) * kLdT + e / kNB] = regs[q];                            // T[m][row] = G[row][m]
+  }
+}
+
+template <bool RING>
 __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict__ L, int ld, int nb, int bw,
                                                        const double *__restrict__ Dinv, double *__restrict__ W,
                                                        double *__restrict__ Wt) {
   __shared__ double At[kNB * kLdT];
-  __shared__ double Ws[kNB * kCw], S[kNB * kCw];
+  __shared__ double Ws[(RING ? kRing : 1) * kNB * kCw], S[kNB * kCw];
   constexpr int kSl = kNB / kCw;
   const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCw;
   const int r = threadIdx.x & (kNB - 1), g = threadIdx.x / kNB;      // row, column pair (2g, 2g+1) of the slice
@@ -312,30 +331,38 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
     const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
     W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = v;
     Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = v;
+    if (RING) Ws[(kb % kRing) * kNB * kCw + e] = v;
   }
+  double regs[kNB * kNB / kBlock];
+  if (kb + 1 < nb) tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)max(kb, kb + 1 - bw) * kNB, ld, regs);
   for (int ib = kb + 1; ib < nb; ++ib) {
     double acc0 = 0.0, acc1 = 0.0;
     const int jlo = max(kb, ib - bw);
     for (int jb = jlo; jb < ib; ++jb) {
       __syncthreads();                                                 // previous tile consumed, earlier W rows written
-      stage_rows_as_k_minor(L + ((size_t)ib * kNB) * ld + (size_t)jb * kNB, ld, At);    // At[m][row] = L_ij[row][m]
-      for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
-        const int m = e / kCw, c = e % kCw;
-        Ws[e] = W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
-      }
+      tile_store_k_minor(regs, At);                                    // At[m][row] = L_ij[row][m]
+      if (!RING)
+        for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
+          const int m = e / kCw, c = e % kCw;
+          Ws[e] = W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
+        }
       __syncthreads();
+      if (jb + 1 < ib) tile_fetch(L + ((size_t)ib * kNB) * ld + (size_t)(jb + 1) * kNB, ld, regs);
+      else tile_fetch(Dinv + (size_t)ib * kNB * kNB, kNB, regs);
+      const double *w = Ws + (RING ? (jb % kRing) * kNB * kCw : 0);
 #pragma unroll 8
       for (int m = 0; m < kNB; ++m) {
         const double a = At[m * kLdT + r];
-        acc0 += a * Ws[m * kCw + 2 * g];
-        acc1 += a * Ws[m * kCw + 2 * g + 1];
+        acc0 += a * w[m * kCw + 2 * g];
+        acc1 += a * w[m * kCw + 2 * g + 1];
       }
     }
     __syncthreads();
     S[r * kCw + 2 * g] = acc0;
     S[r * kCw + 2 * g + 1] = acc1;
-    stage_rows_as_k_minor(Dinv + (size_t)ib * kNB * kNB, kNB, At);                      // At[m][row] = Dinv_i[row][m]
+    tile_store_k_minor(regs, At);                                      // At[m][row] = Dinv_i[row][m]
     __syncthreads();
+    if (ib + 1 < nb) tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)max(kb, ib + 1 - bw) * kNB, ld, regs);
     double o0 = 0.0, o1 = 0.0;
 #pragma unroll 8
     for (int m = 0; m < kNB; ++m) {
@@ -349,6 +376,11 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
     double *Wtki = Wt + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
     Wtki[0] = -o0;
     Wtki[ld] = -o1;
+    if (RING) {
+      double *slot = Ws + (ib % kRing) * kNB * kCw;                    // free: row ib + 1 needs slices ib+1-bw .. ib
+      slot[r * kCw + 2 * g] = -o0;
+      slot[r * kCw + 2 * g + 1] = -o1;
+    }
   }
 }
 
@@ -420,7 +452,10 @@ inline void dense_factor_inverse(double *A, double *Lf, double *W, double *Wt, d
     const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
     hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
   }
-  hipLaunchKernelGGL(k_trtri_cols, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+  if (bw + 1 <= kRing)
+    hipLaunchKernelGGL(k_trtri_cols<true>, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+  else
+    hipLaunchKernelGGL(k_trtri_cols<false>, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
