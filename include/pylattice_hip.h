@@ -166,8 +166,11 @@ int pl_algorithmic_bytes(pl_handle h, double *out3);
 
 /* Test hook for the device dense SPD solver behind the two-level preconditioner (blocked Cholesky + inverse factor):
  * solves A x = b for a host SPD matrix A[n*n] (row-major) on `device`; quad (may be NULL) gets b^T A^-1 b.
+ * fp32_factor != 0 stores the inverse factor W = L^-1 in fp32, as the preconditioner does (x is then W32^T W32 b:
+ * accurate to ~1e-6 cond(A)^(1/2), which is all a preconditioner needs); 0 keeps it in fp64.
  * Returns PL_ERR_ARG if A is not positive definite. */
-int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad);
+int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad,
+                       int32_t fp32_factor);
 
 /* ---- multi-GPU (slab partition, RCCL) ---------------------------------------------------------------- */
 /* Size of the opaque RCCL unique id the ranks must share (rank 0 fills it with pl_dist_unique_id). */

@@ -74,7 +74,7 @@ def load_library(path: str | None = None):
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
-           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
+           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
            "pl_dist_init": [V, I32, I32, V, V, V, I32, I32]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
@@ -99,14 +99,15 @@ def _check(lib, rc, allow=()):
     return rc
 
 
-def debug_spd_solve(A, b, device=0):
-    """Device dense SPD solve (test hook of the coarse solver): returns (x, b^T A^-1 b)."""
+def debug_spd_solve(A, b, device=0, fp32_factor=False):
+    """Device dense SPD solve (test hook of the coarse solver): returns (x, b^T A^-1 b).  fp32_factor stores the
+    inverse Cholesky factor in fp32, as the preconditioner does."""
     lib = load_library()
     A = np.ascontiguousarray(A, np.float64)
     b = np.ascontiguousarray(b, np.float64)
     x = np.empty_like(b)
     q = C.c_double()
-    _check(lib, lib.pl_debug_spd_solve(device, len(b), _ptr(A), _ptr(b), _ptr(x), C.byref(q)))
+    _check(lib, lib.pl_debug_spd_solve(device, len(b), _ptr(A), _ptr(b), _ptr(x), C.byref(q), int(bool(fp32_factor))))
     return x, q.value
 
 

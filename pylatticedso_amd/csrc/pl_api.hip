@@ -323,6 +323,15 @@ int finish_diag_dist(pl_context *c) {
   return PL_OK;
 }
 
+// fp32 copy of the Jacobi inverse for the multi-level PCG kernels (main stream, after the diagonal is final)
+int launch_dinv32(pl_context *c) {
+  if (!c->coarse.enabled) return PL_OK;
+  hipLaunchKernelGGL(pl::k_to_float, dim3(grid_for(c->N * 6)), dim3(pl::kBlock), 0, c->stream, c->N * 6, c->dinv.p,
+                     c->coarse.dinv32);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
   pl::Coarse &cs = c->coarse;
   if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
@@ -414,7 +423,7 @@ int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
 int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   pl::Coarse &cs = c->coarse;
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, c->dinv.p,
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, cs.dinv32,
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt);
   if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
@@ -426,7 +435,7 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cur + pl::S_RDR * pl::kSlots, c->stream);
   hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                     c->tile.tile_start.p, c->r.p, c->dinv.p, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
+                     c->tile.tile_start.p, c->r.p, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
                      cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, cur, nxt,
                      c->hist.p, hist_slot, cs.rc, cs.ncp);
   PL_HIP(hipGetLastError());
@@ -612,6 +621,63 @@ bool valid(pl_handle h) { return h != nullptr; }
 // ==========================================================================================================
 // C ABI
 // ==========================================================================================================
+namespace {
+template <typename WT>
+int debug_spd_solve_t(int device, int32_t n, const double *A, const double *b, double *x, double *quad) {
+  if (n <= 0 || !A || !b || !x) return fail(PL_ERR_ARG, "pl_debug_spd_solve: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PL_ERR_NODEVICE, "no HIP device visible");
+  PL_HIP(hipSetDevice(device));
+  const int np = (n + pl::kNB - 1) / pl::kNB * pl::kNB;
+  std::vector<double> Ap((size_t)np * np, 0.0), bp(np, 0.0);
+  for (int i = 0; i < np; ++i) {
+    if (i < n) {
+      std::memcpy(&Ap[(size_t)i * np], A + (size_t)i * n, n * sizeof(double));
+      bp[i] = b[i];
+    } else {
+      Ap[(size_t)i * np + i] = 1.0;
+    }
+  }
+  DevBuf<double> dA, dL, dD, db, dt, dy, dq;
+  DevBuf<WT> dW, dWt;
+  DevBuf<int> dinfo;
+  PL_HIP(dA.alloc(Ap.size()));
+  PL_HIP(dW.alloc(Ap.size()));
+  PL_HIP(dL.alloc(Ap.size()));
+  PL_HIP(dWt.alloc(Ap.size()));
+  PL_HIP(hipMemset(dWt.p, 0, Ap.size() * sizeof(WT)));
+  PL_HIP(dD.alloc((size_t)np * pl::kNB));
+  PL_HIP(db.alloc(np));
+  PL_HIP(dt.alloc(np));
+  PL_HIP(dy.alloc(np));
+  PL_HIP(dq.alloc(pl::kSlots));
+  PL_HIP(dinfo.alloc(2));
+  PL_HIP(hipMemcpy(dA.p, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(db.p, bp.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemset(dW.p, 0, Ap.size() * sizeof(WT)));
+  PL_HIP(hipMemset(dq.p, 0, pl::kSlots * sizeof(double)));
+  PL_HIP(hipMemset(dinfo.p, 0, 2 * sizeof(int)));
+  pl::dense_factor_inverse(dA.p, dL.p, dW.p, dWt.p, dD.p, np, np, dinfo.p, 0, nullptr);
+  pl::dense_apply(dW.p, dWt.p, np, np, db.p, dt.p, dy.p, dq.p, nullptr, nullptr);
+  PL_HIP(hipGetLastError());
+  PL_HIP(hipDeviceSynchronize());
+  int info[2];
+  PL_HIP(hipMemcpy(info, dinfo.p, sizeof(info), hipMemcpyDeviceToHost));
+  if (info[0] != 0) return fail(PL_ERR_ARG, "pl_debug_spd_solve: matrix is not positive definite");
+  std::vector<double> y(np), q(pl::kSlots);
+  PL_HIP(hipMemcpy(y.data(), dy.p, np * sizeof(double), hipMemcpyDeviceToHost));
+  PL_HIP(hipMemcpy(q.data(), dq.p, pl::kSlots * sizeof(double), hipMemcpyDeviceToHost));
+  std::memcpy(x, y.data(), n * sizeof(double));
+  if (quad) {
+    *quad = 0.0;
+    for (double v : q) *quad += v;
+  }
+  return PL_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------
+}  // namespace
+
 extern "C" {
 
 const char *pl_last_error(void) { return g_err.c_str(); }
@@ -887,6 +953,8 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     if (rc) return rc;
     rc = build_coarse(h);
     if (rc) return rc;
+    rc = launch_dinv32(h);
+    if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
     if (h->bsr_with_bc) h->have_bsr = false;   // an explicit matrix built with the old mask is stale
   }
@@ -959,6 +1027,8 @@ int pl_assemble(pl_handle h) {
   rc = build_coarse(h);
   if (rc) return rc;
   PL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  rc = launch_dinv32(h);
+  if (rc) return rc;
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
   finish_palette(h);
@@ -1248,58 +1318,12 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   return PL_OK;
 }
 
-int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad) {
-  if (n <= 0 || !A || !b || !x) return fail(PL_ERR_ARG, "pl_debug_spd_solve: bad argument");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PL_ERR_NODEVICE, "no HIP device visible");
-  PL_HIP(hipSetDevice(device));
-  const int np = (n + pl::kNB - 1) / pl::kNB * pl::kNB;
-  std::vector<double> Ap((size_t)np * np, 0.0), bp(np, 0.0);
-  for (int i = 0; i < np; ++i) {
-    if (i < n) {
-      std::memcpy(&Ap[(size_t)i * np], A + (size_t)i * n, n * sizeof(double));
-      bp[i] = b[i];
-    } else {
-      Ap[(size_t)i * np + i] = 1.0;
-    }
-  }
-  DevBuf<double> dA, dL, dW, dWt, dD, db, dt, dy, dq;
-  DevBuf<int> dinfo;
-  PL_HIP(dA.alloc(Ap.size()));
-  PL_HIP(dW.alloc(Ap.size()));
-  PL_HIP(dL.alloc(Ap.size()));
-  PL_HIP(dWt.alloc(Ap.size()));
-  PL_HIP(hipMemset(dWt.p, 0, Ap.size() * sizeof(double)));
-  PL_HIP(dD.alloc((size_t)np * pl::kNB));
-  PL_HIP(db.alloc(np));
-  PL_HIP(dt.alloc(np));
-  PL_HIP(dy.alloc(np));
-  PL_HIP(dq.alloc(pl::kSlots));
-  PL_HIP(dinfo.alloc(2));
-  PL_HIP(hipMemcpy(dA.p, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIP(hipMemcpy(db.p, bp.data(), np * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIP(hipMemset(dW.p, 0, Ap.size() * sizeof(double)));
-  PL_HIP(hipMemset(dq.p, 0, pl::kSlots * sizeof(double)));
-  PL_HIP(hipMemset(dinfo.p, 0, 2 * sizeof(int)));
-  pl::dense_factor_inverse(dA.p, dL.p, dW.p, dWt.p, dD.p, np, np, dinfo.p, 0, nullptr);
-  pl::dense_apply(dW.p, dWt.p, np, np, db.p, dt.p, dy.p, dq.p, nullptr, nullptr);
-  PL_HIP(hipGetLastError());
-  PL_HIP(hipDeviceSynchronize());
-  int info[2];
-  PL_HIP(hipMemcpy(info, dinfo.p, sizeof(info), hipMemcpyDeviceToHost));
-  if (info[0] != 0) return fail(PL_ERR_ARG, "pl_debug_spd_solve: matrix is not positive definite");
-  std::vector<double> y(np), q(pl::kSlots);
-  PL_HIP(hipMemcpy(y.data(), dy.p, np * sizeof(double), hipMemcpyDeviceToHost));
-  PL_HIP(hipMemcpy(q.data(), dq.p, pl::kSlots * sizeof(double), hipMemcpyDeviceToHost));
-  std::memcpy(x, y.data(), n * sizeof(double));
-  if (quad) {
-    *quad = 0.0;
-    for (double v : q) *quad += v;
-  }
-  return PL_OK;
+int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, double *x, double *quad,
+                       int32_t fp32_factor) {
+  return fp32_factor ? debug_spd_solve_t<float>(device, n, A, b, x, quad)
+                     : debug_spd_solve_t<double>(device, n, A, b, x, quad);
 }
 
-// ---- multi-GPU ------------------------------------------------------------------------------------------
 int pl_dist_unique_id_bytes(void) { return pl::dist_unique_id_bytes(); }
 int pl_dist_unique_id(void *id_out) {
   if (!id_out) return fail(PL_ERR_ARG, "pl_dist_unique_id: null argument");

@@ -42,7 +42,8 @@ struct Coarse {
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
-  double *Ac = nullptr, *Lf = nullptr, *W = nullptr, *Wt = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
+  float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
+  double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
@@ -50,6 +51,11 @@ struct Coarse {
   TBuf<uint8_t> tile_on;          // 0: the tile holds nodes shared with another rank (multi-GPU) -> no tile-level term
   std::vector<int32_t> h_tile_start;
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
+  // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
+  // symmetric operator in every iteration, so rounding the Jacobi weights is free).  The node positions stay fp64:
+  // the coarse modes must be EXACTLY rigid per aggregate - their energy is tiny next to ||K||, and a 1e-7 error in
+  // the lever arms costs iterations (measured)
+  float *dinv32 = nullptr;
   // struts inside one aggregate that touch a Dirichlet dof (the only non-crossing struts with coarse energy);
   // rebuilt on the device after every pl_set_bc
   TBuf<int32_t> fix_list;
@@ -57,7 +63,7 @@ struct Coarse {
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count})
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32})
       if (q) (void)hipFree(q);
   }
 };
@@ -93,7 +99,10 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     agg_of_tile[t] = a;
     for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) agg_of_node[i] = a;
   }
-  (void)xyz_dev_order;
+  {
+    (void)xyz_dev_order;
+    if (hipMalloc((void **)&c.dinv32, (size_t)N * 6 * sizeof(float)) != hipSuccess) return 2;
+  }
   std::vector<int32_t> ptr(n_agg + 1, 0), idx(T);
   for (int64_t t = 0; t < T; ++t) ptr[agg_of_tile[t] + 1]++;
   for (int a = 0; a < n_agg; ++a) ptr[a + 1] += ptr[a];
@@ -137,10 +146,10 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   c.ncp = (c.nc + kNB - 1) / kNB * kNB;
   const size_t n2 = (size_t)c.ncp * c.ncp;
   if (hipMalloc((void **)&c.Ac, n2 * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.W, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.W, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Lf, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.Lf, 0, n2 * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.Wt, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.Wt, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;   // + rr, r.D^-1 r
@@ -160,8 +169,8 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     if (hipMemset(c.yt, 0, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
   }
   if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;
-  if (hipMemset(c.W, 0, n2 * sizeof(double)) != hipSuccess) return 2;
-  if (hipMemset(c.Wt, 0, n2 * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.W, 0, n2 * sizeof(float)) != hipSuccess) return 2;
+  if (hipMemset(c.Wt, 0, n2 * sizeof(float)) != hipSuccess) return 2;
   c.enabled = true;
   return 0;
 }
@@ -490,13 +499,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
 // ---------------------------------------------------------------------------------------------------------------
 // x += alpha p ; r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
 // ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__restrict__ x, float *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) y[i] = (float)x[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
                                                             const double *__restrict__ xyz,
                                                             const double *__restrict__ p,
                                                             const double *__restrict__ Ap,
-                                                            const double *__restrict__ dinv,
+                                                            const float *__restrict__ dinv32,
                                                             const double *__restrict__ w /* may be null */,
                                                             double *__restrict__ x, double *__restrict__ r,
                                                             double *__restrict__ scal, double *__restrict__ rc,
@@ -519,12 +533,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     double pv[6], av[6], dv[6], xv[6], rv[6];
     const double2 *p2 = reinterpret_cast<const double2 *>(p + 6 * (int64_t)i);
     const double2 *a2 = reinterpret_cast<const double2 *>(Ap + 6 * (int64_t)i);
-    const double2 *d2 = reinterpret_cast<const double2 *>(dinv + 6 * (int64_t)i);
+    const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
     double2 *x2 = reinterpret_cast<double2 *>(x + 6 * (int64_t)i);
     double2 *r2 = reinterpret_cast<double2 *>(r + 6 * (int64_t)i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double2 pp = p2[k], aa = a2[k], dd = d2[k], xx = x2[k], rr = r2[k];
+      const double2 pp = p2[k], aa = a2[k], xx = x2[k], rr = r2[k];
+      const float2 dd = d2[k];
       pv[2 * k] = pp.x; pv[2 * k + 1] = pp.y; av[2 * k] = aa.x; av[2 * k + 1] = aa.y;
       dv[2 * k] = dd.x; dv[2 * k + 1] = dd.y; xv[2 * k] = xx.x; xv[2 * k + 1] = xx.y;
       rv[2 * k] = rr.x; rv[2 * k + 1] = rr.y;
@@ -613,7 +628,7 @@ __global__ void k_coarse_scalars_from_rc(const double *__restrict__ rc, int ncp,
 // One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
 __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *__restrict__ tile_start,
                                                                  const double *__restrict__ r,
-                                                                 const double *__restrict__ dinv,
+                                                                 const float *__restrict__ dinv32,
                                                                  const double *__restrict__ xyz,
                                                                  const int32_t *__restrict__ agg_of_tile,
                                                                  const double *__restrict__ cen,
@@ -656,11 +671,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     const unsigned fb = fixedbits[i];
     const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);
-    const double2 *d2 = reinterpret_cast<const double2 *>(dinv + 6 * i);
+    const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);
     double2 *p2 = reinterpret_cast<double2 *>(p + 6 * i);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const double2 rr = r2[q], dd = d2[q];
+      const double2 rr = r2[q];
+      const float2 dd = d2[q];
       double2 pp = p2[q];
       const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
       const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);

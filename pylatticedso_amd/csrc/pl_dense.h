@@ -317,10 +317,10 @@ __device__ __forceinline__ void tile_store_k_minor(const double regs[kNB * kNB /
   }
 }
 
-template <bool RING>
+template <typename WT, bool RING>
 __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict__ L, int ld, int nb, int bw,
-                                                       const double *__restrict__ Dinv, double *__restrict__ W,
-                                                       double *__restrict__ Wt) {
+                                                       const double *__restrict__ Dinv, WT *__restrict__ W,
+                                                       WT *__restrict__ Wt) {
   __shared__ double At[kNB * kLdT];
   __shared__ double Ws[(RING ? kRing : 1) * kNB * kCw], S[kNB * kCw];
   constexpr int kSl = kNB / kCw;
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
   for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
     const int row = e / kCw, c = e % kCw;
     const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
-    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = v;
-    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = v;
+    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
+    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
     if (RING) Ws[(kb % kRing) * kNB * kCw + e] = v;
   }
   double regs[kNB * kNB / kBlock];
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
       if (!RING)
         for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
           const int m = e / kCw, c = e % kCw;
-          Ws[e] = W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
+          Ws[e] = (double)W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
         }
       __syncthreads();
       if (jb + 1 < ib) tile_fetch(L + ((size_t)ib * kNB) * ld + (size_t)(jb + 1) * kNB, ld, regs);
@@ -370,12 +370,12 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
       o0 += a * S[m * kCw + 2 * g];
       o1 += a * S[m * kCw + 2 * g + 1];
     }
-    double *Wik = W + ((size_t)ib * kNB + r) * ld + (size_t)kb * kNB + c0 + 2 * g;
-    Wik[0] = -o0;
-    Wik[1] = -o1;
-    double *Wtki = Wt + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
-    Wtki[0] = -o0;
-    Wtki[ld] = -o1;
+    WT *Wik = W + ((size_t)ib * kNB + r) * ld + (size_t)kb * kNB + c0 + 2 * g;
+    Wik[0] = (WT)(-o0);
+    Wik[1] = (WT)(-o1);
+    WT *Wtki = Wt + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
+    Wtki[0] = (WT)(-o0);
+    Wtki[ld] = (WT)(-o1);
     if (RING) {
       double *slot = Ws + (ib % kRing) * kNB * kCw;                    // free: row ib + 1 needs slices ib+1-bw .. ib
       slot[r * kCw + 2 * g] = -o0;
@@ -384,8 +384,39 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
   }
 }
 
+// Row dot products of the triangular GEMVs: columns [c_lo, c_hi) of one row, strided over the wave.
+// W may be stored in fp32 (the preconditioner is then W32^T W32 - still exactly symmetric positive definite - and
+// the GEMVs move half the bytes); the vectors and the accumulation stay fp64.
+__device__ __forceinline__ double row_dot(const double *__restrict__ Wr, const double *__restrict__ v, int c_lo,
+                                          int c_hi, int lane) {
+  const double2 *W2 = reinterpret_cast<const double2 *>(Wr);
+  const double2 *v2 = reinterpret_cast<const double2 *>(v);
+  double s = 0.0;
+#pragma unroll 4
+  for (int j = (c_lo >> 1) + lane; j < ((c_hi + 1) >> 1); j += 64) {
+    const double2 w = W2[j], x = v2[j];
+    s += w.x * x.x + w.y * x.y;
+  }
+  return s;
+}
+__device__ __forceinline__ double row_dot(const float *__restrict__ Wr, const double *__restrict__ v, int c_lo,
+                                          int c_hi, int lane) {
+  const float4 *W4 = reinterpret_cast<const float4 *>(Wr);
+  const double2 *v2 = reinterpret_cast<const double2 *>(v);
+  double s = 0.0;
+#pragma unroll 4
+  for (int j = (c_lo >> 2) + lane; j < ((c_hi + 3) >> 2); j += 64) {
+    const float4 w = W4[j];
+    const double2 x0 = v2[2 * j], x1 = v2[2 * j + 1];
+    s += (double)w.x * x0.x + (double)w.y * x0.y + (double)w.z * x1.x + (double)w.w * x1.y;
+  }
+  return s;
+}
+
 // t = W r (W lower triangular, one wave per row); dot_out[slot] += t.t
-__global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const double *__restrict__ W, int ld,
+// (rows are zero right of the diagonal and n is a multiple of 64, so reading a few columns past it is harmless)
+template <typename WT>
+__global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const WT *__restrict__ W, int ld,
                                                      const double *__restrict__ r, double *__restrict__ t,
                                                      double *__restrict__ dot_out, const double *__restrict__ add0) {
   __shared__ double red[kBlock / kWave];
@@ -393,16 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const double *__rest
   const int row = blockIdx.x * (kBlock / kWave) + wv;
   double sq = 0.0;
   if (row < n) {
-    const double2 *Wr = reinterpret_cast<const double2 *>(W + (size_t)row * ld);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
-    double s = 0.0;
-    const int n2 = (row >> 1) + 1;                 // double2 pairs covering columns 0..row (W is zero above the diagonal)
-#pragma unroll 4
-    for (int j = lane; j < n2; j += 64) {
-      const double2 w = Wr[j], v = r2[j];
-      s += w.x * v.x + w.y * v.y;
-    }
-    s = wave_sum(s);
+    const double s = wave_sum(row_dot(W + (size_t)row * ld, r, 0, row + 1, lane));
     if (lane == 0) {
       t[row] = s;
       sq = s * s;
@@ -422,28 +444,21 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const double *__rest
 }
 
 // y = W^T t with the explicitly stored transpose (upper triangular rows, one wave per row).
-__global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const double *__restrict__ Wt, int ld,
+template <typename WT>
+__global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const WT *__restrict__ Wt, int ld,
                                                            const double *__restrict__ t, double *__restrict__ y) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row = blockIdx.x * (kBlock / kWave) + wv;
   if (row >= n) return;
-  const double2 *Wr = reinterpret_cast<const double2 *>(Wt + (size_t)row * ld);
-  const double2 *t2 = reinterpret_cast<const double2 *>(t);
-  double s = 0.0;
-  const int n2 = n >> 1;                           // n is a multiple of 64; W^T is zero below the diagonal
-#pragma unroll 4
-  for (int j = (row >> 1) + lane; j < n2; j += 64) {
-    const double2 w = Wr[j], v = t2[j];
-    s += w.x * v.x + w.y * v.y;
-  }
-  s = wave_sum(s);
+  const double s = wave_sum(row_dot(Wt + (size_t)row * ld, t, row, n, lane));   // zero left of the diagonal
   if (lane == 0) y[row] = s;
 }
 
 // Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used; its diagonal blocks end up holding
 // L_kk, the off-diagonal blocks of L go to Lf) and build W = L^-1.
 // bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
-inline void dense_factor_inverse(double *A, double *Lf, double *W, double *Wt, double *Dinv, int n, int ld, int *info,
+template <typename WT>
+inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *Dinv, int n, int ld, int *info,
                                  int bw, hipStream_t s) {
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
@@ -453,16 +468,17 @@ inline void dense_factor_inverse(double *A, double *Lf, double *W, double *Wt, d
     hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
   }
   if (bw + 1 <= kRing)
-    hipLaunchKernelGGL(k_trtri_cols<true>, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+    hipLaunchKernelGGL((k_trtri_cols<WT, true>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
   else
-    hipLaunchKernelGGL(k_trtri_cols<false>, dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+    hipLaunchKernelGGL((k_trtri_cols<WT, false>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
-inline void dense_apply(const double *W, const double *Wt, int n, int ld, const double *r, double *t, double *y,
+template <typename WT>
+inline void dense_apply(const WT *W, const WT *Wt, int n, int ld, const double *r, double *t, double *y,
                         double *dot_out, const double *add0, hipStream_t s) {
-  hipLaunchKernelGGL(k_tri_gemv, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, W, ld, r, t, dot_out, add0);
-  hipLaunchKernelGGL(k_tri_gemv_upper, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, Wt, ld, t, y);
+  hipLaunchKernelGGL(k_tri_gemv<WT>, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, W, ld, r, t, dot_out, add0);
+  hipLaunchKernelGGL(k_tri_gemv_upper<WT>, dim3((n + 3) / 4), dim3(kBlock), 0, s, n, Wt, ld, t, y);
 }
 
 }  // namespace pl
