@@ -20,7 +20,7 @@ ap.add_argument("--geom", default="Octet")
 ap.add_argument("--radius", type=float, default=0.03)
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--precond", type=int, default=2)
+ap.add_argument("--precond", type=int, default=3)
 ap.add_argument("--palette", type=int, default=1)
 args = ap.parse_args()
 n = args.cells
