@@ -124,6 +124,7 @@ struct TilePlan {
   TBuf<int64_t> foreign_ptr;    // [n_tiles+1]
   TBuf<int32_t> foreign_idx;    // strut ids
   int64_t n_foreign = 0;
+  int max_nodes = 0;            // largest tile: sizes the LDS accumulator of the K*p launch
 };
 
 // Computes the strut permutation (bperm[new] = old) that numbers struts by home tile and, inside a tile, so that
@@ -175,8 +176,12 @@ inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int
     prev_home = h;
     if (ta != tb) foreign_idx[fill[std::max(ta, tb)]++] = (int32_t)b;
   }
-  for (int64_t t = 0; t < T; ++t)
+  int max_nodes = 0;
+  for (int64_t t = 0; t < T; ++t) {
     if (tile_start[t + 1] - tile_start[t] > kTileMaxNodes) return 2;
+    max_nodes = std::max(max_nodes, (int)(tile_start[t + 1] - tile_start[t]));
+  }
+  plan.max_nodes = max_nodes;
   plan.n_tiles = T;
   plan.n_foreign = foreign_ptr[T];
   if (plan.tile_start.upload(tile_start) != hipSuccess) return 3;
@@ -187,30 +192,33 @@ inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int
   return 0;
 }
 
-__device__ __forceinline__ void lds_add6(double *dst, V3 f, V3 m) {
-  unsafeAtomicAdd(dst + 0, f.x);
-  unsafeAtomicAdd(dst + 1, f.y);
-  unsafeAtomicAdd(dst + 2, f.z);
-  unsafeAtomicAdd(dst + 3, m.x);
-  unsafeAtomicAdd(dst + 4, m.y);
-  unsafeAtomicAdd(dst + 5, m.z);
+// The LDS accumulator is component-major, ys[k][node] (pitch = stride): the 64 lanes of a ds_add_f64 then spread over
+// node mod 16 bank pairs instead of the (6 node + k) mod 16 = 8 classes of a node-major layout - half the bank
+// conflicts on the instruction this kernel issues most (12 per strut visit).
+__device__ __forceinline__ void lds_add6(double *dst, int stride, V3 f, V3 m) {
+  unsafeAtomicAdd(dst, f.x);
+  unsafeAtomicAdd(dst + stride, f.y);
+  unsafeAtomicAdd(dst + 2 * stride, f.z);
+  unsafeAtomicAdd(dst + 3 * stride, m.x);
+  unsafeAtomicAdd(dst + 4 * stride, m.y);
+  unsafeAtomicAdd(dst + 5 * stride, m.z);
 }
 
 // PAL: the record comes from the palette table through a 2-byte id (pl_palette.h) instead of rec[b].
 template <bool PAL>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
-                                           const double *__restrict__ x, double *ys) {
+                                           const double *__restrict__ x, double *ys, int stride) {
   const int2 c = conn2[b];
   const Record r = PAL ? load_record(rec, pal[b]) : load_record(rec, b);
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
   tip_force(r, uA, tA, uB, tB, F, M);
-  if (c.y >= n0 && c.y < n1) lds_add6(ys + 6 * (c.y - n0), F, M);
+  if (c.y >= n0 && c.y < n1) lds_add6(ys + (c.y - n0), stride, F, M);
   if (c.x >= n0 && c.x < n1) {
     const V3 d = {r.dx, r.dy, r.dz};
-    lds_add6(ys + 6 * (c.x - n0), (-1.0) * F, (-1.0) * M - cross(d, F));
+    lds_add6(ys + (c.x - n0), stride, (-1.0) * F, (-1.0) * M - cross(d, F));
   }
 }
 
@@ -223,30 +231,29 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
                                                       const uint16_t *__restrict__ pal,
                                                       const uint8_t *__restrict__ fixedbits,
                                                       const double *__restrict__ x, double *__restrict__ y,
-                                                      double *__restrict__ dot_out) {
-  __shared__ double ys[kTileMaxNodes * 6];
+                                                      double *__restrict__ dot_out, int stride) {
+  extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
   __shared__ double red[kBlock / kWave];
   const unsigned t = xcd_block(blockIdx.x, gridDim.x);
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int nn = n1 - n0;
-  for (int i = threadIdx.x; i < nn * 6; i += kBlock) ys[i] = 0.0;
+  for (int i = threadIdx.x; i < 6 * stride; i += kBlock) ys[i] = 0.0;
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
-#pragma unroll 2
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys);
+#pragma unroll 4
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
-#pragma unroll 2
+#pragma unroll 4
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock)
-    tile_strut<PAL>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys);
+    tile_strut<PAL>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys, stride);
   __syncthreads();
   double acc = 0.0;
-  const double2 *ys2 = reinterpret_cast<const double2 *>(ys);
   double2 *y2 = reinterpret_cast<double2 *>(y) + 3 * (int64_t)n0;
   const double2 *x2 = reinterpret_cast<const double2 *>(x) + 3 * (int64_t)n0;
   for (int i = threadIdx.x; i < nn * 3; i += kBlock) {
-    double2 v = ys2[i];
+    const int node = i / 3, part = i - 3 * node;
+    double2 v = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
     if (MASK) {
-      const int node = i / 3, part = i - 3 * node;
       const unsigned fb = fixedbits[n0 + node] >> (2 * part);
       if (fb & 1u) v.x = 0.0;
       if (fb & 2u) v.y = 0.0;
@@ -267,10 +274,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
                              const uint8_t *fixedbits, const double *x, double *y, double *dot_dev, hipStream_t s) {
   const dim3 g((unsigned)plan.n_tiles), blk(kBlock);
+  const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
+  const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
 #define PL_T(M, D, P)                                                                                          \
-  hipLaunchKernelGGL((k_spmv_tile<M, D, P>), g, blk, 0, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
-                     plan.foreign_idx.p, conn2, rec, pal, fixedbits, x, y, dot_dev)
+  hipLaunchKernelGGL((k_spmv_tile<M, D, P>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
+                     plan.foreign_idx.p, conn2, rec, pal, fixedbits, x, y, dot_dev, stride)
   if (pal) {
     if (fixedbits && dot_dev) PL_T(true, true, true);
     else if (fixedbits) PL_T(true, false, true);
