@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
+    ap.add_argument("--tile-nodes", type=int, default=0, help="target nodes per K*p tile (0 = library default)")
     ap.add_argument("--precond", type=int, default=3,
                     help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
@@ -138,7 +139,8 @@ def main():
         dist.all_reduce(nn)
         grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette)
+                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
+                           tile_nodes=args.tile_nodes)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world
