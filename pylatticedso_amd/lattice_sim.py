@@ -59,7 +59,9 @@ def material_properties(name):
 
 class LatticeSim:
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0,
-                 enable_domain_decomposition_solver: bool = False):
+                 enable_domain_decomposition_solver: bool = False, data_roots=None):
+        """Same arguments as the reference (lattice_sim.py:44-47) plus ``data_roots``: extra directories in which the
+        reduced-basis files of the surrogate DDM modes are looked up (the reference finds them in its own checkout)."""
         if mesh_trimmer is not None:
             raise NotImplementedError("mesh_trimmer is outside the accelerated path")
         self._verbose = verbose
@@ -98,7 +100,24 @@ class LatticeSim:
         self.cell_schur_index = None       # (C,) index into self.schur_complements
         self.schur_complements = None      # (n_S, 6 n_b, 6 n_b)
         self.iteration = 0
-        if self.domain_decomposition_solver and self.type_schur_complement_computation == "exact":
+        self.enable_gradient_computing = False     # lattice_sim.py:114: also keep dS/dr per unique cell
+        self.schur_gradients = None                # [n_S] lists of dS/dr_j
+        self.schur_surrogate = None
+        if self.domain_decomposition_solver:
+            if self.type_schur_complement_computation == "FE2":
+                raise NotImplementedError("FE2 Schur complements are outside the accelerated path")
+            if self.type_schur_complement_computation != "exact":
+                # reduced basis + surrogate for its coefficients (lattice_sim.py:126-135); the .npz is looked up
+                # like the reference does, below <root>/data/outputs/schur_complement/reduced_basis/
+                from .schur_surrogate import SchurSurrogate
+                self.schur_surrogate = SchurSurrogate.load(self.geom_types, self.precision_greedy,
+                                                           self.type_schur_complement_computation,
+                                                           search_dirs=data_roots)
+                self.reduce_basis_dict = {"basis_reduced_ortho": self.schur_surrogate.basis,
+                                          "alpha_ortho": self.schur_surrogate.alpha_train.T,
+                                          "list_elements": self.schur_surrogate.points}
+                self.alpha_coefficients_greedy = self.schur_surrogate.alpha_train
+                self.shape_schur_complement = self.schur_surrogate.n
             self.calculate_schur_complement_cells()
 
     # ------------------------------------------------------------------------------------------------
@@ -361,9 +380,8 @@ class LatticeSim:
         """Exact Schur complement of one representative cell per (geometry, radii) group (lattice_sim.py:846-919),
         condensed on the device (pl_schur) from that cell's own struts with their penalised segments."""
         from ._capi import HipLattice
-        if self.type_schur_complement_computation not in ("exact",):
-            raise NotImplementedError("surrogate Schur complements (reduced basis / RBF) need the reference's data "
-                                      "files; install matrices with set_schur_complements()")
+        if self.type_schur_complement_computation != "exact":
+            return self._surrogate_schur_complement_cells()
         lat, pen = self.lattice, self.penalized
         cb = self.cell_boundary_nodes()
         keys = [tuple(np.round(lat.cell_radii[c], 8)) for c in range(lat.n_cells)]
@@ -382,6 +400,36 @@ class LatticeSim:
                 groups[k] = len(mats) - 1
             idx[c] = groups[k]
         self.set_schur_complements(np.stack(mats), idx)
+
+    def _surrogate_schur_complement_cells(self):
+        """Surrogate branch of lattice_sim.py:846-919: one batched evaluation S(r) = B alpha(r) for the distinct
+        radius sets of the lattice (keys rounded to 8 decimals like the reference's cache), plus dS/dr when
+        enable_gradient_computing is set."""
+        if self.schur_surrogate is None:
+            raise NotImplementedError("Not implemented schur complement computation method.")
+        lat = self.lattice
+        keys = [tuple(round(float(r), 8) for r in lat.cell_radii[c]) for c in range(lat.n_cells)]
+        uniq = {}
+        idx = np.zeros(lat.n_cells, np.int32)
+        for c, k in enumerate(keys):
+            idx[c] = uniq.setdefault(k, len(uniq))
+        radii_batch = [list(k) for k in uniq]
+        S = self.schur_surrogate.schur_batch(radii_batch)
+        self.schur_gradients = ([self.schur_surrogate.schur_gradients(r) for r in radii_batch]
+                                if self.enable_gradient_computing else None)
+        if self._verbose > 1:
+            print("Number of unique Schur complements computed:", len(radii_batch))
+        self.set_schur_complements(S, idx)
+
+    def get_schur_complement_from_reduced_basis_batch(self, geometric_params_list):
+        """lattice_sim.py:919-977."""
+        if self.schur_surrogate is None:
+            raise NotImplementedError("Not implemented schur complement computation method.")
+        return self.schur_surrogate.schur_batch(geometric_params_list)
+
+    def get_schur_complement_from_reduced_basis(self, geometric_params):
+        """lattice_sim.py:979-1018."""
+        return self.get_schur_complement_from_reduced_basis_batch([list(geometric_params)])[0]
 
     def ddm_model(self):
         from ._capi import HipLattice

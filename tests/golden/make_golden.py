@@ -277,8 +277,37 @@ def gen_ddm():
         print(f"ddm_{name}: n={len(xsol)} info={info} its={L.iteration}")
 
 
+def gen_surrogate():
+    """Surrogate Schur complements of the reference (lattice_sim.py:755-813,919-977,1020-1082) evaluated through its
+    own reduced basis of the BCC cell: S(r) for the three surrogate kinds (inside, at and outside the training range),
+    the analytic RBF gradients and the finite-difference gradients of the linear surrogate.  The reduced basis itself
+    (a data file of the reference, 55 KB) is stored next to the expected outputs."""
+    import shutil
+    rb = os.path.join(REF, "data", "outputs", "schur_complement", "reduced_basis", "reduced_basis_BCC_tol_1e-6.npz")
+    shutil.copyfile(rb, os.path.join(OUT, "reduced_basis_BCC_tol_1e-6.npz"))
+    radii = np.array([[0.012], [0.03], [0.05], [0.0777], [0.1], [0.115], [0.004]])
+    res = {"radii": radii}
+    for kind in ["nearest_neighbor", "linear", "RBF"]:
+        ddm = {"enable_preconditioner": False, "max_iterations": 100,
+               "schur_complement_computation": {"type": kind, "precision_greedy": 1e-6}}
+        preset = _preset(["BCC"], [0.05], (2, 1, 1), bcs=CANTILEVER, periodicity=False, ddm=ddm)
+        L = _make(preset, enable_domain_decomposition_solver=True)
+        res[f"S_{kind}"] = np.asarray(_quiet(L.get_schur_complement_from_reduced_basis_batch, radii.tolist()))
+        if kind == "RBF":
+            if L.radial_basis_function is None:
+                L._define_radial_basis_functions()
+            res["dS_RBF"] = np.array([_quiet(L._compute_schur_gradients_RBF, [float(r[0])])[0] for r in radii[:5]])
+        if kind == "linear":
+            res["dS_linear_fd"] = np.array([_quiet(L._compute_schur_gradients, L.cells[0], [float(r[0])])[0]
+                                            for r in radii[:5]])
+    np.savez_compressed(os.path.join(OUT, "surrogate_bcc.npz"), **res)
+    print("surrogate_bcc:", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "surrogate"]
+    if "surrogate" in which:
+        gen_surrogate()
     if "lattice" in which:
         gen_lattice_states()
     if "schur" in which:

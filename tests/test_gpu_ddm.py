@@ -19,9 +19,11 @@ def _rel(a, b):
 def test_solve_ddm_reproduces_reference_solution(golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"ddm_{name}.npz"))
     preset = json.loads(str(g["preset_json"]))
-    L = LatticeSim(preset, enable_domain_decomposition_solver=True)
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
     assert not L.is_penalized                       # surrogate mode: penalisation lives in the Schur matrices
-    L.set_schur_complements(g["schur"])             # the matrix the reference evaluated from its RBF surrogate
+    # the preset asks for the RBF surrogate: the host mirror evaluates it from the reference's reduced basis and must
+    # arrive at the matrix the reference evaluated
+    assert L.schur_complements.shape == (1, 48, 48) and _rel(L.schur_complements[0], g["schur"]) < 1e-10
     xsol, info, idx, b = L.solve_DDM()
     assert info == int(g["info"]) == 0
     assert len(xsol) == len(g["xsol"]) and len(b) == len(g["b"])
@@ -62,3 +64,29 @@ def test_ddm_exact_schur_agrees_with_fem(golden_dir):
     # the representative-cell Schur (first cell: corner cell with un-penalised outer joints) is reused for interior
     # cells, exactly as the reference does - hence a modelling difference, not a solver error
     assert info == 0 and _rel(xs_d, xs_f) < 5e-2
+
+
+@pytest.mark.parametrize("kind", ["nearest_neighbor", "linear", "RBF"])
+def test_ddm_surrogate_kinds_on_a_graded_lattice(golden_dir, kind):
+    """Graded radii (one Schur matrix per distinct radius, evaluated in one batch) with every surrogate kind: the
+    device DDM solution satisfies the assembled condensed system built on the host from the same cell matrices."""
+    preset = json.loads(str(np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))["preset_json"]))
+    preset["simulation_parameters"]["DDM"]["schur_complement_computation"] = {"type": kind, "precision_greedy": 1e-6}
+    preset["gradient"] = {"radii": {"rule": "linear", "direction_x": True, "direction_y": False, "direction_z": False,
+                                    "parameter_x": 0.25, "parameter_y": 0.0, "parameter_z": 0.0}}
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    n_distinct = len({tuple(np.round(r, 8)) for r in L.lattice.cell_radii})
+    assert n_distinct > 1 and L.schur_complements.shape == (n_distinct, 48, 48)
+    xsol, info, idx, b = L.solve_DDM()
+    assert info == 0
+    # host assembly of sum_c B_c^T S_c B_c on the free dofs, in the ordering of xsol
+    cb = L.cell_boundary_nodes()
+    nb = L.max_index_boundary + 1
+    K = np.zeros((6 * nb, 6 * nb))
+    for c in range(L.lattice.n_cells):
+        dofs = (6 * L.index_boundary[cb[c]][:, None] + np.arange(6)).ravel()
+        K[np.ix_(dofs, dofs)] += L.schur_complements[L.cell_schur_index[c]]
+    order = np.concatenate([6 * L.index_boundary[n] + np.flatnonzero(~L.fixed_DOF[n]) for n in L._boundary_visit_order])
+    Kff = K[np.ix_(order, order)]
+    assert np.linalg.norm(Kff @ xsol - b) <= 1.05e-6 * np.linalg.norm(b)
+    assert _rel(xsol, np.linalg.solve(Kff, b)) < 1e-3

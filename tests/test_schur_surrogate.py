@@ -1,0 +1,104 @@
+"""Surrogate Schur complements (reduced basis + nearest / linear / thin-plate-spline coefficients) against outputs of
+the running reference (tests/golden/surrogate_bcc.npz, made by make_golden.py::gen_surrogate from the reference's own
+reduced basis of the BCC cell) and against the reference's dolfinx dataset."""
+import os
+
+import numpy as np
+import pytest
+
+from pylatticedso_amd.schur_surrogate import SchurSurrogate, ThinPlateSpline, reduced_basis_file_name
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "surrogate_bcc.npz"))
+
+
+def _surrogate(kind):
+    return SchurSurrogate.load(["BCC"], 1e-6, kind, search_dirs=[GOLD])
+
+
+def test_file_name_rule():
+    # greedy_algorithm.py:214-233
+    assert reduced_basis_file_name(["BCC"], 1e-6) == "reduced_basis_BCC_tol_1e-6.npz"
+    assert reduced_basis_file_name(["BCC", "Hybrid4"], 1e-3) == "reduced_basis_BCC_Hybrid4_tol_1e-3.npz"
+    with pytest.raises(FileNotFoundError):
+        SchurSurrogate.load(["Octet"], 1e-6, "RBF", search_dirs=[GOLD])
+    with pytest.raises(NotImplementedError):
+        SchurSurrogate.load(["BCC"], 1e-6, "kriging", search_dirs=[GOLD])
+
+
+@pytest.mark.parametrize("kind", ["nearest_neighbor", "linear", "RBF"])
+def test_surrogate_matrices_match_reference(gold, kind):
+    """S(r) inside the training range, at training points, and outside it (clamped / extrapolated) - same matrices as
+    LatticeSim.get_schur_complement_from_reduced_basis_batch of the reference."""
+    S = _surrogate(kind).schur_batch(gold["radii"])
+    ref = gold[f"S_{kind}"]
+    assert S.shape == ref.shape == (len(gold["radii"]), 48, 48)
+    for q in range(len(ref)):
+        assert _rel(S[q], ref[q]) < 1e-10, (kind, float(gold["radii"][q, 0]))
+
+
+def test_rbf_gradient_matches_reference_and_finite_differences(gold):
+    sur = _surrogate("RBF")
+    for q, r in enumerate(gold["radii"][:5, 0]):
+        dS = sur.schur_gradients([r])[0]
+        assert _rel(dS, gold["dS_RBF"][q]) < 1e-9
+        h = 1e-6
+        Sp, Sm = sur.schur_batch([[r + h], [r - h]])
+        assert _rel(dS, (Sp - Sm) / (2 * h)) < 1e-5
+
+
+def test_linear_gradient_is_the_reference_finite_difference(gold):
+    sur = _surrogate("linear")
+    for q, r in enumerate(gold["radii"][:5, 0]):
+        got, ref = sur.schur_gradients([r])[0], gold["dS_linear_fd"][q]
+        # a difference quotient over 2e-6 of numbers ~1e3: compare on the matrix scale
+        assert np.abs(got - ref).max() < 1e-6 * np.abs(ref).max()
+
+
+def test_rbf_surrogate_reproduces_the_dolfinx_dataset(golden_dir=GOLD):
+    """The reduced basis was built (tolerance 1e-6) from the reference's dolfinx Schur complements: the surrogate must
+    give those matrices back at the training radii - and these are the matrices oracle/ and pl_schur reproduce."""
+    d = np.load(os.path.join(GOLD, "schur_BCC.npz"))
+    sur = _surrogate("RBF")
+    S = sur.schur_batch(d["radius_values"])
+    for q in range(len(S)):
+        assert _rel(S[q], d["schur_matrices"][q]) < 1e-5
+
+
+def test_thin_plate_spline_nd():
+    """2-parameter cells (hybrid geometries): interpolation property, exactness on affine data, analytic gradient."""
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0.01, 0.1, (14, 2))
+    Y = np.c_[np.sin(20 * X[:, 0]) + X[:, 1] ** 2, 3.0 + 2.0 * X[:, 0] - 5.0 * X[:, 1]]
+    tps = ThinPlateSpline(X, Y)
+    assert np.abs(tps.evaluate(X) - Y).max() < 1e-9
+    q = rng.uniform(0.01, 0.1, (5, 2))
+    assert np.abs(tps.evaluate(q)[:, 1] - (3.0 + 2.0 * q[:, 0] - 5.0 * q[:, 1])).max() < 1e-9
+    g = tps.gradient(q)
+    h = 1e-7
+    for d in range(2):
+        e = np.zeros(2)
+        e[d] = h
+        fd = (tps.evaluate(q + e) - tps.evaluate(q - e)) / (2 * h)
+        assert np.abs(g[:, d, :] - fd).max() < 1e-4 * max(1.0, np.abs(fd).max())
+
+
+def test_linear_surrogate_nd_falls_back_to_nearest_outside_the_hull():
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(0.0, 1.0, (12, 2))
+    alpha = np.c_[1.0 + pts[:, 0] + 2.0 * pts[:, 1], pts[:, 0] - pts[:, 1]]       # affine -> exact inside the hull
+    sur = SchurSurrogate(np.eye(4)[:, :2], alpha.T, pts, "linear")
+    inside = pts[:3].mean(axis=0, keepdims=True)
+    a = sur.alphas(inside)
+    assert np.allclose(a, [[1.0 + inside[0, 0] + 2.0 * inside[0, 1], inside[0, 0] - inside[0, 1]]])
+    far = np.array([[5.0, 5.0]])
+    i0 = np.argmin(np.linalg.norm(pts - far, axis=1))
+    assert np.allclose(sur.alphas(far), alpha[i0][None])
