@@ -10,6 +10,10 @@ the per-strut contraction ``λ_eᵀ (∂K_e/∂r) u_e`` (``pl_sens``) — the re
 ``u_cellᵀ (∂S/∂r) u_cell`` with a finite-differenced cell Schur complement (``lattice_sim.py:1020-1054``), at fixed
 penalised-segment geometry (convention (i) of SURVEY.md appendix A).
 
+``simulation_type: "DDM"`` (what most of the reference's optimisation presets use): the equilibrium goes through
+``solve_DDM`` on the device with surrogate cell Schur complements, the gradient contracts their spline derivatives
+(``schur_surrogate.py``) cell by cell.
+
 Out of scope here: the kriging relative-density surrogate; the density constraint uses the
 direct strut-volume formula instead.
 """
@@ -26,12 +30,13 @@ _DOF = {"X": 0, "Y": 1, "Z": 2, "RX": 3, "RY": 4, "RZ": 5}
 
 
 class LatticeOpti(LatticeSim):
-    def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0, convergence_plotting: bool = False):
+    def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0, convergence_plotting: bool = False,
+                 data_roots=None):
         info = open_lattice_parameters(name_file).get("optimization_informations", {})
-        if info.get("simulation_type", None) == "DDM":
-            raise NotImplementedError("simulation_type 'DDM' (Schur surrogate) is a 'next' row of SURVEY.md §8f; "
-                                      "use 'FEM'")
-        super().__init__(name_file, mesh_trimmer, verbose, False)
+        # lattice_opti.py:96-103: simulation_type "DDM" runs every equilibrium through solve_DDM with the cell Schur
+        # complements (exact or surrogate) and contracts their derivatives dS/dr for the gradient
+        self._ddm_mode = info.get("simulation_type", None) == "DDM"
+        super().__init__(name_file, mesh_trimmer, verbose, self._ddm_mode, data_roots=data_roots)
         self.solution = None
         self.actual_objective = None
         self.denorm_objective = None
@@ -187,6 +192,14 @@ class LatticeOpti(LatticeSim):
         self.cell_radii = self._cell_radii_from_parameters(theta)
         lat = self.lattice
         lat.beam_radius = (self.cell_radii[self._beam_cell, lat.beam_type] * self._cell_gfac[self._beam_cell])
+        if self._ddm_mode:
+            # reset_cell_with_new_radii (lattice_sim.py:1421-1497): new cell radii -> new Schur complements (+ dS/dr)
+            lat.cell_radii = self.cell_radii * self._cell_gfac[:, None]
+            if self.type_schur_complement_computation == "exact":
+                raise NotImplementedError("DDM optimisation with exact Schur complements: use a surrogate type "
+                                          "(the reference finite-differences dolfinx solves here) or 'FEM'")
+            self._surrogate_schur_complement_cells()
+            return
         dev = self.device_model()
         dev.update_radii(lat.beam_radius)
 
@@ -200,7 +213,12 @@ class LatticeOpti(LatticeSim):
 
     def _simulate_lattice_equilibrium(self):
         self._initialize_simulation_parameters()
-        _, self._model = solve_FEM_FenicsX(self)
+        if self._ddm_mode:
+            xsol, info, _, _ = self.solve_DDM()
+            if xsol is None:
+                raise RuntimeError("solve_DDM: zero right-hand side")
+        else:
+            _, self._model = solve_FEM_FenicsX(self)
         self._sim_is_current = True
 
     def compute_compliance(self):
@@ -267,14 +285,56 @@ class LatticeOpti(LatticeSim):
             return dev.sens(u, self._adjoint(q))
         raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
 
+    def _ddm_adjoint(self, q_nodes):
+        """S lam = q on the free cell-boundary dofs (lattice_opti.py:1560-1650: CG to 1e-10, no preconditioner)."""
+        dev = self.ddm_model()
+        bn = self._boundary_nodes_by_index()
+        fixed = self.fixed_DOF[bn]
+        dev.set_bc(fixed, None, np.where(fixed, 0.0, q_nodes[bn]))
+        lam_b, _ = dev.solve(rtol=1e-10, max_iter=max(2000, self.number_iteration_max or 0))
+        lam = np.zeros_like(self.displacement_vector)
+        lam[bn] = lam_b
+        return lam
+
+    def _ddm_cell_sensitivities(self):
+        """(C, G):  lam_c^T (dS_c/dr_j) u_c per cell and geometry, u_c / lam_c on the cell's boundary nodes in
+        Cell.define_node_order_to_simulate order (lattice_opti.py:746-760, 866-890)."""
+        if self.schur_gradients is None:
+            raise RuntimeError("Schur complement gradients are not available: enable_gradient_computing must be true")
+        cb = self.cell_boundary_nodes()
+        U = self.displacement_vector[cb].reshape(len(cb), -1)
+        if self.objective_type == "compliance":
+            Lam = U
+        elif self.objective_type == "displacement":
+            nodes = self._objective_nodes(self.objectif_data["Surface"])
+            q = np.zeros_like(self.displacement_vector)
+            cnt = len(nodes) * len(self.objectif_data["DOF"])
+            sign = -1.0 if self.objective_function == "max" else 1.0
+            for d in self.objectif_data["DOF"]:
+                q[nodes, _DOF[d]] += sign / cnt
+            Lam = self._ddm_adjoint(q)[cb].reshape(len(cb), -1)
+        else:
+            raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
+        G = len(self.geom_types)
+        s_cell = np.zeros((len(cb), G))
+        for k, dS_list in enumerate(self.schur_gradients):            # one batched contraction per distinct matrix
+            sel = np.flatnonzero(self.cell_schur_index == k)
+            for j, dS in enumerate(dS_list):
+                s_cell[sel, j] = np.einsum("ci,ij,cj->c", Lam[sel], dS, U[sel])
+        return s_cell * self._cell_gfac[:, None]
+
     def calculate_gradient(self):
         """Raw gradient in the reference's sign convention (lattice_opti.py:735-907): sum over the struts driven by
-        each parameter of λ_eᵀ (∂K_e/∂r) u_e, chained through Cell.get_radius and the parameterisation."""
-        s = self.strut_sensitivities()
+        each parameter of λ_eᵀ (∂K_e/∂r) u_e (FEM) or over the cells of λ_cᵀ (∂S_c/∂r) u_c (DDM), chained through
+        Cell.get_radius and the parameterisation."""
         lat = self.lattice
         G = len(self.geom_types)
-        s_cell = np.zeros((lat.n_cells, G))
-        np.add.at(s_cell, (self._beam_cell, lat.beam_type), s * self._cell_gfac[self._beam_cell])
+        if self._ddm_mode:
+            s_cell = self._ddm_cell_sensitivities()
+        else:
+            s = self.strut_sensitivities()
+            s_cell = np.zeros((lat.n_cells, G))
+            np.add.at(s_cell, (self._beam_cell, lat.beam_type), s * self._cell_gfac[self._beam_cell])
         t = self.optimization_parameters["type"]
         if t == "unit_cell":
             return s_cell.ravel()
@@ -348,7 +408,8 @@ class LatticeOpti(LatticeSim):
                 self.initial_parameters = [init] * self.number_parameters
 
     def callback_function(self, r):
-        self.iteration += 1
+        self._opt_iteration = getattr(self, "_opt_iteration", 0) + 1   # (solve_DDM keeps its CG count in .iteration)
+        self.iteration = self._opt_iteration
         self._history["iteration"].append(self.iteration)
         self._history["objective_norm"].append(self.actual_objective)
         self._history["objective"].append(self.denorm_objective)
@@ -360,6 +421,7 @@ class LatticeOpti(LatticeSim):
         from scipy.optimize import NonlinearConstraint, minimize
         self.initial_value_objective = None
         self.iteration = 0
+        self._opt_iteration = 0
         self._sim_is_current = False
         self.actual_optimization_parameters = []
         self._initialize_optimization_solver()

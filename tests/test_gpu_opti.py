@@ -89,3 +89,54 @@ def test_short_slsqp_run_decreases_compliance():
     sol = L.optimize_lattice()
     assert L._history["objective"][-1] < L._history["objective"][0] * 1.0001 or sol.fun < 1.0
     assert L.relative_density() <= 0.05 * 1.02        # SLSQP iterates are only feasible to its own tolerance
+
+
+# ---- simulation_type "DDM": equilibrium through solve_DDM with RBF-surrogate cell Schur complements, gradient from the
+# ---- spline derivative dS/dr (what most optimisation presets of the reference use) ---------------------------------
+def _ddm_preset(**opt):
+    p = _preset(simulation_type="DDM", **opt)
+    p["simulation_parameters"]["DDM"] = {"enable_preconditioner": False, "max_iterations": 5000,
+                                         "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}
+    return p
+
+
+def _ddm_opti(golden_dir, **opt):
+    L = LatticeOpti(_ddm_preset(**opt), data_roots=[golden_dir])
+    # CG of the DDM solve stops at 1e-6 (the reference's fixed tolerance): too loose for a finite-difference check of
+    # the objective, so tighten it for the test by solving in a wrapper
+    solve = L.ddm_model
+
+    def tight():
+        dev = solve()
+        orig = dev.solve
+        dev.solve = lambda rtol=1e-6, **k: orig(rtol=min(rtol, 1e-11), **k)
+        return dev
+    L.ddm_model = tight
+    return L
+
+
+def test_ddm_gradient_unit_cell_compliance(golden_dir):
+    L = _ddm_opti(golden_dir, optimization_parameters={"type": "unit_cell"})
+    assert L.domain_decomposition_solver and L.number_parameters == 12
+    rng = np.random.default_rng(1)
+    theta = list(0.3 + 0.4 * rng.random(12))
+    g = _fd_check(L, theta, [0, 7, 11], h=1e-4, tol=5e-5)
+    assert np.all(g < 0)
+
+
+def test_ddm_gradient_constant_displacement(golden_dir):
+    L = _ddm_opti(golden_dir, objective_type="displacement", objective_function="min",
+                  objective_data={"Surface": ["Xmax"], "DOF": ["Z"]})
+    _fd_check(L, [0.5], [0], h=1e-4, tol=5e-5)
+
+
+def test_ddm_and_fem_objectives_agree(golden_dir):
+    """Same preset through both simulation types: the RBF surrogate reproduces dolfinx Schur complements of ONE
+    periodic cell, the FEM path penalises the real joints of the finite lattice - the compliances agree to a few
+    per cent, and both gradients say the same thing."""
+    Ld = _ddm_opti(golden_dir)
+    Lf = LatticeOpti(_preset())
+    Ld.objective([0.45]), Lf.objective([0.45])
+    assert abs(Ld.denorm_objective - Lf.denorm_objective) < 0.08 * abs(Lf.denorm_objective)
+    gd, gf = Ld.gradient([0.45]), Lf.gradient([0.45])
+    assert gd[0] < 0 and gf[0] < 0 and abs(gd[0] - gf[0]) < 0.15 * abs(gf[0])
