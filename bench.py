@@ -83,8 +83,9 @@ def main():
     ap.add_argument("--reorder", type=int, default=1)
     ap.add_argument("--lpn", type=int, default=0, help="lanes per node of the gather kernel (0 = library default)")
     ap.add_argument("--tile-nodes", type=int, default=0, help="target nodes per K*p tile (0 = library default)")
-    ap.add_argument("--precond", type=int, default=3,
-                    help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level")
+    ap.add_argument("--precond", type=int, default=0,
+                    help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level, 4 = 3 + "
+                         "rank-local dense level; 0 = 3")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
@@ -109,6 +110,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    if args.precond == 0:
+        # 4 (rank-local dense level) was measured on the single-GPU rehearsal of the multi-rank path: +11 us per
+        # iteration and +2 ms per assembly for 12-14 % fewer iterations when the global level is coarse - a wash, so 3
+        args.precond = 3
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -214,7 +219,9 @@ def main():
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"],
                    "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
-                                      3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)"}[args.precond],
+                                      3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)",
+                                      4: "multi-level (Jacobi + tile blocks + rank-local dense level + all-reduced "
+                                         "dense rigid-body coarse space)"}[args.precond],
                    "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond >= 2 else "")
                            + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},

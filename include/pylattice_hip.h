@@ -60,7 +60,10 @@ typedef struct {
                             (sliced ELL), 3 = per-strut with LDS tile accumulators */
   int32_t precond;       /* 1 = Jacobi (diagonal); 2 = two-level: Jacobi + rigid-body-mode coarse space on brick
                             aggregates, dense solve; 3 = 2 plus a tile level (rigid-body modes of every K*p tile,
-                            6 x 6 block solves).  2 and 3 need reorder = 1 */
+                            6 x 6 block solves); 4 = 3 plus a rank-LOCAL dense level (aggregates of this handle only,
+                            nodes shared with other ranks left out, no communication) under the global one: for
+                            multi-GPU runs, where the all-reduced global level has to coarsen with the rank count.
+                            2, 3 and 4 need reorder = 1 */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
   int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
   int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
@@ -68,7 +71,8 @@ typedef struct {
   int32_t coarse_max_dofs; /* precond = 2/3: upper bound on 6 * (number of aggregates) (0 -> 3072) */
   int32_t palette;       /* 1: K*p (LDS-tile kernel) reads 2-byte palette ids instead of 64-byte records when the lattice
                             has <= ~30 000 distinct records (compared on 40 mantissa bits, i.e. to 1e-12) */
-  int32_t reserved[3];
+  int32_t local_max_dofs;  /* precond = 4: upper bound on 6 * (aggregates of the rank-local level) (0 -> 3072) */
+  int32_t reserved[2];
   double alpha_max;      /* > 0: clamp the CG step like conjugate_gradient_solver.py:79 (DDM solves use 100) */
   /* Multi-GPU only: bounding box and node count of the WHOLE lattice, so that every rank cuts the same brick /
    * aggregate grid (all zero -> derived from this handle's own nodes). */

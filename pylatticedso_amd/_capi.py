@@ -33,7 +33,7 @@ class PlOpts(C.Structure):
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
                 ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("palette", C.c_int32),
-                ("reserved", C.c_int32 * 3),
+                ("local_max_dofs", C.c_int32), ("reserved", C.c_int32 * 2),
                 ("alpha_max", C.c_double), ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3),
                 ("grid_nodes", C.c_int64)]
 
@@ -116,7 +116,7 @@ class HipLattice:
 
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
                  pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=32, lanes_per_node=0, tile_nodes=0, precond=1,
-                 coarse_max_dofs=0, grid=None, palette=0):
+                 coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -134,6 +134,7 @@ class HipLattice:
         opts.lanes_per_node = lanes_per_node
         opts.tile_nodes = tile_nodes
         opts.precond, opts.coarse_max_dofs = precond, coarse_max_dofs
+        opts.local_max_dofs = local_max_dofs
         opts.palette = palette
         if grid is not None:                       # (lo[3], hi[3], n_nodes) of the whole lattice (multi-GPU)
             lo, hi, nn = grid

@@ -121,6 +121,11 @@ struct pl_context {
   // two-level preconditioner (rigid-body coarse space)
   pl::Coarse coarse;
   int coarse_info = 0;
+  // precond = 4: a second, rank-LOCAL dense level (aggregates of this handle only, nodes shared with other ranks left
+  // out, never communicated) under the global one, so that the aggregate size can stay fixed under weak scaling
+  // while the all-reduced global level coarsens
+  pl::Coarse coarseL;
+  DevBuf<uint8_t> sharedbits, maskL;
   // multi-GPU
   pl::Dist dist;
 
@@ -344,8 +349,7 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
 }
 
 // A_c = Z^T P K P Z on the device, then its Cholesky factor and W = L^-1 (pl_dense.h).
-int build_coarse(pl_context *c) {
-  pl::Coarse &cs = c->coarse;
+int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool reduce) {
   cs.ready = false;
   if (!cs.enabled || !c->have_bc) return PL_OK;
   const int n = cs.ncp;
@@ -358,7 +362,7 @@ int build_coarse(pl_context *c) {
     for (int pass = 0; pass < 2; ++pass) {
       PL_HIP(hipMemsetAsync(cs.fix_count, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(pl::k_list_fixed_struts, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B,
-                         c->conn.p, cs.agg_of_node.p, c->fixedbits.p, pass ? keys.p : (int64_t *)nullptr, cs.fix_count);
+                         c->conn.p, cs.agg_of_node.p, mask, pass ? keys.p : (int64_t *)nullptr, cs.fix_count);
       if (pass == 0) {
         PL_HIP(hipMemcpyAsync(&cnt, cs.fix_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         PL_HIP(hipStreamSynchronize(c->stream));
@@ -385,13 +389,13 @@ int build_coarse(pl_context *c) {
   }
   if (cs.n_fix > 0)
     hipLaunchKernelGGL(pl::k_coarse_assemble, dim3(grid_for(cs.n_fix)), dim3(pl::kBlock), 0, c->stream, cs.n_fix,
-                       cs.fix_list.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, c->fixedbits.p, n,
+                       cs.fix_list.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, mask, n,
                        cs.Ac);
   if (cs.n_cross > 0)
     hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
                        cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
-                       c->fixedbits.p, n, cs.Ac);
-  if (c->dist.active) {   // every rank holds the contribution of ITS struts; all ranks then factor the same matrix
+                       mask, n, cs.Ac);
+  if (reduce && c->dist.active) {   // every rank holds the contribution of ITS struts; all ranks then factor the same matrix
     if (pl::dist_sum_scalars(c->dist, cs.Ac, n * n, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
   }
@@ -401,9 +405,24 @@ int build_coarse(pl_context *c) {
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
   PL_HIP(hipStreamSynchronize(c->stream));
-  c->coarse_info = info[0];
+  if (&cs == &c->coarse) c->coarse_info = info[0];
   cs.ready = (info[0] == 0);   // not SPD -> fall back to Jacobi
   return PL_OK;
+}
+
+__global__ void k_local_mask(int64_t N, const uint8_t *__restrict__ fixedbits, const uint8_t *__restrict__ shared,
+                             uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) mask[i] = (uint8_t)(fixedbits[i] | (shared[i] ? 0x3f : 0));
+}
+
+int build_coarse(pl_context *c) {
+  int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true);
+  if (rc || !c->coarseL.enabled) return rc;
+  // the local level sees shared nodes as constrained: its modes live on this rank's own nodes only
+  hipLaunchKernelGGL(k_local_mask, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->fixedbits.p,
+                     c->sharedbits.p, c->maskL.p);
+  return build_coarse_level(c, c->coarseL, c->maskL.p, false);
 }
 
 int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
@@ -421,11 +440,14 @@ int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
 
 // Everything of a two-level PCG iteration after K*p: update + restriction, coarse solve, new direction.
 int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
-  pl::Coarse &cs = c->coarse;
+  pl::Coarse &cs = c->coarse, &cl = c->coarseL;
+  const bool useL = cl.ready;
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, cs.dinv32,
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
-                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt);
+                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
+                     (const uint8_t *)c->sharedbits.p, cl.rc);
   if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
     hipLaunchKernelGGL(pl::k_coarse_tail_from_scal, dim3(1), dim3(pl::kWave), 0, c->stream, cur, cs.rc, cs.ncp);
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2, c->stream))
@@ -434,10 +456,15 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cur + pl::S_RDR * pl::kSlots, c->stream);
+  if (useL)   // rank-local level: no communication; r.z += r_L . A_L^-1 r_L
+    pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cur + pl::S_RZ_NEW * pl::kSlots,
+                    (const double *)nullptr, c->stream);
   hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, c->r.p, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
                      cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, cur, nxt,
-                     c->hist.p, hist_slot, cs.rc, cs.ncp);
+                     c->hist.p, hist_slot, cs.rc, cs.ncp,
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
+                     (const uint8_t *)c->sharedbits.p, cl.rc, cl.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -811,12 +838,21 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
-  if (o->precond == 2 || o->precond == 3) {
-    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3 (multi-level) needs reorder = 1"));
-    c->coarse.tile_level = (o->precond == 3);
+  if (o->precond >= 2 && o->precond <= 4) {
+    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
+    c->coarse.tile_level = (o->precond >= 3);
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
+    if (o->precond == 4) {
+      const int maxL = o->local_max_dofs > 0 ? o->local_max_dofs : 3072;
+      rc = pl::coarse_setup(c->coarseL, tile_start, tile_brick, grid, xyz.data(), N, maxL, conn, true);
+      if (rc) return bail(fail(PL_ERR_HIP, "pl_create: local coarse-space setup failed (" + std::to_string(rc) + ")"));
+      c->coarseL.tile_level = false;
+      PL_HIPC(c->sharedbits.alloc(N));
+      PL_HIPC(c->maskL.alloc(N));
+      PL_HIPC(hipMemset(c->sharedbits.p, 0, N));
+    }
   }
 
   const size_t n6 = (size_t)N * 6;
@@ -941,6 +977,7 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
   h->have_bc = true;
   h->coarse.n_fix = -1;
+  h->coarseL.n_fix = -1;
   if (h->assembled && h->opkind == 1) {
     pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
     PL_HIP(hipStreamSynchronize(h->stream));
@@ -1352,6 +1389,12 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
       on[t] = 0;
     }
     if (h->coarse.tile_on.upload(on) != hipSuccess) return fail(PL_ERR_HIP, "pl_dist_init: tile flags upload failed");
+  }
+  if (h->coarseL.enabled) {
+    std::vector<uint8_t> sh((size_t)h->N, 0);
+    for (int i = 0; i < n_shared; ++i) sh[loc[i]] = 1;
+    PL_HIP(hipMemcpy(h->sharedbits.p, sh.data(), sh.size(), hipMemcpyHostToDevice));
+    h->coarseL.n_fix = -1;
   }
   h->assembled = false;
   return PL_OK;

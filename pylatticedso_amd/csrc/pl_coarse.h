@@ -71,31 +71,43 @@ struct Coarse {
 // Host: aggregates = groups of g^3 bricks of the (global) brick grid; ids are dense over the whole aggregate grid so
 // that all ranks of a multi-GPU run agree (aggregates without nodes give identity rows).  The reference point of an
 // aggregate's rigid-body modes is the geometric centre of its cell (any point spans the same space).
+// local = true (the rank-local level of a multi-GPU run, see pl_api.hip): only the aggregates that hold tiles of THIS
+// handle are numbered, and g is chosen from their count - the level is never summed over ranks.
 inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const std::vector<int64_t> &tile_brick,
                         const BrickGrid &grid, const double *xyz_dev_order, int64_t N, int max_dofs,
-                        const std::vector<int32_t> &conn) {
+                        const std::vector<int32_t> &conn, bool local = false) {
   const int64_t T = (int64_t)tile_start.size() - 1;
   const int64_t *nbrick = grid.nb;
+  auto grid_agg = [&](int64_t key, int g, const int64_t *na) {
+    const int64_t b2 = key % nbrick[2], b1 = (key / nbrick[2]) % nbrick[1], b0 = key / (nbrick[2] * nbrick[1]);
+    return ((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g);
+  };
   int g = 2;
   int64_t na[3];
+  std::vector<int64_t> used;                       // local: sorted grid ids of the aggregates that hold tiles
   for (;; ++g) {
     for (int k = 0; k < 3; ++k) na[k] = (nbrick[k] + g - 1) / g;
-    if (na[0] * na[1] * na[2] * 6 <= max_dofs || g > 64) break;
+    int64_t count = na[0] * na[1] * na[2];
+    if (local) {
+      used.clear();
+      for (int64_t t = 0; t < T; ++t) used.push_back(grid_agg(tile_brick[t], g, na));
+      std::sort(used.begin(), used.end());
+      used.erase(std::unique(used.begin(), used.end()), used.end());
+      count = (int64_t)used.size();
+    }
+    if (count * 6 <= max_dofs || g > 64) break;
   }
-  const int n_agg = (int)(na[0] * na[1] * na[2]);
+  const int n_agg = local ? (int)used.size() : (int)(na[0] * na[1] * na[2]);
   std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
   std::vector<double> cen((size_t)n_agg * 3, 0.0);
-  for (int64_t a0 = 0; a0 < na[0]; ++a0)
-    for (int64_t a1 = 0; a1 < na[1]; ++a1)
-      for (int64_t a2 = 0; a2 < na[2]; ++a2) {
-        const int64_t a = (a0 * na[1] + a1) * na[2] + a2;
-        const int64_t ai[3] = {a0, a1, a2};
-        for (int k = 0; k < 3; ++k) cen[3 * a + k] = grid.lo[k] + (ai[k] + 0.5) * g * grid.side;
-      }
+  for (int a = 0; a < n_agg; ++a) {
+    const int64_t ga = local ? used[a] : a;
+    const int64_t ai[3] = {ga / (na[1] * na[2]), (ga / na[2]) % na[1], ga % na[2]};
+    for (int k = 0; k < 3; ++k) cen[3 * a + k] = grid.lo[k] + (ai[k] + 0.5) * g * grid.side;
+  }
   for (int64_t t = 0; t < T; ++t) {
-    const int64_t key = tile_brick[t];
-    const int64_t b2 = key % nbrick[2], b1 = (key / nbrick[2]) % nbrick[1], b0 = key / (nbrick[2] * nbrick[1]);
-    const int a = (int)(((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g));
+    const int64_t ga = grid_agg(tile_brick[t], g, na);
+    const int a = local ? (int)(std::lower_bound(used.begin(), used.end(), ga) - used.begin()) : (int)ga;
     agg_of_tile[t] = a;
     for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) agg_of_node[i] = a;
   }
@@ -122,7 +134,11 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     }
     // struts join neighbouring bricks only, so aggregates couple to their 26 neighbours: a bound from the aggregate
     // grid alone (identical on every rank of a multi-GPU run, whatever struts this rank holds)
-    const int64_t max_diff = std::min<int64_t>(n_agg - 1, na[1] * na[2] + na[2] + 1);
+    int64_t max_diff = std::min<int64_t>(n_agg - 1, na[1] * na[2] + na[2] + 1);
+    if (local) {                   // compact numbering: take the band from the couplings that exist
+      max_diff = 0;
+      for (const auto &pr : cross) max_diff = std::max<int64_t>(max_diff, std::abs(pr.first / n_agg - pr.first % n_agg));
+    }
     c.bw_blocks = (int)((6 * (max_diff + 1) + kNB - 1) / kNB + 1);
     for (const auto &pr : cross)   // struts longer than an aggregate (degenerate tiling): no band assumption
       if (std::abs(pr.first / n_agg - pr.first % n_agg) > max_diff) c.bw_blocks = 0;
@@ -515,8 +531,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             double *__restrict__ x, double *__restrict__ r,
                                                             double *__restrict__ scal, double *__restrict__ rc,
                                                             const double *__restrict__ Bt_inv /* may be null */,
-                                                            double *__restrict__ yt) {
-  __shared__ double red[8][kBlock / kWave];
+                                                            double *__restrict__ yt,
+                                                            const int32_t *__restrict__ aggL_of_tile /* may be null */,
+                                                            const double *__restrict__ cenL,
+                                                            const uint8_t *__restrict__ shared /* may be null */,
+                                                            double *__restrict__ rcL) {
+  __shared__ double red[14][kBlock / kWave];
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
   const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
@@ -529,6 +549,15 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     for (int j = 0; j < 6; ++j) bi[j] = Bt_inv[(size_t)t * 36 + 6 * threadIdx.x + j];
   }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // rank-local dense level (multi-GPU): its own aggregates / reference points, nodes shared with other ranks left out
+  const int aL = aggL_of_tile ? aggL_of_tile[t] : 0;
+  double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+  if (aggL_of_tile) {
+    l0 = cenL[3 * aL];
+    l1 = cenL[3 * aL + 1];
+    l2 = cenL[3 * aL + 2];
+  }
+  double accL[6] = {0, 0, 0, 0, 0, 0};
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
     double pv[6], av[6], dv[6], xv[6], rv[6];
     const double2 *p2 = reinterpret_cast<const double2 *>(p + 6 * (int64_t)i);
@@ -572,6 +601,15 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
     }
+    if (aggL_of_tile && !(shared && shared[i])) {
+      const double sx = xyz[3 * (int64_t)i] - l0, sy = xyz[3 * (int64_t)i + 1] - l1, sz = xyz[3 * (int64_t)i + 2] - l2;
+      accL[0] += rv[0];
+      accL[1] += rv[1];
+      accL[2] += rv[2];
+      accL[3] += rv[3] + (sy * rv[2] - sz * rv[1]);
+      accL[4] += rv[4] + (sz * rv[0] - sx * rv[2]);
+      accL[5] += rv[5] + (sx * rv[1] - sy * rv[0]);
+    }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -579,7 +617,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     const double s = wave_sum(acc[k]);
     if (lane == 0) red[k][wv] = s;
   }
+  if (aggL_of_tile) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double s = wave_sum(accL[k]);
+      if (lane == 0) red[8 + k][wv] = s;
+    }
+  }
   __syncthreads();
+  if (aggL_of_tile && threadIdx.x >= kWave && threadIdx.x < kWave + 6) {   // wave 1 publishes the local restriction
+    const int k = threadIdx.x - kWave;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBlock / kWave; ++q) s += red[8 + k][q];
+    unsafeAtomicAdd(rcL + 6 * aL + k, s);
+  }
   if (threadIdx.x < 8) {
     double s = 0.0;
 #pragma unroll
@@ -639,11 +691,18 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ scal,
                                                                  double *__restrict__ scal_next,
                                                                  double *__restrict__ hist, int k,
-                                                                 double *__restrict__ rc, int ncp) {
+                                                                 double *__restrict__ rc, int ncp,
+                                                                 const int32_t *__restrict__ aggL_of_tile /* may be null */,
+                                                                 const double *__restrict__ cenL,
+                                                                 const double *__restrict__ ycL,
+                                                                 const uint8_t *__restrict__ shared /* may be null */,
+                                                                 double *__restrict__ rcL, int ncpL) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
     for (int e = threadIdx.x; e < ncp + 2; e += kBlock) rc[e] = 0.0;
+  if (aggL_of_tile && (blockIdx.x == 2 || gridDim.x <= 2))
+    for (int e = threadIdx.x; e < ncpL + 2; e += kBlock) rcL[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
     const double rr = scalar_read(scal, S_RR);
     const int s = threadIdx.x;
@@ -666,9 +725,27 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     U0 += q[0]; U1 += q[1]; U2 += q[2]; W0 += q[3]; W1 += q[4]; W2 += q[5];
   }
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double L[6] = {0, 0, 0, 0, 0, 0}, l0 = 0.0, l1 = 0.0, l2 = 0.0;     // rank-local dense level (multi-GPU)
+  if (aggL_of_tile) {
+    const int aL = aggL_of_tile[t];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) L[q] = ycL[6 * aL + q];
+    l0 = cenL[3 * aL];
+    l1 = cenL[3 * aL + 1];
+    l2 = cenL[3 * aL + 2];
+  }
   for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
+    if (aggL_of_tile && !(shared && shared[i])) {
+      const double sx = xyz[3 * i] - l0, sy = xyz[3 * i + 1] - l1, sz = xyz[3 * i + 2] - l2;
+      zc[0] += L[0] + (L[4] * sz - L[5] * sy);
+      zc[1] += L[1] + (L[5] * sx - L[3] * sz);
+      zc[2] += L[2] + (L[3] * sy - L[4] * sx);
+      zc[3] += L[3];
+      zc[4] += L[4];
+      zc[5] += L[5];
+    }
     const unsigned fb = fixedbits[i];
     const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);

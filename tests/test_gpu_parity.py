@@ -297,6 +297,14 @@ def test_rccl_path_with_single_rank_communicator(golden_dir):
         dev.assemble()
         u3, st3 = dev.solve(rtol=1e-11)
     assert _rel(u3, u0) < 1e-8 and st3["converged"] == 1
+    # ... and with the rank-local dense level under a coarser global one (precond = 4, what bench.py uses for N > 1):
+    # shared nodes are left out of the local level, nothing of it is communicated
+    with _device(L, precond=4, tile_nodes=32, coarse_max_dofs=100, local_max_dofs=600, grid=grid) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        u4, st4 = dev.solve(rtol=1e-11)
+    assert _rel(u4, u0) < 1e-8 and st4["converged"] == 1
     with _device(L) as ref:
         ref.assemble()
         y0 = ref.spmv(x)
@@ -389,6 +397,17 @@ def test_tile_level_reduces_iterations_octet16():
     assert all(st["converged"] == 1 for _, st in out.values())
     assert _rel(out[2][0], out[1][0]) < 1e-7 and _rel(out[3][0], out[1][0]) < 1e-7
     assert out[3][1]["iterations"] < out[2][1]["iterations"] < out[1][1]["iterations"]
+    # precond = 4: with a global level forced to be coarse (as it is on many GPUs), the rank-local dense level wins
+    # iterations back
+    res = {}
+    for pc in (3, 4):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=pc, coarse_max_dofs=100) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            res[pc] = dev.solve(rtol=1e-10, max_iter=20000)
+    assert _rel(res[4][0], out[1][0]) < 1e-7 and res[4][1]["converged"] == 1
+    assert res[4][1]["iterations"] < res[3][1]["iterations"]
 
 
 @pytest.mark.parametrize("n", [5, 64, 100, 700])
