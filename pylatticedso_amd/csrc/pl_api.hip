@@ -447,15 +447,13 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
-                     (const uint8_t *)c->sharedbits.p, cl.rc);
-  if (c->dist.active) {   // one collective: [Z^T r | r.r | r.D^-1 r]; the coarse solve is then redundant per rank
-    hipLaunchKernelGGL(pl::k_coarse_tail_from_scal, dim3(1), dim3(pl::kWave), 0, c->stream, cur, cs.rc, cs.ncp);
-    if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2, c->stream))
+                     (const uint8_t *)c->sharedbits.p, cl.rc, cs.ncp);
+  if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
+    if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
-    hipLaunchKernelGGL(pl::k_coarse_scalars_from_rc, dim3(1), dim3(pl::kWave), 0, c->stream, cs.rc, cs.ncp, cur);
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
-                  cur + pl::S_RDR * pl::kSlots, c->stream);
+                  cs.rc + cs.ncp + pl::kSlots, c->stream);
   if (useL)   // rank-local level: no communication; r.z += r_L . A_L^-1 r_L
     pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                     (const double *)nullptr, c->stream);

@@ -168,7 +168,9 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.Wt, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;   // + rr, r.D^-1 r
+  // r_c plus, in its tail, the kSlots partial sums each of r.r and r.D^-1 r (+ tile terms): on several GPUs the
+  // whole buffer travels in ONE all-reduce and nothing has to be copied in or out of it
+  if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2 * kSlots) * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
@@ -184,7 +186,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
     if (hipMemset(c.yt, 0, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
   }
-  if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2) * sizeof(double)) != hipSuccess) return 2;
+  if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2 * kSlots) * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.W, 0, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMemset(c.Wt, 0, n2 * sizeof(float)) != hipSuccess) return 2;
   c.enabled = true;
@@ -535,8 +537,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const int32_t *__restrict__ aggL_of_tile /* may be null */,
                                                             const double *__restrict__ cenL,
                                                             const uint8_t *__restrict__ shared /* may be null */,
-                                                            double *__restrict__ rcL) {
+                                                            double *__restrict__ rcL, int ncp) {
   __shared__ double red[14][kBlock / kWave];
+  double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
   const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
     // r_c is zeroed by the previous direction kernel; ~8 tiles add into each aggregate's six entries
     if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
-    else if (threadIdx.x == 6) scalar_add(scal, S_RR, s);
+    else if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, s);
     if (!Bt_inv) {
-      if (threadIdx.x == 7) scalar_add(scal, S_RDR, s);
+      if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
     } else {
       // tile level: y_t = B_t^-1 (Z_t^T r); its share r_t . y_t of r.z joins r.D^-1 r (lanes 0..7 of wave 0)
       double tj[6];
@@ -654,25 +657,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       v += __shfl_xor(v, 1, 8);
       v += __shfl_xor(v, 2, 8);
       v += __shfl_xor(v, 4, 8);
-      if (threadIdx.x == 0) scalar_add(scal, S_RDR, v);
+      if (threadIdx.x == 0) unsafeAtomicAdd(rdr_slot, v);
     }
-  }
-}
-
-// multi-GPU: the local r.r and r.D^-1 r (32 slots each) go to the tail of r_c before its all-reduce ...
-__global__ void k_coarse_tail_from_scal(const double *__restrict__ scal, double *__restrict__ rc, int ncp) {
-  const double rr = scalar_read(scal, S_RR), rdr = scalar_read(scal, S_RDR);
-  if (threadIdx.x == 0) {
-    rc[ncp] = rr;
-    rc[ncp + 1] = rdr;
-  }
-}
-// ... and come back as global values (slot 0 holds the total, the other slots are cleared)
-__global__ void k_coarse_scalars_from_rc(const double *__restrict__ rc, int ncp, double *__restrict__ scal) {
-  const int s = threadIdx.x;
-  if (s < kSlots) {
-    scal[S_RR * kSlots + s] = (s == 0) ? rc[ncp] : 0.0;
-    scal[S_RDR * kSlots + s] = (s == 0) ? rc[ncp + 1] : 0.0;
   }
 }
 
@@ -700,19 +686,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
-    for (int e = threadIdx.x; e < ncp + 2; e += kBlock) rc[e] = 0.0;
+    for (int e = threadIdx.x; e < ncp; e += kBlock) rc[e] = 0.0;
   if (aggL_of_tile && (blockIdx.x == 2 || gridDim.x <= 2))
-    for (int e = threadIdx.x; e < ncpL + 2; e += kBlock) rcL[e] = 0.0;
+    for (int e = threadIdx.x; e < ncpL; e += kBlock) rcL[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
-    const double rr = scalar_read(scal, S_RR);
     const int s = threadIdx.x;
+    double rr = (s < kSlots) ? rc[ncp + s] : 0.0;            // ||r||^2 slots in the tail of r_c (this wave alone
+#pragma unroll                                                // reads and then clears the tail)
+    for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o, 64);
     if (s == 0) hist[k] = rr;
     if (s < kSlots) {
+      rc[ncp + s] = 0.0;
+      rc[ncp + kSlots + s] = 0.0;
       scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
       scal_next[S_RZ_NEW * kSlots + s] = 0.0;
-      scal_next[S_RR * kSlots + s] = 0.0;
       scal_next[S_PAP * kSlots + s] = 0.0;
-      scal_next[S_RDR * kSlots + s] = 0.0;
     }
   }
   const int t = blockIdx.x;

@@ -32,23 +32,36 @@ struct Dist {
   ncclComm_t comm = nullptr;
   int32_t n_shared = 0, n_shared_global = 0;
   DBuf<int32_t> local_idx, global_idx;   // [n_shared]
+  DBuf<int32_t> slot2loc;                // [n_shared_global] local node of a global interface slot, -1 if not here
   DBuf<double> pack;                     // [6*n_shared_global]
   DBuf<double> weight;                   // [6N] 1/multiplicity
 };
 
-__global__ void k_pack_shared(int32_t n, const int32_t *__restrict__ loc, const int32_t *__restrict__ glob,
-                              const double *__restrict__ y, double *__restrict__ pack) {
+// One kernel fills the whole message: interface rows this rank holds (others zero: the all-reduce sums ranks), then
+// the optional scalar tail.  slot2loc[g] = local node of global interface slot g, or -1.
+__global__ void k_pack_message(int64_t nrow, const int32_t *__restrict__ slot2loc, const double *__restrict__ y,
+                               const double *__restrict__ scal, int nscal, double *__restrict__ pack) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)n * 6) return;
-  const int64_t s = i / 6, k = i - 6 * s;
-  pack[6 * (int64_t)glob[s] + k] = y[6 * (int64_t)loc[s] + k];
+  if (i < nrow) {
+    const int64_t g = i / 6, k = i - 6 * g;
+    const int32_t l = slot2loc[g];
+    pack[i] = l >= 0 ? y[6 * (int64_t)l + k] : 0.0;
+  } else if (i < nrow + nscal) {
+    pack[i] = scal[i - nrow];
+  }
 }
-__global__ void k_unpack_shared(int32_t n, const int32_t *__restrict__ loc, const int32_t *__restrict__ glob,
-                                const double *__restrict__ pack, double *__restrict__ y) {
+// ... and one kernel takes it apart again.
+__global__ void k_unpack_message(int32_t n, const int32_t *__restrict__ loc, const int32_t *__restrict__ glob,
+                                 const double *__restrict__ pack, double *__restrict__ y, int64_t nrow,
+                                 double *__restrict__ scal, int nscal) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)n * 6) return;
-  const int64_t s = i / 6, k = i - 6 * s;
-  y[6 * (int64_t)loc[s] + k] = pack[6 * (int64_t)glob[s] + k];
+  const int64_t n6 = (int64_t)n * 6;
+  if (i < n6) {
+    const int64_t s = i / 6, k = i - 6 * s;
+    y[6 * (int64_t)loc[s] + k] = pack[6 * (int64_t)glob[s] + k];
+  } else if (i < n6 + nscal) {
+    scal[i - n6] = pack[nrow + (i - n6)];
+  }
 }
 __global__ void k_fill(int64_t n, double v, double *__restrict__ x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,30 +80,22 @@ inline int dist_unique_id(void *out) {
   return 0;
 }
 
-__global__ void k_copy_small(int n, const double *__restrict__ src, double *__restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
 // y[shared] <- sum over ranks of y[shared]; optionally `nscal` device scalars (e.g. the 32 slots of a LOCAL partial
-// dot product) ride in the tail of the same message and are summed over ranks too: ONE collective.
+// dot product) ride in the tail of the same message and are summed over ranks too: ONE collective, one kernel
+// before it and one after.
 inline int dist_sum_shared(Dist &d, double *y, hipStream_t s, double *scal = nullptr, int nscal = 0) {
   if (!d.active) return 0;
-  const size_t nrow = (size_t)d.n_shared_global * 6;
-  const size_t n = nrow + (size_t)(scal ? nscal : 0);
+  const int64_t nrow = (int64_t)d.n_shared_global * 6;
+  if (!scal) nscal = 0;
+  const int64_t n = nrow + nscal;
   if (n == 0) return 0;
-  if (nrow && hipMemsetAsync(d.pack.p, 0, nrow * sizeof(double), s) != hipSuccess) return 1;
-  if (d.n_shared > 0)
-    hipLaunchKernelGGL(k_pack_shared, dim3((unsigned)((d.n_shared * 6 + 255) / 256)), dim3(256), 0, s, d.n_shared,
-                       d.local_idx.p, d.global_idx.p, y, d.pack.p);
-  if (scal && nscal > 0)
-    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((nscal + 63) / 64)), dim3(64), 0, s, nscal, scal, d.pack.p + nrow);
-  if (ncclAllReduce(d.pack.p, d.pack.p, n, ncclDouble, ncclSum, d.comm, s) != ncclSuccess) return 2;
-  if (d.n_shared > 0)
-    hipLaunchKernelGGL(k_unpack_shared, dim3((unsigned)((d.n_shared * 6 + 255) / 256)), dim3(256), 0, s, d.n_shared,
-                       d.local_idx.p, d.global_idx.p, d.pack.p, y);
-  if (scal && nscal > 0)
-    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((nscal + 63) / 64)), dim3(64), 0, s, nscal, d.pack.p + nrow, scal);
+  hipLaunchKernelGGL(k_pack_message, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nrow, d.slot2loc.p, y, scal,
+                     nscal, d.pack.p);
+  if (ncclAllReduce(d.pack.p, d.pack.p, (size_t)n, ncclDouble, ncclSum, d.comm, s) != ncclSuccess) return 2;
+  const int64_t m = (int64_t)d.n_shared * 6 + nscal;
+  if (m > 0)
+    hipLaunchKernelGGL(k_unpack_message, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d.n_shared,
+                       d.local_idx.p, d.global_idx.p, d.pack.p, y, nrow, scal, nscal);
   return 0;
 }
 
@@ -115,6 +120,12 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
   if (n_shared > 0) {
     if (hipMemcpy(d.local_idx.p, loc, n_shared * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return 3;
     if (hipMemcpy(d.global_idx.p, glob, n_shared * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return 3;
+  }
+  {
+    std::vector<int32_t> s2l((size_t)std::max(1, n_shared_global), -1);
+    for (int32_t i = 0; i < n_shared; ++i) s2l[glob[i]] = loc[i];
+    if (d.slot2loc.alloc(s2l.size()) != hipSuccess) return 2;
+    if (hipMemcpy(d.slot2loc.p, s2l.data(), s2l.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return 3;
   }
   d.active = true;
   // multiplicity = all-reduce of ones on the shared nodes; weight = 1/multiplicity
