@@ -30,7 +30,6 @@
 
 namespace pl {
 
-enum { S_RDR = 6 };   // scalar id (see S_* in pl_kernels.h): r . D^-1 r
 
 struct Coarse {
   bool enabled = false;     // topology prepared (pl_create)
@@ -38,16 +37,15 @@ struct Coarse {
   int n_agg = 0, nc = 0, ncp = 0;   // ncp = nc rounded up to the dense block size (padding rows are identity)
   int bw_blocks = 0;                // block bandwidth of A_c (aggregates couple to their 26 neighbours only)
   int64_t n_tiles = 0;
-  TBuf<int32_t> agg_of_node, agg_of_tile, agg_tile_ptr, agg_tile_idx;
+  TBuf<int32_t> agg_of_node, agg_of_tile;
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
   float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
-  double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *part = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
+  double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
-  TBuf<int32_t> tile_of_node;
   TBuf<uint8_t> tile_on;          // 0: the tile holds nodes shared with another rank (multi-GPU) -> no tile-level term
   std::vector<int32_t> h_tile_start;
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
@@ -62,7 +60,7 @@ struct Coarse {
   int *fix_count = nullptr;
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
-    for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)part, (void *)rc, (void *)yc, (void *)tv,
+    for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
                     (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32})
       if (q) (void)hipFree(q);
   }
@@ -115,11 +113,6 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     (void)xyz_dev_order;
     if (hipMalloc((void **)&c.dinv32, (size_t)N * 6 * sizeof(float)) != hipSuccess) return 2;
   }
-  std::vector<int32_t> ptr(n_agg + 1, 0), idx(T);
-  for (int64_t t = 0; t < T; ++t) ptr[agg_of_tile[t] + 1]++;
-  for (int a = 0; a < n_agg; ++a) ptr[a + 1] += ptr[a];
-  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-  for (int64_t t = 0; t < T; ++t) idx[fill[agg_of_tile[t]]++] = (int32_t)t;
   c.n_agg = n_agg;
   c.nc = 6 * n_agg;
   c.n_tiles = T;
@@ -156,7 +149,6 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     if (c.cross_idx.upload(idx2) != hipSuccess) return 1;
   }
   if (c.agg_of_node.upload(agg_of_node) != hipSuccess || c.agg_of_tile.upload(agg_of_tile) != hipSuccess ||
-      c.agg_tile_ptr.upload(ptr) != hipSuccess || c.agg_tile_idx.upload(idx) != hipSuccess ||
       c.cen.upload(cen) != hipSuccess)
     return 1;
   c.ncp = (c.nc + kNB - 1) / kNB * kNB;
@@ -167,7 +159,6 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMemset(c.Lf, 0, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Wt, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Dinv, (size_t)c.ncp * kNB * sizeof(double)) != hipSuccess) return 2;
-  if (hipMalloc((void **)&c.part, (size_t)T * 8 * sizeof(double)) != hipSuccess) return 2;
   // r_c plus, in its tail, the kSlots partial sums each of r.r and r.D^-1 r (+ tile terms): on several GPUs the
   // whole buffer travels in ONE all-reduce and nothing has to be copied in or out of it
   if (hipMalloc((void **)&c.rc, (size_t)(c.ncp + 2 * kSlots) * sizeof(double)) != hipSuccess) return 2;
@@ -175,12 +166,9 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
   {
-    std::vector<int32_t> tile_of(N);
-    for (int64_t t = 0; t < T; ++t)
-      for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of[i] = (int32_t)t;
     std::vector<uint8_t> on((size_t)T, 1);
     c.h_tile_start = tile_start;
-    if (c.tile_of_node.upload(tile_of) != hipSuccess || c.tile_on.upload(on) != hipSuccess) return 1;
+    if (c.tile_on.upload(on) != hipSuccess) return 1;
     if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
     if (hipMalloc((void **)&c.yt, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
     if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
