@@ -72,31 +72,10 @@ class LatticeSim:
         params = open_lattice_parameters(name_file)
         self._extract_geometry(params)
         self.define_simulation_parameters(params)
-        self.lattice = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
-                                   (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
-                                   self.radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,
-                                   erased_blocks=self.eraser_blocks)
-        lat = self.lattice
-        self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max = map(float, lat.bbox)
-        N = lat.n_nodes
-        self.fixed_DOF = np.zeros((N, 6), dtype=bool)
-        self.displacement_vector = np.zeros((N, 6))
-        self.applied_force = np.zeros((N, 6))
-        self.reaction_force_vector = np.zeros((N, 6))
-        self.penalized = None
-        # lattice_sim.py:119-122: joints are penalised for the FEM path and for DDM with exact Schur complements;
-        # with a surrogate the penalisation lives inside the stored Schur matrices
-        if self.enable_simulation_properties and (not self.domain_decomposition_solver
-                                                  or self.type_schur_complement_computation == "exact"):
-            self.define_angles_between_beams()
-            self.set_penalized_beams()
-        else:
-            self.lzone = np.zeros((lat.n_beams, 2))
-            self.penalized = LA.penalize(lat, None)
-        self.define_node_index_boundary()
-        self.set_boundary_conditions()
-        self._device = None
-        self._ddm_device = None
+        self._base_radii = [float(r) for r in self.radii]
+        self._cell_radii_override = None
+        self._device = self._ddm_device = None
+        self._generate_and_prepare()
         self.cell_schur_index = None       # (C,) index into self.schur_complements
         self.schur_complements = None      # (n_S, 6 n_b, 6 n_b)
         self.iteration = 0
@@ -188,6 +167,55 @@ class LatticeSim:
         self.young_modulus, self.poisson_ratio = material_properties(self.material_name)
 
     # ------------------------------------------------------------------------------------------------
+    def reset_cell_with_new_radii(self, new_radii, index_cell: int = 0):
+        """lattice_sim.py:1421-1497: give one cell new base radii and redo everything that depends on them - the
+        struts of that cell, the penalisation lengths (L_zone depends on the neighbours' radii), boundary indices and
+        boundary conditions.  Array-backed: the lattice is regenerated with a per-cell radius override."""
+        if len(new_radii) != len(self.radii):
+            raise ValueError("Invalid hybrid radii data.")
+        if not (0 <= index_cell < self.lattice.n_cells):
+            raise IndexError("Invalid cell index.")
+        self.radii = [float(r) for r in new_radii]
+        if getattr(self, "_cell_radii_override", None) is None:
+            self._cell_radii_override = np.tile(np.asarray(self._base_radii, dtype=float), (self.lattice.n_cells, 1))
+        self._cell_radii_override[index_cell] = self.radii
+        self._generate_and_prepare()
+
+    def _generate_and_prepare(self):
+        """Lattice arrays + penalisation + boundary indices + boundary conditions from the current parameters."""
+        for dev in (getattr(self, "_device", None), getattr(self, "_ddm_device", None)):
+            if dev is not None:
+                dev.close()
+        self._device = self._ddm_device = None
+        self.lattice = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
+                                   (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
+                                   self._base_radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,
+                                   erased_blocks=self.eraser_blocks,
+                                   cell_radii_override=(None if self._cell_radii_override is None else
+                                                        self._cell_radii_override * self._cell_gfac[:, None]))
+        lat = self.lattice
+        if self._cell_radii_override is None:      # gradient factor of Cell.get_radius (cell.py:385-412), per cell
+            self._cell_gfac = lat.cell_radii[:, 0] / self._base_radii[0]
+        self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max = map(float, lat.bbox)
+        N = lat.n_nodes
+        self.fixed_DOF = np.zeros((N, 6), dtype=bool)
+        self.displacement_vector = np.zeros((N, 6))
+        self.applied_force = np.zeros((N, 6))
+        self.reaction_force_vector = np.zeros((N, 6))
+        self.penalized = None
+        self.is_penalized = False
+        # lattice_sim.py:119-122: joints are penalised for the FEM path and for DDM with exact Schur complements;
+        # with a surrogate the penalisation lives inside the stored Schur matrices
+        if self.enable_simulation_properties and (not self.domain_decomposition_solver
+                                                  or self.type_schur_complement_computation == "exact"):
+            self.define_angles_between_beams()
+            self.set_penalized_beams()
+        else:
+            self.lzone = np.zeros((lat.n_beams, 2))
+            self.penalized = LA.penalize(lat, None)
+        self.define_node_index_boundary()
+        self.set_boundary_conditions()
+
     def get_number_cells(self):
         return self.lattice.n_cells
 

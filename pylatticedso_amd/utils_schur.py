@@ -1,6 +1,8 @@
 """Drop-in for ``get_schur_complement`` (src/pyLatticeSim/utils_schur.py:22-53) on MI355X."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -38,3 +40,31 @@ def get_schur_complement(lattice, cell_index=None, rtol=1e-13, max_iter=200000):
     dev = lattice.device_model()
     dev.assemble()
     return dev.schur(order, rtol=rtol, max_iter=max_iter)
+
+
+def define_path_schur_complement(lattice_object):
+    """``<repo>/data/outputs/schur_complement/Schur_complement_<geoms>.npz`` (utils_schur.py:74-95)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "Schur_complement_" + "_".join(str(g) for g in lattice_object.geom_types) + ".npz"
+    return os.path.join(root, "data", "outputs", "schur_complement", name)
+
+
+def save_schur_complement_npz(lattice_object, radius_values, schur_matrices):
+    """utils_schur.py:55-72: the dataset the reduced-basis construction starts from."""
+    path = define_path_schur_complement(lattice_object)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez(path, radius_values=np.array(radius_values), schur_matrices=np.array(schur_matrices))
+    print("Schur complement data saved to", path)
+
+
+def load_schur_complement_dataset(lattice_object, enable_normalization: bool = False):
+    """utils_schur.py:97-129: {radius tuple: matrix}."""
+    data = np.load(define_path_schur_complement(lattice_object), allow_pickle=True)
+    radius_values, schur_matrices = data["radius_values"], data["schur_matrices"]
+    if np.ndim(radius_values[0]) == 0 or np.ndim(radius_values) == 1:
+        out = {tuple(np.atleast_1d(radius_values)): schur_matrices}
+    else:
+        out = {tuple(r): m for r, m in zip(radius_values, schur_matrices)}
+    if enable_normalization:
+        out = {k: m / np.linalg.norm(m) for k, m in out.items()}
+    return out

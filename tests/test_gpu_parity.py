@@ -174,6 +174,31 @@ def test_schur_complement_matches_dolfinx_golden(golden_dir, geom, name):
         assert _rel(S, G) < 1e-8, (geom, r)
 
 
+def test_schur_dataset_construction_flow(golden_dir, tmp_path, monkeypatch):
+    """The reference's construct_schur_complement_dataset.py flow on the GPU: one LatticeSim, reset_cell_with_new_radii
+    per sample, get_schur_complement, save / load of the dataset - against the reference's dolfinx dataset."""
+    from pylatticedso_amd import utils_schur as US
+    sg = np.load(os.path.join(golden_dir, "schur_BCC.npz"))
+    preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": 1, "y": 1, "z": 1},
+                           "radii": [0.02], "geom_types": ["BCC"]},
+              "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": True}}
+    L = LatticeSim(preset)
+    radii, mats = [], []
+    for r in sg["radius_values"].ravel():
+        L.reset_cell_with_new_radii([float(r)])
+        assert np.allclose(L.lattice.beam_radius, r)
+        mats.append(get_schur_complement(L))
+        radii.append([float(r)])
+    for S, G in zip(mats, sg["schur_matrices"]):
+        assert _rel(S, G) < 1e-8
+    monkeypatch.setattr(US, "define_path_schur_complement", lambda lat: str(tmp_path / "Schur_complement_BCC.npz"))
+    US.save_schur_complement_npz(L, radii, mats)
+    back = US.load_schur_complement_dataset(L)
+    assert len(back) == len(radii) and _rel(back[(float(radii[2][0]),)], mats[2]) == 0.0
+    with pytest.raises(ValueError):
+        L.reset_cell_with_new_radii([0.05, 0.05])
+
+
 def test_sensitivity_matches_finite_difference(golden_dir):
     _, L = _sim(golden_dir, "bcc_2x2x2")
     lat, pen = L.lattice, L.penalized
