@@ -304,8 +304,30 @@ def gen_surrogate():
     print("surrogate_bcc:", {k: v.shape for k, v in res.items()})
 
 
+def gen_greedy():
+    """The reference's greedy reduced-basis construction (greedy_algorithm.py:35-154) run on its own dolfinx dataset of
+    the BCC cell, for two tolerances: inputs (the dataset, 10 matrices) and every output."""
+    from pyLatticeSim.greedy_algorithm import reduce_basis_greedy
+    d = np.load(os.path.join(REF, "data", "outputs", "schur_complement", "Schur_complement_BCC.npz"))
+    data = {tuple(r): m for r, m in zip(d["radius_values"], d["schur_matrices"])}
+    res = {"radius_values": d["radius_values"], "schur_matrices": d["schur_matrices"]}
+    for tol in (1e-3, 1e-6):
+        out = _quiet(reduce_basis_greedy, dict(data), tol, None, 0)
+        tag = f"{tol:.0e}"
+        res[f"mainelem_{tag}"] = np.asarray(out[0])
+        res[f"reducedcoef_{tag}"] = np.asarray(out[1])
+        res[f"basis_{tag}"] = np.asarray(out[3])
+        res[f"alpha_{tag}"] = np.asarray(out[4])
+        res[f"matP_{tag}"] = np.asarray(out[5])
+        res[f"norms_{tag}"] = np.asarray(out[6])
+    np.savez_compressed(os.path.join(OUT, "greedy_bcc.npz"), **res)
+    print("greedy_bcc:", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "surrogate"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "surrogate", "greedy"]
+    if "greedy" in which:
+        gen_greedy()
     if "surrogate" in which:
         gen_surrogate()
     if "lattice" in which:

@@ -102,3 +102,43 @@ def test_linear_surrogate_nd_falls_back_to_nearest_outside_the_hull():
     far = np.array([[5.0, 5.0]])
     i0 = np.argmin(np.linalg.norm(pts - far, axis=1))
     assert np.allclose(sur.alphas(far), alpha[i0][None])
+
+
+# ---- greedy reduced-basis construction (tests/golden/greedy_bcc.npz: the reference's own greedy run on its dolfinx
+# ---- dataset of the BCC cell) -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tol", [1e-3, 1e-6])
+def test_greedy_reduced_basis_matches_reference(tol, tmp_path):
+    from pylatticedso_amd.greedy_algorithm import reduce_basis_greedy
+    g = np.load(os.path.join(GOLD, "greedy_bcc.npz"))
+    data = {tuple(r): m for r, m in zip(g["radius_values"], g["schur_matrices"])}
+    tag = f"{tol:.0e}"
+    main, coef, fields, basis, alpha, matP, norms = reduce_basis_greedy(dict(data), tol, "rb_test", verbose=0,
+                                                                        root=str(tmp_path))
+    assert list(main) == list(g[f"mainelem_{tag}"])
+    assert basis.shape == g[f"basis_{tag}"].shape
+    assert np.abs(basis - g[f"basis_{tag}"]).max() < 1e-9
+    assert _rel(alpha, g[f"alpha_{tag}"]) < 1e-9
+    assert _rel(coef, g[f"reducedcoef_{tag}"]) < 1e-8
+    assert _rel(matP, g[f"matP_{tag}"]) < 1e-9 and _rel(norms, g[f"norms_{tag}"]) < 1e-12
+    # (one-pass Gram-Schmidt, as in the reference: the last vectors normalise residuals of ~1e-6)
+    assert np.abs(basis.T @ basis - np.eye(basis.shape[1])).max() < 1e-6
+    # the file it wrote is what the surrogate modes load
+    d = np.load(tmp_path / "data" / "outputs" / "schur_complement" / "reduced_basis" / "rb_test.npz")
+    assert set(d.files) == {"basis_reduced_ortho", "alpha_ortho", "list_elements"}
+    s2 = SchurSurrogate(d["basis_reduced_ortho"], d["alpha_ortho"], d["list_elements"], "RBF")
+    S = s2.schur_batch(g["radius_values"])
+    worst = max(_rel(S[q], g["schur_matrices"][q]) for q in range(len(S)))
+    assert worst < (5e-3 if tol == 1e-3 else 1e-5)
+
+
+def test_greedy_1e6_reproduces_the_committed_reduced_basis():
+    """Same dataset, same tolerance -> the reduced basis the reference ships (up to the sign of a basis vector)."""
+    from pylatticedso_amd.greedy_algorithm import reduce_basis_greedy
+    g = np.load(os.path.join(GOLD, "greedy_bcc.npz"))
+    ref = np.load(os.path.join(GOLD, "reduced_basis_BCC_tol_1e-6.npz"))
+    data = {tuple(r): m for r, m in zip(g["radius_values"], g["schur_matrices"])}
+    basis, alpha = reduce_basis_greedy(data, 1e-6, None, verbose=0)[3:5]
+    assert basis.shape == ref["basis_reduced_ortho"].shape
+    sign = np.sign((basis * ref["basis_reduced_ortho"]).sum(axis=0))
+    assert np.abs(basis * sign - ref["basis_reduced_ortho"]).max() < 1e-8
+    assert _rel(alpha * sign[:, None], ref["alpha_ortho"]) < 1e-8
