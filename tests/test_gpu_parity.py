@@ -379,6 +379,39 @@ def test_full_size_properties_config2():
                 assert _rel(u2, u_ref) < 1e-6                                    # two independent kernels agree
 
 
+def test_full_size_properties_config3():
+    """BASELINE.json configs[2] (100^3 BCC, r = 0.05: 8 M struts, 2.03 M nodes) on one GPU with the bench settings
+    (multi-level preconditioner, record palette): operator symmetry, rigid-body null space, true residual and
+    Clapeyron's theorem for the cantilever solve."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 100
+    lat = LA.generate((1, 1, 1), (n, n, n), ["BCC"], [0.05])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    assert lat.n_beams == 8_000_000 and lat.n_nodes == 2_030_301
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == float(n)
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    rng = np.random.default_rng(12)
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                          precond=3, palette=1) as dev:
+        dev.assemble()
+        a, b = rng.standard_normal((2, 6 * lat.n_nodes))
+        Ka, Kb = dev.spmv(a).ravel(), dev.spmv(b).ravel()
+        assert abs(b @ Ka - a @ Kb) < 1e-10 * abs(b @ Ka)
+        om = np.array([0.3, -0.2, 0.5])
+        rigid = np.c_[np.cross(om, lat.node_xyz) + [1.0, 2.0, 3.0], np.tile(om, (lat.n_nodes, 1))]
+        assert np.abs(dev.spmv(rigid)).max() < 1e-7 * np.abs(Ka).max()
+        dev.set_bc(fixed, None, f)
+        u, st = dev.solve(rtol=1e-8, max_iter=50000)
+        assert st["converged"] == 1
+        res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
+        assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8
+        assert abs((f * u).sum() - 2.0 * dev.energy(u)) < 1e-7 * abs((f * u).sum())
+        assert np.all(u[fixed != 0] == 0.0)
+
+
 @pytest.mark.parametrize("name", ["bcc_4x4x4", "bcc_6x3x3_flexion"])
 def test_multilevel_preconditioners_same_solution(golden_dir, name):
     """precond = 2 (Jacobi + rigid-body coarse space) must give the same displacements as Jacobi-PCG."""
