@@ -328,6 +328,13 @@ int finish_diag_dist(pl_context *c) {
   return PL_OK;
 }
 
+// Dirichlet mask OR "shared with another rank" (all six dofs): the mask of the rank-local levels
+__global__ void k_local_mask(int64_t N, const uint8_t *__restrict__ fixedbits, const uint8_t *__restrict__ shared,
+                             uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) mask[i] = (uint8_t)(fixedbits[i] | (shared[i] ? 0x3f : 0));
+}
+
 // fp32 copy of the Jacobi inverse for the multi-level PCG kernels (main stream, after the diagonal is final)
 int launch_dinv32(pl_context *c) {
   if (!c->coarse.enabled) return PL_OK;
@@ -340,10 +347,13 @@ int launch_dinv32(pl_context *c) {
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
   pl::Coarse &cs = c->coarse;
   if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
+  if (c->dist.active)   // tile modes live on this rank's own nodes: shared nodes count as constrained
+    hipLaunchKernelGGL(k_local_mask, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, st, c->N, c->fixedbits.p,
+                       c->sharedbits.p, c->maskL.p);
   hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
                      c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                      reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                     c->fixedbits.p, cs.tile_on.p, cs.Bt_inv);
+                     c->dist.active ? c->maskL.p : c->fixedbits.p, cs.Bt_inv);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -410,12 +420,6 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   return PL_OK;
 }
 
-__global__ void k_local_mask(int64_t N, const uint8_t *__restrict__ fixedbits, const uint8_t *__restrict__ shared,
-                             uint8_t *__restrict__ mask) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) mask[i] = (uint8_t)(fixedbits[i] | (shared[i] ? 0x3f : 0));
-}
-
 int build_coarse(pl_context *c) {
   int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true);
   if (rc || !c->coarseL.enabled) return rc;
@@ -447,7 +451,8 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
-                     (const uint8_t *)c->sharedbits.p, cl.rc, cs.ncp);
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
+                     cs.ncp);
   if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
@@ -462,7 +467,8 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, cur, nxt,
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
-                     (const uint8_t *)c->sharedbits.p, cl.rc, cl.ncp);
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
+                     cl.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -842,14 +848,14 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
+    PL_HIPC(c->sharedbits.alloc(N));
+    PL_HIPC(c->maskL.alloc(N));
+    PL_HIPC(hipMemset(c->sharedbits.p, 0, N));
     if (o->precond == 4) {
       const int maxL = o->local_max_dofs > 0 ? o->local_max_dofs : 3072;
       rc = pl::coarse_setup(c->coarseL, tile_start, tile_brick, grid, xyz.data(), N, maxL, conn, true);
       if (rc) return bail(fail(PL_ERR_HIP, "pl_create: local coarse-space setup failed (" + std::to_string(rc) + ")"));
       c->coarseL.tile_level = false;
-      PL_HIPC(c->sharedbits.alloc(N));
-      PL_HIPC(c->maskL.alloc(N));
-      PL_HIPC(hipMemset(c->sharedbits.p, 0, N));
     }
   }
 
@@ -1379,16 +1385,7 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   int rc = pl::dist_init(h->dist, rank, world, unique_id, loc.data(), shared_global, n_shared, n_shared_global, h->N,
                          h->stream);
   if (rc) return fail(PL_ERR_HIP, "pl_dist_init: RCCL communicator setup failed (" + std::to_string(rc) + ")");
-  if (h->coarse.enabled) {   // tiles holding a shared node get no tile-level term (their block would span two ranks)
-    const std::vector<int32_t> &ts = h->coarse.h_tile_start;
-    std::vector<uint8_t> on(ts.size() - 1, 1);
-    for (int i = 0; i < n_shared; ++i) {
-      const size_t t = (size_t)(std::upper_bound(ts.begin(), ts.end(), loc[i]) - ts.begin()) - 1;
-      on[t] = 0;
-    }
-    if (h->coarse.tile_on.upload(on) != hipSuccess) return fail(PL_ERR_HIP, "pl_dist_init: tile flags upload failed");
-  }
-  if (h->coarseL.enabled) {
+  if (h->coarse.enabled) {   // the tile level and the rank-local dense level leave shared nodes out
     std::vector<uint8_t> sh((size_t)h->N, 0);
     for (int i = 0; i < n_shared; ++i) sh[loc[i]] = 1;
     PL_HIP(hipMemcpy(h->sharedbits.p, sh.data(), sh.size(), hipMemcpyHostToDevice));

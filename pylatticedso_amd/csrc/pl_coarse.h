@@ -46,7 +46,6 @@ struct Coarse {
   int *info = nullptr;
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
-  TBuf<uint8_t> tile_on;          // 0: the tile holds nodes shared with another rank (multi-GPU) -> no tile-level term
   std::vector<int32_t> h_tile_start;
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
   // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
@@ -166,9 +165,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
   {
-    std::vector<uint8_t> on((size_t)T, 1);
     c.h_tile_start = tile_start;
-    if (c.tile_on.upload(on) != hipSuccess) return 1;
     if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
     if (hipMalloc((void **)&c.yt, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
     if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
@@ -358,6 +355,8 @@ __global__ void k_coarse_regularize(int nc, double *__restrict__ Ac) {
 // Tile level: B_t = Z_t^T P K P Z_t (6 x 6) for the rigid-body modes of tile t about its aggregate's centre, inverted
 // in place.  One workgroup per tile walks the tile's home + foreign strut lists (pl_tile.h), every lane keeps a
 // 6 x 6 partial in registers, so there are no atomics.  Modes without stiffness (all their dofs fixed) are dropped.
+// `fixedbits` is the Dirichlet mask, on several GPUs OR-ed with "shared with another rank": the tile modes live on
+// this rank's own nodes only (a block that includes shared nodes would need the other rank's struts).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void spd6_inverse(double *A /* 36, in/out */) {
   double dmax = 0.0;
@@ -429,15 +428,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
                                                         const int32_t *__restrict__ agg_of_tile,
                                                         const double *__restrict__ cen, const double *__restrict__ xyz,
                                                         const uint8_t *__restrict__ fixedbits,
-                                                        const uint8_t *__restrict__ tile_on,
                                                         double *__restrict__ Bt_inv) {
   __shared__ double red[36][kBlock / kWave];
   __shared__ double A[36];
   const int t = blockIdx.x;
-  if (!tile_on[t]) {
-    if (threadIdx.x < 36) Bt_inv[(size_t)t * 36 + threadIdx.x] = 0.0;
-    return;
-  }
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
@@ -526,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const double *__restrict__ cenL,
                                                             const uint8_t *__restrict__ shared /* may be null */,
                                                             double *__restrict__ rcL, int ncp) {
-  __shared__ double red[14][kBlock / kWave];
+  __shared__ double red[20][kBlock / kWave];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -549,6 +543,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     l2 = cenL[3 * aL + 2];
   }
   double accL[6] = {0, 0, 0, 0, 0, 0};
+  double accT[6] = {0, 0, 0, 0, 0, 0};      // tile level on several GPUs: the tile's restriction without shared nodes
+  const bool own_t = Bt_inv && shared;
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
     double pv[6], av[6], dv[6], xv[6], rv[6];
     const double2 *p2 = reinterpret_cast<const double2 *>(p + 6 * (int64_t)i);
@@ -592,6 +588,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
     }
+    if (own_t && !shared[i]) {
+      accT[0] += rv[0];
+      accT[1] += rv[1];
+      accT[2] += rv[2];
+      accT[3] += rv[3] + (ry * rv[2] - rz * rv[1]);
+      accT[4] += rv[4] + (rz * rv[0] - rx * rv[2]);
+      accT[5] += rv[5] + (rx * rv[1] - ry * rv[0]);
+    }
     if (aggL_of_tile && !(shared && shared[i])) {
       const double sx = xyz[3 * (int64_t)i] - l0, sy = xyz[3 * (int64_t)i + 1] - l1, sz = xyz[3 * (int64_t)i + 2] - l2;
       accL[0] += rv[0];
@@ -615,6 +619,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (lane == 0) red[8 + k][wv] = s;
     }
   }
+  if (own_t) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double s = wave_sum(accT[k]);
+      if (lane == 0) red[14 + k][wv] = s;
+    }
+  }
   __syncthreads();
   if (aggL_of_tile && threadIdx.x >= kWave && threadIdx.x < kWave + 6) {   // wave 1 publishes the local restriction
     const int k = threadIdx.x - kWave;
@@ -634,14 +645,22 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
     } else {
       // tile level: y_t = B_t^-1 (Z_t^T r); its share r_t . y_t of r.z joins r.D^-1 r (lanes 0..7 of wave 0)
+      double st = s;                           // this lane's component of the TILE restriction
+      if (own_t) {
+        st = 0.0;
+        if (threadIdx.x < 6) {
+#pragma unroll
+          for (int q = 0; q < kBlock / kWave; ++q) st += red[14 + threadIdx.x][q];
+        }
+      }
       double tj[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) tj[j] = __shfl(s, j, 8);
+      for (int j = 0; j < 6; ++j) tj[j] = __shfl(st, j, 8);
       double y = 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) y += bi[j] * tj[j];
       if (threadIdx.x < 6) yt[6 * (size_t)t + threadIdx.x] = y;
-      double v = threadIdx.x < 6 ? y * s : (threadIdx.x == 7 ? s : 0.0);
+      double v = threadIdx.x < 6 ? y * st : (threadIdx.x == 7 ? s : 0.0);
       v += __shfl_xor(v, 1, 8);
       v += __shfl_xor(v, 2, 8);
       v += __shfl_xor(v, 4, 8);
@@ -696,10 +715,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   const int a = agg_of_tile[t];
   const double *y = yc + 6 * a;
   double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
-  if (yt) {   // the tile's modes use the same reference point, so the two rigid motions just add
+  double T[6] = {0, 0, 0, 0, 0, 0};
+  if (yt) {   // the tile's modes use the same reference point, so the two rigid motions just add ...
     const double *q = yt + 6 * (size_t)t;
-    U0 += q[0]; U1 += q[1]; U2 += q[2]; W0 += q[3]; W1 += q[4]; W2 += q[5];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) T[k] = q[k];
+    if (!shared) {
+      U0 += T[0]; U1 += T[1]; U2 += T[2]; W0 += T[3]; W1 += T[4]; W2 += T[5];
+    }
   }
+  const bool own_t = yt && shared;   // ... except on several GPUs, where nodes shared with other ranks are left out
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
   double L[6] = {0, 0, 0, 0, 0, 0}, l0 = 0.0, l1 = 0.0, l2 = 0.0;     // rank-local dense level (multi-GPU)
   if (aggL_of_tile) {
@@ -713,6 +738,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
+    if (own_t && !shared[i]) {
+      zc[0] += T[0] + (T[4] * rz - T[5] * ry);
+      zc[1] += T[1] + (T[5] * rx - T[3] * rz);
+      zc[2] += T[2] + (T[3] * ry - T[4] * rx);
+      zc[3] += T[3];
+      zc[4] += T[4];
+      zc[5] += T[5];
+    }
     if (aggL_of_tile && !(shared && shared[i])) {
       const double sx = xyz[3 * i] - l0, sy = xyz[3 * i + 1] - l1, sz = xyz[3 * i + 2] - l2;
       zc[0] += L[0] + (L[4] * sz - L[5] * sy);
