@@ -344,12 +344,18 @@ int launch_dinv32(pl_context *c) {
   return PL_OK;
 }
 
+// The rank-local levels (tile blocks on several GPUs, local dense level) see shared nodes as constrained.
+int launch_local_mask(pl_context *c) {
+  if (!c->coarse.enabled || !(c->dist.active || c->coarseL.enabled)) return PL_OK;
+  hipLaunchKernelGGL(k_local_mask, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->fixedbits.p,
+                     c->sharedbits.p, c->maskL.p);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
   pl::Coarse &cs = c->coarse;
   if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
-  if (c->dist.active)   // tile modes live on this rank's own nodes: shared nodes count as constrained
-    hipLaunchKernelGGL(k_local_mask, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, st, c->N, c->fixedbits.p,
-                       c->sharedbits.p, c->maskL.p);
   hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
                      c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                      reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
@@ -423,9 +429,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
 int build_coarse(pl_context *c) {
   int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true);
   if (rc || !c->coarseL.enabled) return rc;
-  // the local level sees shared nodes as constrained: its modes live on this rank's own nodes only
-  hipLaunchKernelGGL(k_local_mask, dim3(grid_for(c->N)), dim3(pl::kBlock), 0, c->stream, c->N, c->fixedbits.p,
-                     c->sharedbits.p, c->maskL.p);
+  // (mask = Dirichlet | shared, launch_local_mask: its modes live on this rank's own nodes only)
   return build_coarse_level(c, c->coarseL, c->maskL.p, false);
 }
 
@@ -990,6 +994,8 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     if (rc) return rc;
     rc = finish_diag_dist(h);
     if (rc) return rc;
+    rc = launch_local_mask(h);
+    if (rc) return rc;
     rc = launch_tile_blocks(h, h->stream);
     if (rc) return rc;
     rc = build_coarse(h);
@@ -1046,6 +1052,8 @@ int pl_assemble(pl_handle h) {
   }
   PL_HIP(hipEventRecord(h->ev0, h->stream));
   int rc = launch_records(h);
+  if (rc) return rc;
+  rc = launch_local_mask(h);
   if (rc) return rc;
   // fork: everything that only streams the records runs on the side stream while the main stream walks the
   // latency-bound chain of the coarse factorisation
