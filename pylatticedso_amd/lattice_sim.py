@@ -477,9 +477,11 @@ class LatticeSim:
         (xsol, info, global_displacement_index, b) or four None when b == 0."""
         if not self.domain_decomposition_solver:
             raise ValueError("LatticeSim was not created with enable_domain_decomposition_solver=True")
-        if self.enable_preconditioner:
-            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not accelerated; running "
-                  "plain CG")
+        if self.enable_preconditioner and not getattr(self, "_precond_note_done", False):
+            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not ported; running plain CG "
+                  "on the device to the same tolerance (max_iterations of the preset then only applies if larger "
+                  "than the unpreconditioned default)")
+            self._precond_note_done = True
         dev = self.ddm_model()
         bn = self._boundary_nodes_by_index()
         fixed = self.fixed_DOF[bn]
@@ -494,6 +496,10 @@ class LatticeSim:
             print("No external forces or imposed displacements in the lattice. Process aborted.")
             return None, None, None, None
         maxit = self.number_iteration_max or 1000
+        if self.enable_preconditioner:
+            # presets written for the LU-preconditioned CG cap it at a handful of iterations; the plain CG that
+            # replaces it needs O(sqrt(cond)) of them to reach the same 1e-6
+            maxit = max(maxit, 20000)
         u, st = dev.solve(rtol=1e-6, max_iter=maxit, raise_on_noconv=False)
         self.iteration = st["iterations"]
         info = 0 if st["converged"] else 1

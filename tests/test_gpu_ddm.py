@@ -90,3 +90,20 @@ def test_ddm_surrogate_kinds_on_a_graded_lattice(golden_dir, kind):
     Kff = K[np.ix_(order, order)]
     assert np.linalg.norm(Kff @ xsol - b) <= 1.05e-6 * np.linalg.norm(b)
     assert _rel(xsol, np.linalg.solve(Kff, b)) < 1e-3
+
+
+def test_presets_written_for_the_preconditioned_solver_still_converge(golden_dir, capsys):
+    """The reference's DDM presets enable its LU preconditioner and cap CG at a handful of iterations
+    (optimization_DDM_surrogate.json: 10).  The device runs plain CG instead: it must say so once and lift the cap."""
+    preset = json.loads(str(np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))["preset_json"]))
+    ddm = preset["simulation_parameters"]["DDM"]
+    ddm.update(enable_preconditioner=True, preconditioner_type="mean", max_iterations=10)
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    xsol, info, _, _ = L.solve_DDM()
+    L.solve_DDM()
+    assert info == 0 and L.iteration > 10 and _rel(xsol, g["xsol"]) < 1e-5
+    assert capsys.readouterr().out.count("not ported") == 1
+    ddm.pop("preconditioner_type")
+    with pytest.raises(ValueError):
+        LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
