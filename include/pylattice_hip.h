@@ -105,7 +105,8 @@ void pl_destroy(pl_handle h);
  * cell-boundary nodes; every cell c couples its nb boundary nodes cell_nodes[c*nb..] (order of
  * Cell.define_node_order_to_simulate, cell.py:611-680) through the dense Schur complement S[cell_S[c]] ((6nb)^2,
  * row-major).  The handle then serves pl_set_bc / pl_assemble / pl_spmv / pl_spmv_free / pl_solve / pl_reactions with
- * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (no preconditioner, as the reference) with opts->alpha_max. */
+ * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (opts->precond = 0, as the reference's default) or Jacobi-CG
+ * (opts->precond = 1, offered where the reference factorises the assembled matrix) with opts->alpha_max. */
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S, const double *S,
                   const int32_t *cell_S, const pl_opts_t *opts, pl_handle *out);
 

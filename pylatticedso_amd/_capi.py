@@ -145,8 +145,9 @@ class HipLattice:
         self.last_stats = None
 
     @classmethod
-    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1):
-        """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm)."""
+    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0):
+        """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm).  precond = 0: plain CG as the
+        reference's default; 1: Jacobi on the assembled diagonal."""
         self = cls.__new__(cls)
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -159,6 +160,7 @@ class HipLattice:
         opts = PlOpts()
         self._lib.pl_default_opts(C.byref(opts))
         opts.device, opts.alpha_max, opts.check_every = device, alpha_max, check_every
+        opts.precond = precond
         _check(self._lib, self._lib.pl_create_ddm(self.n_nodes, cn.shape[0], cn.shape[1], _ptr(cn), Sm.shape[0],
                                                   _ptr(Sm), _ptr(cs), C.byref(opts), C.byref(self._h)))
         self.last_stats = None

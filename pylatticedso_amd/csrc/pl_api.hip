@@ -898,7 +898,7 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIP(hipSetDevice(o->device));
   pl_context *c = new pl_context();
   c->opt = *o;
-  c->opt.precond = 0;
+  c->opt.precond = (o->precond == 1) ? 1 : 0;   // 1: Jacobi on the assembled Schur diagonal; else the reference's plain CG
   c->opkind = 1;
   c->N = n_nodes;
   c->B = 0;
@@ -1042,8 +1042,15 @@ int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_ns
 int pl_assemble(pl_handle h) {
   if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble: null handle");
   PL_HIP(hipSetDevice(h->opt.device));
-  if (h->opkind == 1) {   // DDM operator: nothing to build; no preconditioner (the reference runs plain CG here)
-    pl::launch_fill(h->N * 6, 1.0, h->diag.p, h->stream);
+  if (h->opkind == 1) {   // DDM operator: nothing to build; plain CG as the reference, or Jacobi if asked for
+    if (h->opt.precond == 1) {
+      PL_HIP(hipMemsetAsync(h->diag.p, 0, h->N * 6 * sizeof(double), h->stream));
+      const int64_t m = (int64_t)h->ddm_cells * h->ddm_nb * 6;
+      hipLaunchKernelGGL(pl::k_ddm_diag, dim3(grid_for(m)), dim3(pl::kBlock), 0, h->stream, h->ddm_cells, h->ddm_nb,
+                         h->ddm_cell_nodes.p, h->ddm_cell_S.p, h->ddm_St.p, h->diag.p);
+    } else {
+      pl::launch_fill(h->N * 6, 1.0, h->diag.p, h->stream);
+    }
     pl::launch_invert_diag(h->N * 6, h->diag.p, h->have_bc ? h->fixed.p : nullptr, h->dinv.p, h->stream);
     PL_HIP(hipStreamSynchronize(h->stream));
     h->ms_assembly = 0.0;

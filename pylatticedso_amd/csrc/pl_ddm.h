@@ -43,4 +43,18 @@ __global__ __launch_bounds__(kBlock) void k_ddm_apply(int64_t C, int nb, const i
   }
 }
 
+// diag(sum_c B_c^T S_c B_c): the Jacobi preconditioner offered in place of the reference's SuperLU factorisation of
+// the assembled Schur matrix (lattice_sim.py:1351-1415) when a preset enables the preconditioner.
+__global__ __launch_bounds__(kBlock) void k_ddm_diag(int64_t C, int nb, const int32_t *__restrict__ cell_nodes,
+                                                     const int32_t *__restrict__ cell_S,
+                                                     const double *__restrict__ St, double *__restrict__ diag) {
+  const int m = 6 * nb;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= C * m) return;
+  const int64_t c = e / m;
+  const int i = (int)(e - c * m);
+  const double *S = St + (size_t)cell_S[c] * m * m;
+  unsafeAtomicAdd(diag + 6 * (int64_t)cell_nodes[c * nb + i / 6] + i % 6, S[(size_t)i * m + i]);
+}
+
 }  // namespace pl

@@ -466,8 +466,11 @@ class LatticeSim:
                              "set_schur_complements()")
         if self._ddm_device is None:
             cb = self.cell_boundary_nodes()
+            # enable_preconditioner: the reference LU-factorises the assembled Schur matrix (lattice_sim.py:1351-1415);
+            # here the CG gets the Jacobi preconditioner of the same matrix instead (same solution, more iterations)
             self._ddm_device = HipLattice.ddm(self.max_index_boundary + 1, self.index_boundary[cb],
-                                              self.schur_complements, self.cell_schur_index)
+                                              self.schur_complements, self.cell_schur_index,
+                                              precond=1 if self.enable_preconditioner else 0)
         return self._ddm_device
 
     def solve_DDM(self):
@@ -478,9 +481,9 @@ class LatticeSim:
         if not self.domain_decomposition_solver:
             raise ValueError("LatticeSim was not created with enable_domain_decomposition_solver=True")
         if self.enable_preconditioner and not getattr(self, "_precond_note_done", False):
-            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not ported; running plain CG "
-                  "on the device to the same tolerance (max_iterations of the preset then only applies if larger "
-                  "than the unpreconditioned default)")
+            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not ported; running "
+                  "Jacobi-preconditioned CG on the device to the same tolerance (max_iterations of the preset then "
+                  "only applies if larger than the default of that solver)")
             self._precond_note_done = True
         dev = self.ddm_model()
         bn = self._boundary_nodes_by_index()

@@ -103,6 +103,7 @@ def test_presets_written_for_the_preconditioned_solver_still_converge(golden_dir
     xsol, info, _, _ = L.solve_DDM()
     L.solve_DDM()
     assert info == 0 and L.iteration > 10 and _rel(xsol, g["xsol"]) < 1e-5
+    assert L.iteration < int(g["iterations"])            # Jacobi on the assembled diagonal beats the plain CG count
     assert capsys.readouterr().out.count("not ported") == 1
     ddm.pop("preconditioner_type")
     with pytest.raises(ValueError):
