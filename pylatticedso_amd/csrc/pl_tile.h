@@ -222,8 +222,12 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
   }
 }
 
+// Workgroup size of the tile K*p.  Measured on the 50^3 Octet (256-node tiles): 128 / 256 / 384 / 512 / 640 / 768 / 1024
+// threads -> 45.9 / 40.6 / 39.7 / 36.2 / 47.8 / 42.8 / 55.0 us: with 512 a tile's ~1900 strut visits are 3-4 per thread, so a
+// workgroup lives half as long while 4 of them still fit a CU.
+constexpr int kTileBlock = 512;
 template <bool MASK, bool DOT, bool PAL>
-__global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
+__global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ home_ptr,
                                                       const int64_t *__restrict__ foreign_ptr,
                                                       const int32_t *__restrict__ foreign_idx,
@@ -233,24 +237,24 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
                                                       const double *__restrict__ x, double *__restrict__ y,
                                                       double *__restrict__ dot_out, int stride) {
   extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
-  __shared__ double red[kBlock / kWave];
+  __shared__ double red[kTileBlock / kWave];
   const unsigned t = xcd_block(blockIdx.x, gridDim.x);
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int nn = n1 - n0;
-  for (int i = threadIdx.x; i < 6 * stride; i += kBlock) ys[i] = 0.0;
+  for (int i = threadIdx.x; i < 6 * stride; i += kTileBlock) ys[i] = 0.0;
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 4
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys, stride);
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 4
-  for (int64_t k = f0 + threadIdx.x; k < f1; k += kBlock)
+  for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
     tile_strut<PAL>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys, stride);
   __syncthreads();
   double acc = 0.0;
   double2 *y2 = reinterpret_cast<double2 *>(y) + 3 * (int64_t)n0;
   const double2 *x2 = reinterpret_cast<const double2 *>(x) + 3 * (int64_t)n0;
-  for (int i = threadIdx.x; i < nn * 3; i += kBlock) {
+  for (int i = threadIdx.x; i < nn * 3; i += kTileBlock) {
     const int node = i / 3, part = i - 3 * node;
     double2 v = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
     if (MASK) {
@@ -265,7 +269,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
     }
   }
   if (DOT) {
-    const double s = block_sum(acc, red);
+    double s = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = 0.0;
+    if (threadIdx.x == 0)
+      for (int q = 0; q < kTileBlock / kWave; ++q) s += red[q];
     if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
   }
 }
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(const int32_t *__restrict_
 // pal != nullptr: `rec` is the palette table and pal[b] the strut's entry.
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
                              const uint8_t *fixedbits, const double *x, double *y, double *dot_dev, hipStream_t s) {
-  const dim3 g((unsigned)plan.n_tiles), blk(kBlock);
+  const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
