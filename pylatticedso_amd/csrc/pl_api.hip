@@ -541,11 +541,18 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
   }
   const double thresh = rtol * rtol * bb;
-  const int chunk = c->opt.check_every > 0 ? c->opt.check_every : 32;
+  // The host looks at the residual history every `chunk` iterations.  With the default (check_every = 0) the chunk
+  // adapts: 32 while far from the threshold, then what the observed decay rate predicts is still needed - a fixed
+  // chunk overshoots by 16 iterations on average, 8 % of a 200-iteration solve.  (Every rank of a multi-GPU run sees
+  // the same all-reduced history, hence takes the same decisions.)
+  const bool adaptive = c->opt.check_every <= 0;
+  const int chunk = adaptive ? 32 : c->opt.check_every;
   std::vector<double> h_hist(chunk);
-  int k = 0;
+  int k = 0, next = chunk;
+  double rr_prev = bb;
+  int k_prev = 0;
   while (k < max_iter) {
-    const int todo = std::min(chunk, max_iter - k);
+    const int todo = std::min(next, max_iter - k);
     for (int j = 0; j < todo; ++j) {
       rc = pcg_iteration(c, k + j);
       if (rc) return rc;
@@ -563,6 +570,17 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     }
     k += todo;
     if (st->converged) break;
+    if (adaptive) {
+      const double rr_end = h_hist[todo - 1];
+      next = chunk;
+      if (rr_end < rr_prev && rr_end > thresh) {
+        const double per_it = std::log(rr_end / rr_prev) / (double)(k - k_prev);      // < 0
+        const double need = std::log(thresh / rr_end) / per_it;
+        if (need < 2.0 * chunk) next = std::max(2, std::min(chunk, (int)std::ceil(0.75 * need)));
+      }
+      rr_prev = rr_end;
+      k_prev = k;
+    }
   }
   if (!st->converged) st->iterations = k;
   return PL_OK;
