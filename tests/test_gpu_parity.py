@@ -412,6 +412,37 @@ def test_full_size_properties_config3():
         assert np.all(u[fixed != 0] == 0.0)
 
 
+def test_two_rank_workload_emulated_on_one_gpu():
+    """The 2-GPU weak-scaling workload of bench.py (50 x 100 x 50 Octet, 6.05 M struts) solved on ONE GPU through the
+    multi-rank code path (single-rank RCCL communicator) with the slab interface plane declared shared, so that the
+    rank-local levels leave those nodes out exactly as two ranks would: same solution as the plain single-GPU solve,
+    and the iteration count DESIGN.md section 8 quotes for N = 2 (191; the all-reduced dense level is coarser than at
+    N = 1, 155)."""
+    from pylatticedso_amd import lattice_arrays as LA
+    lat = LA.generate((1, 1, 1), (50, 100, 50), ["Octet"], [0.03])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == 50.0
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    shared = np.flatnonzero(lat.node_xyz[:, 1] == 50.0)
+    assert len(shared) == 5101
+    out = []
+    for emulate in (False, True):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, palette=1) as dev:
+            if emulate:
+                dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            out.append(dev.solve(rtol=1e-8, max_iter=5000))
+    (u0, s0), (u1, s1) = out
+    assert s0["converged"] == 1 and s1["converged"] == 1
+    assert _rel(u1, u0) < 1e-6
+    assert s0["iterations"] <= 195 and s1["iterations"] <= 200          # measured: 188 and 191
+
+
 @pytest.mark.parametrize("name", ["bcc_4x4x4", "bcc_6x3x3_flexion"])
 def test_multilevel_preconditioners_same_solution(golden_dir, name):
     """precond = 2 (Jacobi + rigid-body coarse space) must give the same displacements as Jacobi-PCG."""
