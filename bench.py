@@ -221,9 +221,7 @@ def main():
                    "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
                                       3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)",
                                       4: "multi-level (Jacobi + tile blocks + rank-local dense level + all-reduced "
-                                         "dense rigid-body coarse space)",
-                                      5: "multi-level (Jacobi + octant blocks + tile blocks + dense rigid-body coarse "
-                                         "space)"}[args.precond],
+                                         "dense rigid-body coarse space)"}[args.precond],
                    "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond >= 2 else "")
                            + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
                    "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},

@@ -360,11 +360,6 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
                      c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                      reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
                      c->dist.active ? c->maskL.p : c->fixedbits.p, cs.Bt_inv);
-  if (cs.sub_level)
-    hipLaunchKernelGGL(pl::k_subtile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st,
-                       c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
-                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                       c->dist.active ? c->maskL.p : c->fixedbits.p, cs.sub_of_node.p, cs.Bs_inv);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -461,8 +456,7 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cs.ncp, cs.sub_level ? (const uint8_t *)cs.sub_of_node.p : (const uint8_t *)nullptr, cs.Bs_inv,
-                     cs.ysub);
+                     cs.ncp);
   if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
@@ -478,7 +472,7 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cl.ncp, cs.sub_level ? (const uint8_t *)cs.sub_of_node.p : (const uint8_t *)nullptr, cs.ysub);
+                     cl.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -870,10 +864,9 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
-  if (o->precond >= 2 && o->precond <= 5) {
-    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2..5 (multi-level) needs reorder = 1"));
+  if (o->precond >= 2 && o->precond <= 4) {
+    if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
     c->coarse.tile_level = (o->precond >= 3);
-    c->coarse.sub_level = (o->precond == 5);
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));

@@ -48,10 +48,6 @@ struct Coarse {
   bool tile_level = true;
   std::vector<int32_t> h_tile_start;
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
-  // sub-tile level (precond = 5): the eight octants of every brick as aggregates of their own, 6 x 6 blocks
-  bool sub_level = false;
-  TBuf<uint8_t> sub_of_node;                 // [N] octant of the node inside its brick
-  double *Bs_inv = nullptr, *ysub = nullptr; // [n_tiles*8*36], [n_tiles*8*6]
   // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
   // symmetric operator in every iteration, so rounding the Jacobi weights is free).  The node positions stay fp64:
   // the coarse modes must be EXACTLY rigid per aggregate - their energy is tiny next to ||K||, and a 1e-7 error in
@@ -64,7 +60,7 @@ struct Coarse {
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)Bs_inv, (void *)ysub})
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32})
       if (q) (void)hipFree(q);
   }
 };
@@ -113,6 +109,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) agg_of_node[i] = a;
   }
   {
+    (void)xyz_dev_order;
     if (hipMalloc((void **)&c.dinv32, (size_t)N * 6 * sizeof(float)) != hipSuccess) return 2;
   }
   c.n_agg = n_agg;
@@ -169,23 +166,6 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
   {
     c.h_tile_start = tile_start;
-    {
-      std::vector<uint8_t> sub(N);
-      for (int64_t i = 0; i < N; ++i) {
-        int o = 0;
-        for (int k = 0; k < 3; ++k) {
-          const double u = (xyz_dev_order[3 * i + k] - grid.lo[k]) / grid.side;
-          const double cell = std::max(0.0, std::min((double)(nbrick[k] - 1), std::floor(u)));
-          o = 2 * o + ((u - cell) >= 0.5 ? 1 : 0);
-        }
-        sub[i] = (uint8_t)o;
-      }
-      if (c.sub_of_node.upload(sub) != hipSuccess) return 1;
-      if (hipMalloc((void **)&c.Bs_inv, (size_t)T * 8 * 36 * sizeof(double)) != hipSuccess) return 2;
-      if (hipMalloc((void **)&c.ysub, (size_t)T * 8 * 6 * sizeof(double)) != hipSuccess) return 2;
-      if (hipMemset(c.Bs_inv, 0, (size_t)T * 8 * 36 * sizeof(double)) != hipSuccess) return 2;
-      if (hipMemset(c.ysub, 0, (size_t)T * 8 * 6 * sizeof(double)) != hipSuccess) return 2;
-    }
     if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
     if (hipMalloc((void **)&c.yt, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
     if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
@@ -516,75 +496,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
     for (int e = 0; e < 36; ++e) Bt_inv[(size_t)t * 36 + e] = M[e];
   }
 }
-// Sub-tile level: the same per octant of the brick.  One workgroup per tile, eight 6 x 6 blocks accumulated in LDS
-// (ds_add_f64: only struts that leave their octant or touch constrained dofs contribute), inverted by eight lanes.
-__global__ __launch_bounds__(kBlock) void k_subtile_blocks(const int32_t *__restrict__ tile_start,
-                                                           const int64_t *__restrict__ home_ptr,
-                                                           const int64_t *__restrict__ foreign_ptr,
-                                                           const int32_t *__restrict__ foreign_idx,
-                                                           const int2 *__restrict__ conn2, const Record *__restrict__ rec,
-                                                           const int32_t *__restrict__ agg_of_tile,
-                                                           const double *__restrict__ cen, const double *__restrict__ xyz,
-                                                           const uint8_t *__restrict__ fixedbits,
-                                                           const uint8_t *__restrict__ sub_of_node,
-                                                           double *__restrict__ Bs_inv) {
-  __shared__ double A[8 * 36];
-  const int t = blockIdx.x;
-  for (int e = threadIdx.x; e < 8 * 36; e += kBlock) A[e] = 0.0;
-  __syncthreads();
-  const int n0 = tile_start[t], n1 = tile_start[t + 1];
-  const int a = agg_of_tile[t];
-  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1], f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
-  const int64_t total = (h1 - h0) + (f1 - f0);
-  for (int64_t q = threadIdx.x; q < total; q += kBlock) {
-    const int64_t b = q < (h1 - h0) ? h0 + q : (int64_t)foreign_idx[f0 + (q - (h1 - h0))];
-    const int2 cn = conn2[b];
-    const bool ina = cn.x >= n0 && cn.x < n1, inb = cn.y >= n0 && cn.y < n1;
-    const int sa = ina ? sub_of_node[cn.x] : -1, sb = inb ? sub_of_node[cn.y] : -2;
-    const unsigned fa = fixedbits[cn.x], fb = fixedbits[cn.y];
-    if (sa == sb && fa == 0u && fb == 0u) continue;         // rigid motion of the whole strut
-    const Record r = load_record(rec, b);
-    const double rela[3] = {xyz[3 * (int64_t)cn.x] - c0, xyz[3 * (int64_t)cn.x + 1] - c1, xyz[3 * (int64_t)cn.x + 2] - c2};
-    const double relb[3] = {xyz[3 * (int64_t)cn.y] - c0, xyz[3 * (int64_t)cn.y + 1] - c1, xyz[3 * (int64_t)cn.y + 2] - c2};
-    double Kss[36], Kso[36], C[36];
-    if (inb) {
-      tip_blocks(r, Kss, Kso);                               // K_bb, K_ba
-      coarse_block(Kss, fb, fb, relb, relb, C);
-#pragma unroll
-      for (int e = 0; e < 36; ++e) unsafeAtomicAdd(A + 36 * sb + e, C[e]);
-      if (sa == sb) {
-        coarse_block(Kso, fb, fa, relb, rela, C);
-#pragma unroll
-        for (int e = 0; e < 36; ++e) unsafeAtomicAdd(A + 36 * sb + e, C[e]);
-      }
-    }
-    if (ina) {
-      tip_blocks(reversed(r), Kss, Kso);                     // K_aa, K_ab
-      coarse_block(Kss, fa, fa, rela, rela, C);
-#pragma unroll
-      for (int e = 0; e < 36; ++e) unsafeAtomicAdd(A + 36 * sa + e, C[e]);
-      if (sa == sb) {
-        coarse_block(Kso, fa, fb, rela, relb, C);
-#pragma unroll
-        for (int e = 0; e < 36; ++e) unsafeAtomicAdd(A + 36 * sa + e, C[e]);
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    double M[36];
-#pragma unroll
-    for (int e = 0; e < 36; ++e) M[e] = A[36 * threadIdx.x + e];
-    bool any = false;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) any = any || (M[7 * e] > 0.0);
-    if (any) spd6_inverse(M);
-#pragma unroll
-    for (int e = 0; e < 36; ++e) Bs_inv[((size_t)t * 8 + threadIdx.x) * 36 + e] = any ? M[e] : 0.0;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // x += alpha p ; r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
 // ---------------------------------------------------------------------------------------------------------------
@@ -608,14 +519,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const int32_t *__restrict__ aggL_of_tile /* may be null */,
                                                             const double *__restrict__ cenL,
                                                             const uint8_t *__restrict__ shared /* may be null */,
-                                                            double *__restrict__ rcL, int ncp,
-                                                            const uint8_t *__restrict__ sub_of_node /* may be null */,
-                                                            const double *__restrict__ Bs_inv,
-                                                            double *__restrict__ ysub) {
+                                                            double *__restrict__ rcL, int ncp) {
   __shared__ double red[20][kBlock / kWave];
-  __shared__ double sacc[8 * 6];             // sub-tile level: restriction of r per octant of the brick
-  if (sub_of_node && threadIdx.x < 48) sacc[threadIdx.x] = 0.0;
-  if (sub_of_node) __syncthreads();
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -683,15 +588,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
     }
-    if (sub_of_node && !(shared && shared[i])) {
-      double *q = sacc + 6 * sub_of_node[i];
-      unsafeAtomicAdd(q + 0, rv[0]);
-      unsafeAtomicAdd(q + 1, rv[1]);
-      unsafeAtomicAdd(q + 2, rv[2]);
-      unsafeAtomicAdd(q + 3, rv[3] + (ry * rv[2] - rz * rv[1]));
-      unsafeAtomicAdd(q + 4, rv[4] + (rz * rv[0] - rx * rv[2]));
-      unsafeAtomicAdd(q + 5, rv[5] + (rx * rv[1] - ry * rv[0]));
-    }
     if (own_t && !shared[i]) {
       accT[0] += rv[0];
       accT[1] += rv[1];
@@ -731,21 +627,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     }
   }
   __syncthreads();
-  if (sub_of_node && threadIdx.x >= 2 * kWave && threadIdx.x < 3 * kWave) {   // wave 2: eight 6 x 6 sub-tile solves
-    const int e = threadIdx.x - 2 * kWave;       // (octant, component) for e < 48
-    double v = 0.0;
-    if (e < 48) {
-      const int o = e / 6, k = e - 6 * o;
-      const double *Bi = Bs_inv + ((size_t)t * 8 + o) * 36 + 6 * k;
-      double y = 0.0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) y += Bi[j] * sacc[6 * o + j];
-      ysub[((size_t)t * 8 + o) * 6 + k] = y;
-      v = y * sacc[e];
-    }
-    v = wave_sum(v);                             // sum_o r_o . y_o joins r.D^-1 r
-    if (e == 0) unsafeAtomicAdd(rdr_slot, v);
-  }
   if (aggL_of_tile && threadIdx.x >= kWave && threadIdx.x < kWave + 6) {   // wave 1 publishes the local restriction
     const int k = threadIdx.x - kWave;
     double s = 0.0;
@@ -808,12 +689,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ cenL,
                                                                  const double *__restrict__ ycL,
                                                                  const uint8_t *__restrict__ shared /* may be null */,
-                                                                 double *__restrict__ rcL, int ncpL,
-                                                                 const uint8_t *__restrict__ sub_of_node /* may be null */,
-                                                                 const double *__restrict__ ysub) {
-  __shared__ double ys8[8 * 6];
-  if (sub_of_node && threadIdx.x < 48) ys8[threadIdx.x] = ysub[(size_t)blockIdx.x * 48 + threadIdx.x];
-  if (sub_of_node) __syncthreads();
+                                                                 double *__restrict__ rcL, int ncpL) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
@@ -862,15 +738,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
-    if (sub_of_node && !(shared && shared[i])) {
-      const double *S = ys8 + 6 * sub_of_node[i];
-      zc[0] += S[0] + (S[4] * rz - S[5] * ry);
-      zc[1] += S[1] + (S[5] * rx - S[3] * rz);
-      zc[2] += S[2] + (S[3] * ry - S[4] * rx);
-      zc[3] += S[3];
-      zc[4] += S[4];
-      zc[5] += S[5];
-    }
     if (own_t && !shared[i]) {
       zc[0] += T[0] + (T[4] * rz - T[5] * ry);
       zc[1] += T[1] + (T[5] * rx - T[3] * rz);

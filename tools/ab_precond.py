@@ -13,7 +13,7 @@ fixed = np.zeros((lat.n_nodes, 6), np.uint8); fixed[lat.node_xyz[:, 0] == 0.0] =
 tgt = lat.node_xyz[:, 0] == float(n)
 f = np.zeros((lat.n_nodes, 6)); f[tgt, 2] = -0.1 / tgt.sum()
 u0 = None
-for pc in (1, 2, 3, 4, 5):
+for pc in (1, 2, 3, 4):
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
                           precond=pc, tile_nodes=tn, coarse_max_dofs=cmax, local_max_dofs=cmaxL) as dev:
         if plane is not None:
