@@ -122,7 +122,10 @@ int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_ns
 
 /* Per-strut stiffness build ("assembly" of the matrix-free operator): condensed element records + the
  * preconditioner.  Replaces Material.compute_mechanical_properties + the FFCx element kernel
- * (material_definition.py:142-156, simulation_base.py:220-225). */
+ * (material_definition.py:142-156, simulation_base.py:220-225).
+ * Once pl_assemble_bsr has been called on the handle, pl_assemble also refreshes that explicit matrix (same with_bc):
+ * the fill runs on a second stream next to the factorisation of the coarse operator.  Collective on a multi-GPU
+ * handle (pl_dist_init): every rank must call it. */
 int pl_assemble(pl_handle h);
 
 /* Explicit global K as BSR(6x6) on the device (dolfinx assemble_matrix, simulation_base.py:473-476).
