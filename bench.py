@@ -195,6 +195,8 @@ def main():
     ms_iter = dev.time_kernel(3, 50)
     ms_rec = dev.time_kernel(1, 20)
     ms_bsr = dev.time_kernel(2, 10) if not args.no_bsr else None
+    # the two collectives of an iteration, alone (every rank makes the same calls; rank 0's clock is reported)
+    ms_coll = {"interface_allreduce": dev.time_kernel(5, 50), "coarse_allreduce": dev.time_kernel(6, 50)} if multi else None
     ab = dev.algorithmic_bytes()
     achieved = ab["spmv"] / (ms_spmv * 1e-3) / 1e9
     # HBM bytes per K*p launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
@@ -232,6 +234,8 @@ def main():
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"]},
     }
+    if ms_coll is not None:
+        out["collectives_ms"] = ms_coll
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol)
         out["cpu_baseline"] = cb

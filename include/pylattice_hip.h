@@ -167,7 +167,8 @@ int pl_get_records(pl_handle h, double *rec);
 
 /* Measurement hooks (bench.py): run `reps` launches of one kernel on the handle's stream between two HIP
  * events and return the average milliseconds.  which: 0 = K*p (PCG operator), 1 = record build,
- * 2 = BSR fill, 3 = one full PCG iteration, 4 = BSR SpMV. */
+ * 2 = BSR fill, 3 = one full PCG iteration, 4 = BSR SpMV; on a multi-GPU handle also 5 = the interface all-reduce of
+ * one K*p (staging kernels + RCCL) and 6 = the coarse-residual all-reduce - collective calls, every rank must make them. */
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
 /* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr. */
 int pl_algorithmic_bytes(pl_handle h, double *out3);

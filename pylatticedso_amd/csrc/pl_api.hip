@@ -1372,6 +1372,14 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
         hipLaunchKernelGGL(pl::k_bsr_spmv, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N,
                            h->bsr_rowptr.p, h->bsr_col.p, h->bsr_vals.p, h->p.p, h->Ap.p);
         return PL_OK;
+      case 5:   // multi-GPU: the interface all-reduce of a K*p alone (pack, RCCL, unpack) - collective call
+        if (!h->dist.active) return fail(PL_ERR_STATE, "pl_time_kernel: 5/6 need pl_dist_init");
+        return pl::dist_sum_shared(h->dist, h->Ap.p, h->stream, h->scal.p + pl::S_PAP * pl::kSlots, pl::kSlots)
+                   ? fail(PL_ERR_HIP, "RCCL all-reduce failed") : PL_OK;
+      case 6:   // multi-GPU: the coarse-residual all-reduce alone - collective call
+        if (!h->dist.active || !h->coarse.ready) return fail(PL_ERR_STATE, "pl_time_kernel: 6 needs a coarse level");
+        return pl::dist_sum_scalars(h->dist, h->coarse.tv, h->coarse.ncp, h->stream)
+                   ? fail(PL_ERR_HIP, "RCCL all-reduce failed") : PL_OK;
       default: return fail(PL_ERR_ARG, "pl_time_kernel: unknown kernel id");
     }
   };
