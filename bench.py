@@ -72,8 +72,8 @@ def cpu_baseline(cells, radius, rtol):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=50, help="cells per edge (per GPU along y)")
     ap.add_argument("--geom", default="Octet")
     ap.add_argument("--radius", type=float, default=0.03)
@@ -87,7 +87,8 @@ def main():
                     help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level, 4 = 3 + "
                          "rank-local dense level; 0 = 3")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
-    ap.add_argument("--cpu-cells", type=int, default=24, help="edge of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cells", type=int, default=36,
+                    help="edge of the CPU-baseline sample (0 = skip); 36 = 1.1 M struts, ~10-15 s on one core")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (slab build, RCCL communicator) even with one rank (rehearsal)")
