@@ -373,6 +373,11 @@ class LatticeSim:
         from ._capi import HipLattice
         if self._device is None:
             pen = self.penalized
+            if self.lattice.n_nodes >= 20000:
+                # large lattices: multi-level preconditioner + record palette (what bench.py measures); small ones
+                # converge in a few hundred Jacobi iterations and have too few nodes per tile for the coarse levels
+                kw.setdefault("precond", 3)
+                kw.setdefault("palette", 1)
             self._device = HipLattice(self.lattice.node_xyz, self.lattice.beam_conn, self.lattice.beam_radius,
                                       pen.seg_len, pen.seg_nsub, self.young_modulus, self.poisson_ratio,
                                       pen_coef=self.penalization_coefficient, **kw)
