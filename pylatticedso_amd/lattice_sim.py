@@ -351,21 +351,18 @@ class LatticeSim:
     # ------------------------------------------------------------------------------------------------
     def get_global_displacement(self, withFixed: bool = False, OnlyImposed: bool = False):
         """lattice_sim.py:502-542: free dofs of the cell-boundary nodes in visit order."""
-        disp, index = [], []
-        for n in self._boundary_visit_order:
-            for i in range(6):
-                free = not self.fixed_DOF[n, i]
-                if free and not OnlyImposed:
-                    disp.append(self.displacement_vector[n, i])
-                    index.append(int(self.index_boundary[n]))
-                elif free and self.applied_force[n, i] == 0:
-                    disp.append(0)
-                elif withFixed or OnlyImposed:
-                    disp.append(self.displacement_vector[n, i])
-                    index.append(int(self.index_boundary[n]))
+        V = np.asarray(self._boundary_visit_order, dtype=np.int64)
+        U, fixed = self.displacement_vector[V], self.fixed_DOF[V]
+        idx6 = np.repeat(self.index_boundary[V].astype(np.int64)[:, None], 6, axis=1)
+        if not OnlyImposed:                       # free dofs (+ the constrained ones if asked for), node-major
+            take = ~fixed | bool(withFixed)
+            disp, index = U[take], idx6[take].tolist()
+        else:                                     # every dof: 0 for unloaded free ones (no index entry for those)
+            silent = ~fixed & (self.applied_force[V] == 0)
+            disp, index = np.where(silent, 0.0, U).ravel(), idx6[~silent].tolist()
         if not OnlyImposed:
             self.global_displacement_index = index
-        return np.array(disp), index
+        return np.asarray(disp, dtype=float), index
 
     # ------------------------------------------------------------------------------------------------
     def device_model(self, **kw):
