@@ -385,12 +385,11 @@ class LatticeSim:
     # ------------------------------------------------------------------------------------------------
     def cell_boundary_nodes(self):
         """(C, n_b) node ids of every cell in the order of Cell.define_node_order_to_simulate (cell.py:611-680)."""
-        from .utils_schur import node_order_to_simulate
-        rows = [node_order_to_simulate(self, c) for c in range(self.lattice.n_cells)]
-        nb = {len(r) for r in rows}
-        if len(nb) != 1:
+        from .utils_schur import node_order_all_cells
+        rows = node_order_all_cells(self)
+        if rows is None:
             raise NotImplementedError("cells with different numbers of boundary nodes")
-        return np.asarray(rows, dtype=np.int64)
+        return rows
 
     def set_schur_complements(self, S, cell_index=None):
         """Install cell Schur complements: one (6n_b)^2 matrix for every cell, or a stack plus a per-cell index.

@@ -29,6 +29,32 @@ def node_order_to_simulate(lattice, cell_index=0, tol=1e-9):
     return np.asarray(ordered, dtype=np.int64)
 
 
+def node_order_all_cells(lattice, tol=1e-9):
+    """node_order_to_simulate for every cell at once: (C, n_b) node ids, or None when the cells do not all have the
+    same number of boundary nodes.  One lexsort over all (cell, node) pairs instead of a Python loop per cell."""
+    lat = lattice.lattice
+    C = lat.n_cells
+    cell = np.repeat(np.arange(C), np.diff(lat.cell_node_ptr))
+    nodes = lat.cell_node_idx
+    keep = lattice.index_boundary[nodes] >= 0
+    cell, nodes = cell[keep], nodes[keep]
+    counts = np.bincount(cell, minlength=C)
+    if C == 0 or not np.all(counts == counts[0]):
+        return None
+    xyz = lat.node_xyz[nodes]
+    lo = lat.cell_coord[cell]
+    hi = lo + lat.cell_size[cell]
+    on = np.stack([np.abs(xyz[:, 0] - lo[:, 0]) <= tol, np.abs(xyz[:, 0] - hi[:, 0]) <= tol,
+                   np.abs(xyz[:, 1] - lo[:, 1]) <= tol, np.abs(xyz[:, 1] - hi[:, 1]) <= tol,
+                   np.abs(xyz[:, 2] - lo[:, 2]) <= tol, np.abs(xyz[:, 2] - hi[:, 2]) <= tol], axis=1)
+    face = np.argmax(on, axis=1)
+    # in-plane sort keys of the six faces: (y, z, x), (y, z, x), (x, z, y), (x, z, y), (x, y, z), (x, y, z)
+    perm = np.array([[1, 2, 0], [1, 2, 0], [0, 2, 1], [0, 2, 1], [0, 1, 2], [0, 1, 2]])[face]
+    k = np.take_along_axis(xyz, perm, axis=1)
+    order = np.lexsort((k[:, 2], k[:, 1], k[:, 0], face, cell))
+    return nodes[order].reshape(C, counts[0]).astype(np.int64)
+
+
 def get_schur_complement(lattice, cell_index=None, rtol=1e-13, max_iter=200000):
     """S = K_BB - K_BI K_II^-1 K_IB of one cell on its boundary nodes, (6 n_b, 6 n_b), node order as the reference."""
     if cell_index is None and lattice.get_number_cells() > 1:
