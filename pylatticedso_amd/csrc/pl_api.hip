@@ -451,8 +451,8 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
   hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->p.p, c->Ap.p, cs.dinv32,
-                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->x.p, c->r.p, cur,
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->Ap.p, cs.dinv32,
+                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->r.p, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
@@ -468,7 +468,8 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                     (const double *)nullptr, c->stream);
   hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
                      c->tile.tile_start.p, c->r.p, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
-                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, cur, nxt,
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, c->x.p, cur,
+                     nxt,
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,

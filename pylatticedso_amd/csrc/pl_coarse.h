@@ -13,10 +13,10 @@
 //
 // Per iteration (all device-side, no host round trip):
 //   K*p (+ p.Ap)                                                            k_spmv_tile
-//   x += a p, r -= a Ap, r_c += Z^T r (tile partial sums, atomics), r.r, r.D^-1 r,
+//   r -= a Ap, r_c += Z^T r (tile partial sums, atomics), r.r, r.D^-1 r,
 //   y_t = B_t^-1 Z_t^T r and r.D^-1 r += r_t.y_t (tile level)                k_pcg_update_tile
 //   y_c = A_c^-1 r_c, r.z = r.D^-1 r + r_c.y_c                              k_tri_gemv, k_tri_gemv_t
-//   p = D^-1 r + P Z (y_c + y_t) + beta p  (z is never stored)              k_pcg_direction_coarse
+//   x += a p; p = D^-1 r + P Z (y_c + y_t) + beta p  (z is never stored)    k_pcg_direction_coarse
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
   }
 }
 // ---------------------------------------------------------------------------------------------------------------
-// x += alpha p ; r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
+// r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__restrict__ x, float *__restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -508,11 +508,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
                                                             const double *__restrict__ xyz,
-                                                            const double *__restrict__ p,
                                                             const double *__restrict__ Ap,
                                                             const float *__restrict__ dinv32,
                                                             const double *__restrict__ w /* may be null */,
-                                                            double *__restrict__ x, double *__restrict__ r,
+                                                            double *__restrict__ r,
                                                             double *__restrict__ scal, double *__restrict__ rc,
                                                             const double *__restrict__ Bt_inv /* may be null */,
                                                             double *__restrict__ yt,
@@ -546,30 +545,23 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   double accT[6] = {0, 0, 0, 0, 0, 0};      // tile level on several GPUs: the tile's restriction without shared nodes
   const bool own_t = Bt_inv && shared;
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
-    double pv[6], av[6], dv[6], xv[6], rv[6];
-    const double2 *p2 = reinterpret_cast<const double2 *>(p + 6 * (int64_t)i);
+    // (x += alpha p is done by k_pcg_direction_coarse, which reads p anyway: one vector pass less per iteration)
+    double av[6], dv[6], rv[6];
     const double2 *a2 = reinterpret_cast<const double2 *>(Ap + 6 * (int64_t)i);
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
-    double2 *x2 = reinterpret_cast<double2 *>(x + 6 * (int64_t)i);
     double2 *r2 = reinterpret_cast<double2 *>(r + 6 * (int64_t)i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double2 pp = p2[k], aa = a2[k], xx = x2[k], rr = r2[k];
+      const double2 aa = a2[k], rr = r2[k];
       const float2 dd = d2[k];
-      pv[2 * k] = pp.x; pv[2 * k + 1] = pp.y; av[2 * k] = aa.x; av[2 * k + 1] = aa.y;
-      dv[2 * k] = dd.x; dv[2 * k + 1] = dd.y; xv[2 * k] = xx.x; xv[2 * k + 1] = xx.y;
+      av[2 * k] = aa.x; av[2 * k + 1] = aa.y;
+      dv[2 * k] = dd.x; dv[2 * k + 1] = dd.y;
       rv[2 * k] = rr.x; rv[2 * k + 1] = rr.y;
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      xv[k] += alpha * pv[k];
-      rv[k] -= alpha * av[k];
-    }
+    for (int k = 0; k < 6; ++k) rv[k] -= alpha * av[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      x2[k] = {xv[2 * k], xv[2 * k + 1]};
-      r2[k] = {rv[2 * k], rv[2 * k + 1]};
-    }
+    for (int k = 0; k < 3; ++k) r2[k] = {rv[2 * k], rv[2 * k + 1]};
     double wt[6] = {1, 1, 1, 1, 1, 1};
     if (w) {
 #pragma unroll
@@ -680,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ yc,
                                                                  const double *__restrict__ yt /* may be null */,
                                                                  const uint8_t *__restrict__ fixedbits,
-                                                                 double *__restrict__ p,
+                                                                 double *__restrict__ p, double *__restrict__ x,
                                                                  const double *__restrict__ scal,
                                                                  double *__restrict__ scal_next,
                                                                  double *__restrict__ hist, int k,
@@ -692,6 +684,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  double *__restrict__ rcL, int ncpL) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
+  const double pap = scalar_read(scal, S_PAP);
+  const double alpha = (pap != 0.0) ? old / pap : 0.0;      // the step k_pcg_update_tile took: x += alpha p_old here
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
     for (int e = threadIdx.x; e < ncp; e += kBlock) rc[e] = 0.0;
   if (aggL_of_tile && (blockIdx.x == 2 || gridDim.x <= 2))
@@ -759,11 +753,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);
     double2 *p2 = reinterpret_cast<double2 *>(p + 6 * i);
+    double2 *x2 = reinterpret_cast<double2 *>(x + 6 * i);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const double2 rr = r2[q];
       const float2 dd = d2[q];
       double2 pp = p2[q];
+      double2 xx = x2[q];
+      xx.x += alpha * pp.x;
+      xx.y += alpha * pp.y;
+      x2[q] = xx;
       const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
       const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);
       pp.x = z0 + beta * pp.x;
