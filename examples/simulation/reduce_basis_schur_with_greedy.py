@@ -13,6 +13,10 @@ name_file = "simulation/hybrid_cell_simulation"
 tolerance_greedy = 1e-3
 
 lattice_Sim_object = LatticeSim(name_file)
-schur_data = load_schur_complement_dataset(lattice_Sim_object)
+try:
+    schur_data = load_schur_complement_dataset(lattice_Sim_object)
+except FileNotFoundError as err:
+    sys.exit(f"{err}\nNo Schur-complement dataset for this preset yet: run "
+             "examples/simulation/construct_schur_complement_dataset.py first.")
 file_name = find_name_file_reduced_basis(lattice_Sim_object, tol_greedy=tolerance_greedy)
 reduce_basis_greedy(schur_data, tolerance_greedy, file_name)
