@@ -20,6 +20,9 @@ What each function follows (paths relative to the reference repo):
 * ``schur_complement``       src/pyLatticeSim/schur_complement.py:75-147
 * ``solve_dirichlet``        src/pyLatticeSim/simulation_base.py:465-514 (assemble with bcs, lifting, point loads, LU)
 * ``reference_cg``           src/pyLatticeSim/conjugate_gradient_solver.py:15-122
+* ``submesh_vertices`` / ``homogenize_submeshed``  src/pyLatticeSim/homogenization_cell.py:112-147,200-252,
+                             309-331,367-376,405-436 (PARITY UNPINNED: no committed homogenisation output in the
+                             reference and dolfinx_mpc is absent; checked against closed forms in tests/ instead)
 * ``condensed_beam`` / ``beam_matrix``  closed-form static condensation of the above (derivation in DESIGN.md §3)
 """
 from __future__ import annotations
@@ -269,6 +272,78 @@ def beam_apply(scalars, d, xa, xb):
     FA = -FB
     MA = -MB - np.cross(d, FB)
     return np.r_[FA, MA], np.r_[FB, MB]
+
+
+# --------------------------------------------------------------------------------------------
+# periodic homogenisation of one cell on the sub-meshed model
+# --------------------------------------------------------------------------------------------
+CORNER_TAGS = [[1000, 1001, 1002, 1003, 1004, 1005, 1006, 1007]]                       # lattice.py:612-614
+EDGE_TAGS = [[102, 104, 106, 107], [100, 108, 105, 111], [101, 109, 103, 110]]
+FACE_TAGS = [[10, 15], [11, 14], [12, 13]]
+
+
+def submesh_vertices(node_xyz, seg_conn, h):
+    """Coordinates of every vertex of ``assemble_submeshed``'s mesh, in its numbering."""
+    node_xyz = np.asarray(node_xyz, float)
+    out = [node_xyz]
+    for ia, ib in np.asarray(seg_conn):
+        xa, xb = node_xyz[ia], node_xyz[ib]
+        n = gmsh_subdivisions(float(np.linalg.norm(xb - xa)), h)
+        if n > 1:
+            out.append(xa + (xb - xa) * (np.arange(1, n) / n)[:, None])
+    return np.vstack(out)
+
+
+def homogenize_submeshed(K, vert_xyz, node_tag):
+    """6x6 ``homogenizeMatrix`` of one cell, following HomogenizedCell step by step on the sub-meshed K.
+
+    ``node_tag[i]`` = Point.tag of lattice node i (vertices beyond ``len(node_tag)`` are sub-mesh vertices and carry
+    none).  Periodic groups by boundary tag with the first tag of each group as master (:210-252); translations of the
+    vertex at the mean of the mesh coordinates fixed when there is one (:335-376) - otherwise the first lattice node,
+    where the reference would be left with a singular matrix; load case k: -K w_k (:200-206); macro stress =
+    sum over tagged nodes of (K u_tot)[:3] (x) r (:309-331); rows [00, 11, 22, 10, 20, 21]; symmetrised (:435).
+    Returns (C, C_unsymmetrised, [u_tot of the six cases, (n_vertices, 6)])."""
+    vert_xyz = np.asarray(vert_xyz, float)
+    nv = len(vert_xyz)
+    tag = np.asarray(node_tag)
+    master = np.arange(nv)
+    for group in CORNER_TAGS + EDGE_TAGS + FACE_TAGS:
+        m = np.flatnonzero(tag == group[0])
+        for t in group[1:]:
+            s_ = np.flatnonzero(tag == t)
+            if len(m) and len(s_):
+                assert len(m) == len(s_) == 1, "one node per boundary tag (what the reference's pairing supports)"
+                master[s_[0]] = m[0]
+    reps = np.unique(master)
+    slot = np.full(nv, -1)
+    slot[reps] = np.arange(len(reps))
+    cols = (6 * slot[master][:, None] + np.arange(6)).ravel()
+    P = sp.csr_matrix((np.ones(6 * nv), (np.arange(6 * nv), cols)), shape=(6 * nv, 6 * len(reps)))
+    centre = vert_xyz.mean(axis=0)
+    hit = np.flatnonzero(np.all(np.abs(vert_xyz - centre) <= 1e-6, axis=1))
+    anchor = int(hit[0]) if len(hit) else 0
+    fixed = 6 * slot[master[anchor]] + np.arange(3)
+    free = np.setdiff1d(np.arange(P.shape[1]), fixed)
+    Kr = (P.T @ K @ P).tocsc()
+    lu = spla.splu(Kr[free][:, free].tocsc())
+    boundary = np.flatnonzero(tag > 0)
+    x, y, z = vert_xyz.T
+    zero = np.zeros(nv)
+    fields = [(x, zero, zero), (zero, y, zero), (zero, zero, z), (y, x, zero), (z, zero, x), (zero, z, y)]
+    cols_C, u_tots = [], []
+    for wx, wy, wz in fields:
+        w = np.zeros((nv, 6))
+        w[:, 0], w[:, 1], w[:, 2] = wx, wy, wz
+        b = -(P.T @ (K @ w.ravel()))
+        ur = np.zeros(P.shape[1])
+        ur[free] = lu.solve(b[free])
+        u_tot = w + (P @ ur).reshape(nv, 6)
+        R = (K @ u_tot.ravel()).reshape(nv, 6)
+        macro = R[boundary, :3].T @ vert_xyz[boundary]
+        cols_C.append([macro[0, 0], macro[1, 1], macro[2, 2], macro[1, 0], macro[2, 0], macro[2, 1]])
+        u_tots.append(u_tot)
+    C_raw = np.array(cols_C).T
+    return 0.5 * (C_raw + C_raw.T), C_raw, u_tots
 
 
 # --------------------------------------------------------------------------------------------

@@ -81,3 +81,19 @@ def solve_FEM_FenicsX(lattice, rtol=DEFAULT_RTOL, max_iter=DEFAULT_MAX_ITER):
     model.set_reaction_force_on_lattice_with_FEM_results()
     xsol, _ = lattice.get_global_displacement()
     return xsol, model
+
+
+def get_homogenized_properties(lattice):
+    """Periodic homogenisation of a one-cell lattice (utils_simulation.py:83-119): returns the orthotropic compliance
+    matrix and the analysis object (``homogenizeMatrix``, ``orthotropicMatrix``, ``saveDataToExport`` ...)."""
+    from .homogenization_cell import HomogenizedCell
+    if lattice.get_number_cells() > 1:
+        raise ValueError("The lattice must contain only one cell for homogenization.")
+    analysis = HomogenizedCell(lattice)
+    analysis.prepare_simulation()
+    analysis.apply_dirichlet_for_homogenization()
+    analysis.periodic_boundary_condition()
+    analysis.solve_full_homogenization()
+    analysis.print_homogenized_matrix()
+    analysis.print_errors()
+    return analysis.get_S_orthotropic(), analysis

@@ -17,10 +17,19 @@ class exportSimulationResults:
         self._fields["displacement"] = np.asarray(self.model.u)[:, :3]
         self._fields["rotation"] = np.asarray(self.model.u)[:, 3:]
 
-    def export_finalize(self):
+    def export_data_homogenization(self, homogenization_surface: bool = True):
+        """One file per macro-strain case with the total displacement field (reference :197-230; the polar stiffness
+        surface goes through gmsh there and is not written here)."""
+        paths = []
+        for case, u_tot in enumerate(self.model.saveDataToExport):
+            self._fields = {"Displacement": np.asarray(u_tot)[:, :3], "Rotation": np.asarray(u_tot)[:, 3:]}
+            paths.append(self.export_finalize(suffix=f"_case{case + 1}"))
+        return paths
+
+    def export_finalize(self, suffix=""):
         lat = self.model.lattice.lattice
         os.makedirs(self.out_dir, exist_ok=True)
-        path = os.path.join(self.out_dir, f"{self.name}.vtk")
+        path = os.path.join(self.out_dir, f"{self.name}{suffix}.vtk")
         with open(path, "w") as fh:
             fh.write("# vtk DataFile Version 3.0\npylattice-mi355x result\nASCII\nDATASET POLYDATA\n")
             fh.write(f"POINTS {lat.n_nodes} double\n")

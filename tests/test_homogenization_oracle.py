@@ -1,0 +1,88 @@
+"""Oracle's periodic homogenisation (oracle.homogenize_submeshed, restating homogenization_cell.py) against closed
+forms and invariants.  The reference commits no homogenisation output and cannot run here (dolfinx_mpc), so these
+closed forms are what anchors the oracle; tests/test_gpu_homogenization.py then holds the device path to the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import timoshenko_oracle as O
+
+E, NU = 1013.0, 0.3
+
+
+def _simple_cubic(r, h=0.05):
+    """One cell whose 12 edges are struts of radius r (un-penalised), corners tagged as Point.tag_point does."""
+    corners = np.array([[i, j, k] for i in (0.0, 1.0) for j in (0.0, 1.0) for k in (0.0, 1.0)])
+    segs = [(a, b) for a in range(8) for b in range(a + 1, 8) if np.abs(corners[a] - corners[b]).sum() == 1.0]
+    tags = np.arange(1000, 1008)
+    K, nv = O.assemble_submeshed(corners, np.array(segs), np.full(len(segs), r), E, NU, h)
+    V = O.submesh_vertices(corners, np.array(segs), h)
+    assert len(V) == nv
+    return K, V, tags
+
+
+def test_simple_cubic_cell_has_the_closed_form_moduli():
+    r = 0.04
+    K, V, tags = _simple_cubic(r)
+    C, C_raw, _ = O.homogenize_submeshed(K, V, tags)
+    EA = E * np.pi * r ** 2
+    # four struts along every axis, uniform axial strain, no Poisson coupling between orthogonal struts
+    assert np.allclose(np.diag(C)[:3], 4 * EA, rtol=1e-11)
+    off = C - np.diag(np.diag(C))
+    assert np.abs(off).max() < 1e-9 * EA
+    # tensorial shear strain 1 (gamma = 2): every strut of the two families sees a unit relative transverse
+    # displacement with clamped-clamped ends (the shared periodic joint cannot rotate by symmetry):
+    # sigma_xy = 4 * 12 EI / (L^3 (1 + Phi)),  Phi = 12 EI / (kappa G A L^2)  (the four struts normal to the face)
+    EI = E * np.pi * r ** 4 / 4
+    GA = O.KAPPA * E / (2 * (1 + NU)) * np.pi * r ** 2
+    shear = 4 * 12 * EI / (1 + 12 * EI / GA)
+    assert np.allclose(np.diag(C)[3:], shear, rtol=5e-3)          # P1 sub-elements: O(h^2) off the exact beam
+    assert np.linalg.norm(C_raw - C_raw.T) < 1e-10 * np.linalg.norm(C)
+
+
+@pytest.mark.parametrize("name", ["bcc", "hybrid4"])
+def test_reference_cells_cubic_symmetry_and_hill_mandel(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"lattice_{name}_1x1x1_periodic.npz"))
+    keep = ~g["beam_dup"]
+    K, nv = O.assemble_submeshed(g["node_xyz"], g["beam_conn"][keep], g["beam_radius"][keep], E, NU, 0.05)
+    V = O.submesh_vertices(g["node_xyz"], g["beam_conn"][keep], 0.05)
+    C, C_raw, u_tots = O.homogenize_submeshed(K, V, g["node_tag"])
+    assert np.linalg.norm(C_raw - C_raw.T) < 1e-10 * np.linalg.norm(C)
+    assert np.linalg.eigvalsh(C).min() > 0
+    # cubic material: three independent constants
+    assert np.allclose(np.diag(C)[:3], C[0, 0], rtol=1e-10) and np.allclose(np.diag(C)[3:], C[3, 3], rtol=1e-10)
+    assert np.allclose([C[0, 1], C[0, 2], C[1, 2]], C[0, 1], rtol=1e-10)
+    assert np.abs(C[:3, 3:]).max() < 1e-9 * C[0, 0]
+    # Hill-Mandel: boundary-reaction stresses == strain-energy products of the total fields (shear rows: eps_ij and
+    # eps_ji both work, hence the factor 2)
+    en = np.array([[u_tots[i].ravel() @ (K @ u_tots[j].ravel()) for j in range(6)] for i in range(6)])
+    scale = np.array([1, 1, 1, 2, 2, 2.0])
+    assert np.allclose(en, C * scale[:, None], rtol=1e-9, atol=1e-9 * C[0, 0])
+
+
+@pytest.mark.parametrize("name", ["bcc", "hybrid1", "hybrid4"])
+def test_periodic_partners_by_coordinates_reproduce_the_tag_groups(golden_dir, name):
+    """Host mirror: nodes matched modulo the cell size fall into the reference's corner / edge / face tag groups."""
+    from pylatticedso_amd.homogenization_cell import imposed_displacement, periodic_masters
+    g = np.load(os.path.join(golden_dir, f"lattice_{name}_1x1x1_periodic.npz"))
+    xyz, tag = g["node_xyz"], g["node_tag"]
+    master, boundary = periodic_masters(xyz, np.zeros(3), np.ones(3))
+    assert np.array_equal(boundary, tag > 0)
+    assert np.array_equal(master[~boundary], np.flatnonzero(~boundary))
+    for group in O.CORNER_TAGS + O.EDGE_TAGS + O.FACE_TAGS:
+        members = np.flatnonzero(np.isin(tag, group))
+        if len(members):
+            m = np.flatnonzero(tag == group[0])
+            assert len(m) == 1 and np.all(master[members] == m[0])
+    # the six macro strains: symmetric gradient of w_k is the k-th unit strain (shear tensorial)
+    w = np.stack([imposed_displacement(k, xyz)[:, :3] for k in range(1, 7)])
+    A = np.c_[xyz, np.ones(len(xyz))]
+    for k, (i, j) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+        grad = np.linalg.lstsq(A, w[k], rcond=None)[0][:3].T          # d w_a / d x_b
+        eps = 0.5 * (grad + grad.T)
+        expect = np.zeros((3, 3))
+        expect[i, j] = expect[j, i] = 1.0
+        assert np.allclose(eps, expect, atol=1e-12)
+    with pytest.raises(ValueError):
+        imposed_displacement(7, xyz)
