@@ -105,10 +105,24 @@ void pl_destroy(pl_handle h);
  * cell-boundary nodes; every cell c couples its nb boundary nodes cell_nodes[c*nb..] (order of
  * Cell.define_node_order_to_simulate, cell.py:611-680) through the dense Schur complement S[cell_S[c]] ((6nb)^2,
  * row-major).  The handle then serves pl_set_bc / pl_assemble / pl_spmv / pl_spmv_free / pl_solve / pl_reactions with
- * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (opts->precond = 0, as the reference's default) or Jacobi-CG
- * (opts->precond = 1, offered where the reference factorises the assembled matrix) with opts->alpha_max. */
+ * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (opts->precond = 0, as the reference's default), Jacobi-CG
+ * (opts->precond = 1) or CG preconditioned by the factorised assembled matrix (opts->precond = 2, below), with
+ * opts->alpha_max. */
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S, const double *S,
                   const int32_t *cell_S, const pl_opts_t *opts, pl_handle *out);
+
+/* The reference's preconditioner of the DDM solve (LatticeSim.define_preconditioner / build_preconditioner,
+ * lattice_sim.py:1333-1415; Cell.build_coupling_operator / build_local_preconditioner, cell.py:754-827):
+ * G = sum_c B_c^T Shat_c B_c on the free dofs, factorised once (SuperLU there; dense Cholesky + explicit inverse
+ * factor on the device here, so 6 n_nodes <= PL_DDM_DENSE_MAX), z = G^-1 r per iteration.  Selected by
+ * opts->precond = 2 at pl_create_ddm; pl_assemble builds and factorises G for the current Dirichlet mask.
+ * Shat_c defaults to the operator's own matrices (preconditioner_type "exact": CG converges in one step); this call
+ * installs another palette - one mean matrix ("mean"), or the dataset matrices with the nearest-radius index per
+ * cell ("nearest_reference").  S = NULL goes back to the default.  Returns PL_ERR_STATE from pl_assemble when G is
+ * not positive definite. */
+#define PL_DDM_DENSE_MAX 16384
+int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/,
+                              const int32_t *cell_S /*[n_cells]*/);
 
 /* Dirichlet / load data per dof.  fixed[6N] (0/1), ubar[6N] prescribed values (read where fixed), f[6N] nodal
  * loads.  Replaces apply_displacement_all_nodes_with_lattice_data / apply_force_on_all_nodes_with_lattice_data

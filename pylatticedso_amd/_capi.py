@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libpylattice_hip.so")
 PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
-EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_create_ddm", "pl_destroy", "pl_set_bc",
+EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_create_ddm",
+           "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
@@ -68,7 +69,8 @@ def load_library(path: str | None = None):
     lib.pl_destroy.restype = None
     lib.pl_default_opts.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
-    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
+    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
+           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
            "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
@@ -147,7 +149,8 @@ class HipLattice:
     @classmethod
     def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0):
         """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm).  precond = 0: plain CG as the
-        reference's default; 1: Jacobi on the assembled diagonal."""
+        reference's default; 1: Jacobi on the assembled diagonal; 2: the reference's factorised assembled matrix
+        (of the operator's own cell matrices unless ``set_ddm_preconditioner`` installs others)."""
         self = cls.__new__(cls)
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -164,7 +167,23 @@ class HipLattice:
         _check(self._lib, self._lib.pl_create_ddm(self.n_nodes, cn.shape[0], cn.shape[1], _ptr(cn), Sm.shape[0],
                                                   _ptr(Sm), _ptr(cs), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
+        self._n_cells, self._m = cn.shape[0], 6 * cn.shape[1]
         return self
+
+    def set_ddm_preconditioner(self, S=None, cell_S=None):
+        """Cell matrices of the assembled-Schur preconditioner (pl_ddm_set_preconditioner); None = the operator's."""
+        if S is None:
+            _check(self._lib, self._lib.pl_ddm_set_preconditioner(self._h, 0, None, None))
+            return
+        Sm = np.ascontiguousarray(S, dtype=np.float64)
+        if Sm.ndim == 2:
+            Sm = Sm[None]
+        if Sm.shape[1:] != (self._m, self._m):
+            raise ValueError(f"preconditioner matrices must be {self._m} x {self._m}, got {Sm.shape[1:]}")
+        cs = (np.zeros(self._n_cells, np.int32) if cell_S is None else np.ascontiguousarray(cell_S, dtype=np.int32))
+        if cs.shape != (self._n_cells,):
+            raise ValueError("one preconditioner matrix index per cell expected")
+        _check(self._lib, self._lib.pl_ddm_set_preconditioner(self._h, Sm.shape[0], _ptr(Sm), _ptr(cs)))
 
     # -- lifetime ---------------------------------------------------------------------------------------
     def close(self):

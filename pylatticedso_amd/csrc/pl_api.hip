@@ -111,6 +111,14 @@ struct pl_context {
   int ddm_nb = 0;
   DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
   DevBuf<double> ddm_St;
+  // assembled-Schur preconditioner of the DDM operator (opt.precond = 2): optional palette of its own + dense factor
+  DevBuf<int32_t> ddm_cell_P;
+  DevBuf<double> ddm_Pt;
+  bool ddm_have_P = false;
+  DevBuf<double> dd_A, dd_Lf, dd_W, dd_Wt, dd_Dinv, dd_tv;
+  DevBuf<int> dd_info;
+  int dd_n = 0;          // padded order of the dense matrix (0: not allocated)
+  bool dd_ready = false;
   // record palette (pl_palette.h)
   DevBuf<unsigned long long> pal_keys;
   DevBuf<int> pal_owner, pal_flags;
@@ -486,6 +494,16 @@ int pcg_iteration(pl_context *c, int k) {
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
   if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
+  if (c->dd_ready) {   // DDM with the factorised assembled matrix: update leaves z = 0, r.z = 0; then z = G^-1 r
+    hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max);
+    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
+                    cur + pl::S_RZ_NEW * pl::kSlots, (const double *)nullptr, c->stream);
+    hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
+                       c->p.p, cur, nxt, c->hist.p, k);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
   if (c->dist.active) {
     pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
                                    c->stream);
@@ -517,6 +535,11 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   if (c->dist.active) {
     pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream);
     pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream);
+  }
+  if (c->dd_ready) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
+    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
+                    c->scal.p + pl::S_RZ_OLD * pl::kSlots, (const double *)nullptr, c->stream);
+    PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   if (c->coarse.ready) {
     // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
@@ -917,7 +940,14 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIP(hipSetDevice(o->device));
   pl_context *c = new pl_context();
   c->opt = *o;
-  c->opt.precond = (o->precond == 1) ? 1 : 0;   // 1: Jacobi on the assembled Schur diagonal; else the reference's plain CG
+  // 0: the reference's plain CG; 1: Jacobi on the assembled Schur diagonal; 2: the reference's own preconditioner, the
+  // factorised assembled Schur matrix (dense Cholesky on the device, hence the size limit)
+  c->opt.precond = (o->precond == 1 || o->precond == 2) ? o->precond : 0;
+  if (c->opt.precond == 2 && 6 * n_nodes > PL_DDM_DENSE_MAX) {
+    delete c;
+    return fail(PL_ERR_ARG, "pl_create_ddm: precond = 2 factorises a dense (6 n_nodes)^2 matrix; limit is " +
+                                std::to_string(PL_DDM_DENSE_MAX) + " dofs (use precond = 1)");
+  }
   c->opkind = 1;
   c->N = n_nodes;
   c->B = 0;
@@ -958,8 +988,11 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(c->fixedbits.alloc(n_nodes));
   PL_HIPC(c->ubar.alloc(n6));
   PL_HIPC(c->f.alloc(n6));
-  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
-    PL_HIPC(v->alloc(n6));
+  // (vectors padded to the block size of the dense solver and zeroed: its GEMVs read / write whole blocks)
+  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2}) {
+    PL_HIPC(v->alloc(n6 + pl::kNB));
+    PL_HIPC(hipMemset(v->p, 0, (n6 + pl::kNB) * sizeof(double)));
+  }
   PL_HIPC(c->scal.alloc(2 * pl::S_COUNT * pl::kSlots));
   PL_HIPC(hipMemset(c->fixed.p, 0, n6));
   PL_HIPC(hipMemset(c->fixedbits.p, 0, n_nodes));
@@ -968,6 +1001,71 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(hipDeviceSynchronize());
 #undef PL_HIPC
   *out = c;
+  return PL_OK;
+}
+
+int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S, const int32_t *cell_S) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_ddm_set_preconditioner: null handle");
+  if (h->opkind != 1) return fail(PL_ERR_STATE, "pl_ddm_set_preconditioner: not a DDM handle");
+  PL_HIP(hipSetDevice(h->opt.device));
+  h->assembled = false;
+  if (!S) {   // back to the operator's own matrices
+    h->ddm_have_P = false;
+    return PL_OK;
+  }
+  if (n_S <= 0 || !cell_S) return fail(PL_ERR_ARG, "pl_ddm_set_preconditioner: bad argument");
+  for (int64_t c = 0; c < h->ddm_cells; ++c)
+    if (cell_S[c] < 0 || cell_S[c] >= n_S) return fail(PL_ERR_ARG, "pl_ddm_set_preconditioner: matrix id out of range");
+  const int m = 6 * h->ddm_nb;
+  std::vector<double> Pt((size_t)n_S * m * m);
+  for (int s = 0; s < n_S; ++s)
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) Pt[((size_t)s * m + j) * m + i] = S[((size_t)s * m + i) * m + j];
+  PL_HIP(h->ddm_Pt.alloc(Pt.size()));
+  PL_HIP(h->ddm_cell_P.alloc(h->ddm_cells));
+  PL_HIP(hipMemcpy(h->ddm_Pt.p, Pt.data(), Pt.size() * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->ddm_cell_P.p, cell_S, h->ddm_cells * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->ddm_have_P = true;
+  return PL_OK;
+}
+
+// G = sum_c B^T Shat B on the free dofs (unit diagonal elsewhere), Cholesky + explicit inverse factor on the device.
+static int ddm_factor_preconditioner(pl_context *h) {
+  const int64_t n6 = h->N * 6;
+  const int np = (int)((n6 + pl::kNB - 1) / pl::kNB * pl::kNB);
+  if (h->dd_n != np) {
+    const size_t nn = (size_t)np * np;
+    PL_HIP(h->dd_A.alloc(nn));
+    PL_HIP(h->dd_Lf.alloc(nn));
+    PL_HIP(h->dd_W.alloc(nn));
+    PL_HIP(h->dd_Wt.alloc(nn));
+    PL_HIP(h->dd_Dinv.alloc((size_t)np * pl::kNB));
+    PL_HIP(h->dd_tv.alloc(np));
+    PL_HIP(h->dd_info.alloc(2));
+    PL_HIP(hipMemsetAsync(h->dd_W.p, 0, nn * sizeof(double), h->stream));
+    PL_HIP(hipMemsetAsync(h->dd_Wt.p, 0, nn * sizeof(double), h->stream));
+    h->dd_n = np;
+  }
+  h->dd_ready = false;
+  PL_HIP(hipMemsetAsync(h->dd_A.p, 0, (size_t)np * np * sizeof(double), h->stream));
+  PL_HIP(hipMemsetAsync(h->dd_info.p, 0, 2 * sizeof(int), h->stream));
+  const int m = 6 * h->ddm_nb;
+  const int64_t ne = h->ddm_cells * m * m;
+  const uint8_t *fx = h->have_bc ? h->fixed.p : (const uint8_t *)nullptr;
+  hipLaunchKernelGGL(pl::k_ddm_dense_assemble, dim3(grid_for(ne)), dim3(pl::kBlock), 0, h->stream, h->ddm_cells,
+                     h->ddm_nb, h->ddm_cell_nodes.p, h->ddm_have_P ? h->ddm_cell_P.p : h->ddm_cell_S.p,
+                     h->ddm_have_P ? h->ddm_Pt.p : h->ddm_St.p, fx, np, h->dd_A.p);
+  hipLaunchKernelGGL(pl::k_ddm_dense_unit, dim3((np + 255) / 256), dim3(256), 0, h->stream, n6, np, fx, h->dd_A.p);
+  pl::dense_factor_inverse(h->dd_A.p, h->dd_Lf.p, h->dd_W.p, h->dd_Wt.p, h->dd_Dinv.p, np, np, h->dd_info.p, 0,
+                           h->stream);
+  PL_HIP(hipGetLastError());
+  int info[2] = {0, 0};
+  PL_HIP(hipMemcpyAsync(info, h->dd_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  if (info[0] != 0)
+    return fail(PL_ERR_STATE, "pl_assemble: the assembled Schur preconditioner is not positive definite "
+                              "(unconstrained rigid-body motion, or an indefinite surrogate matrix)");
+  h->dd_ready = true;
   return PL_OK;
 }
 
@@ -1061,7 +1159,21 @@ int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_ns
 int pl_assemble(pl_handle h) {
   if (!valid(h)) return fail(PL_ERR_ARG, "pl_assemble: null handle");
   PL_HIP(hipSetDevice(h->opt.device));
-  if (h->opkind == 1) {   // DDM operator: nothing to build; plain CG as the reference, or Jacobi if asked for
+  if (h->opkind == 1) {   // DDM operator: nothing to build; plain CG as the reference, Jacobi, or the factorised matrix
+    h->dd_ready = false;
+    if (h->opt.precond == 2) {
+      PL_HIP(hipEventRecord(h->ev0, h->stream));
+      int rcp = ddm_factor_preconditioner(h);
+      if (rcp) return rcp;
+      PL_HIP(hipMemsetAsync(h->dinv.p, 0, h->N * 6 * sizeof(double), h->stream));   // z comes from the dense solve
+      PL_HIP(hipEventRecord(h->ev1, h->stream));
+      PL_HIP(hipEventSynchronize(h->ev1));
+      float ms = 0.f;
+      PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      h->ms_assembly = ms;
+      h->assembled = true;
+      return PL_OK;
+    }
     if (h->opt.precond == 1) {
       PL_HIP(hipMemsetAsync(h->diag.p, 0, h->N * 6 * sizeof(double), h->stream));
       const int64_t m = (int64_t)h->ddm_cells * h->ddm_nb * 6;

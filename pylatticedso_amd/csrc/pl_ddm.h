@@ -57,4 +57,29 @@ __global__ __launch_bounds__(kBlock) void k_ddm_diag(int64_t C, int nb, const in
   unsafeAtomicAdd(diag + 6 * (int64_t)cell_nodes[c * nb + i / 6] + i % 6, S[(size_t)i * m + i]);
 }
 
+// The reference's CG preconditioner for this operator (LatticeSim.build_preconditioner, lattice_sim.py:1351-1415, with
+// Cell.build_local_preconditioner, cell.py:783-827): G = sum_c B_c^T Shat_c B_c on the free dofs, factorised once.
+// Here G is assembled DENSE (ld = n padded to the block size of pl_dense.h) and handed to the device Cholesky; rows
+// and columns of constrained dofs and of the padding are left out and get a unit diagonal from k_ddm_dense_unit.
+__global__ __launch_bounds__(kBlock) void k_ddm_dense_assemble(int64_t C, int nb, const int32_t *__restrict__ cell_nodes,
+                                                               const int32_t *__restrict__ cell_S,
+                                                               const double *__restrict__ St,
+                                                               const uint8_t *__restrict__ fixed, int ld,
+                                                               double *__restrict__ G) {
+  const int m = 6 * nb;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= C * m * m) return;
+  const int64_t c = e / ((int64_t)m * m);
+  const int ij = (int)(e - c * m * m), j = ij / m, i = ij - j * m;       // consecutive lanes: consecutive i of St[j][i]
+  const int64_t gi = 6 * (int64_t)cell_nodes[c * nb + i / 6] + i % 6;
+  const int64_t gj = 6 * (int64_t)cell_nodes[c * nb + j / 6] + j % 6;
+  if (fixed && (fixed[gi] || fixed[gj])) return;
+  unsafeAtomicAdd(G + gi * ld + gj, St[(size_t)cell_S[c] * m * m + (size_t)j * m + i]);
+}
+__global__ void k_ddm_dense_unit(int64_t n6, int ld, const uint8_t *__restrict__ fixed, double *__restrict__ G) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ld) return;
+  if (d >= n6 || (fixed && fixed[d]) || G[d * ld + d] == 0.0) G[d * ld + d] = 1.0;
+}
+
 }  // namespace pl

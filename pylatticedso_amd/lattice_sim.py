@@ -22,6 +22,8 @@ import numpy as np
 
 from . import lattice_arrays as LA
 
+DDM_DENSE_MAX = 16384      # PL_DDM_DENSE_MAX of include/pylattice_hip.h
+
 _ROOT = Path(__file__).resolve().parents[1]
 PRESET_DIR = _ROOT / "data" / "inputs" / "preset_lattice"
 
@@ -65,6 +67,9 @@ class LatticeSim:
         if mesh_trimmer is not None:
             raise NotImplementedError("mesh_trimmer is outside the accelerated path")
         self._verbose = verbose
+        self.data_roots = list(data_roots or [])
+        self.used_schur_preconditioner = None
+        self._ddm_precond = 0
         self.domain_decomposition_solver = enable_domain_decomposition_solver
         self.n_DOF_per_node = 6
         self.penalization_coefficient = LA.PENALIZATION_COEFFICIENT
@@ -97,6 +102,8 @@ class LatticeSim:
                                           "list_elements": self.schur_surrogate.points}
                 self.alpha_coefficients_greedy = self.schur_surrogate.alpha_train
                 self.shape_schur_complement = self.schur_surrogate.n
+            if self.enable_preconditioner and self.preconditioner_type not in ("mean", "nearest_reference", "exact"):
+                raise NotImplementedError("Not implemented preconditioner approximation method.")   # lattice_sim.py:1323
             self.calculate_schur_complement_cells()
 
     # ------------------------------------------------------------------------------------------------
@@ -180,6 +187,16 @@ class LatticeSim:
             self._cell_radii_override = np.tile(np.asarray(self._base_radii, dtype=float), (self.lattice.n_cells, 1))
         self._cell_radii_override[index_cell] = self.radii
         self._generate_and_prepare()
+
+    def set_cell_radii(self, radii):
+        """Give every cell its own radii, (C, n_geometries) in the cell order of ``lattice.cell_pos`` - what a loop of
+        ``Cell.change_beam_radius`` (cell.py:896-917) does in the reference (LatticeOpti works this way).  The lattice
+        arrays are regenerated once; in DDM mode the cell Schur complements are re-evaluated."""
+        radii = np.asarray(radii, dtype=float).reshape(self.lattice.n_cells, len(self._base_radii))
+        self._cell_radii_override = radii.copy()
+        self._generate_and_prepare()
+        if self.domain_decomposition_solver:
+            self.calculate_schur_complement_cells()
 
     def _generate_and_prepare(self):
         """Lattice arrays + penalisation + boundary indices + boundary conditions from the current parameters."""
@@ -413,7 +430,8 @@ class LatticeSim:
             return self._surrogate_schur_complement_cells()
         lat, pen = self.lattice, self.penalized
         cb = self.cell_boundary_nodes()
-        keys = [tuple(np.round(lat.cell_radii[c], 8)) for c in range(lat.n_cells)]
+        par = self._cell_parameter_radii()       # the reference groups by Cell.radii, which ignores the preset gradient
+        keys = [tuple(np.round(par[c], 8)) for c in range(lat.n_cells)]
         groups, mats, idx = {}, [], np.zeros(lat.n_cells, np.int32)
         for c, k in enumerate(keys):
             if k not in groups:
@@ -437,7 +455,8 @@ class LatticeSim:
         if self.schur_surrogate is None:
             raise NotImplementedError("Not implemented schur complement computation method.")
         lat = self.lattice
-        keys = [tuple(round(float(r), 8) for r in lat.cell_radii[c]) for c in range(lat.n_cells)]
+        par = self._cell_parameter_radii()
+        keys = [tuple(round(float(r), 8) for r in par[c]) for c in range(lat.n_cells)]
         uniq = {}
         idx = np.zeros(lat.n_cells, np.int32)
         for c, k in enumerate(keys):
@@ -467,12 +486,91 @@ class LatticeSim:
                              "set_schur_complements()")
         if self._ddm_device is None:
             cb = self.cell_boundary_nodes()
-            # enable_preconditioner: the reference LU-factorises the assembled Schur matrix (lattice_sim.py:1351-1415);
-            # here the CG gets the Jacobi preconditioner of the same matrix instead (same solution, more iterations)
-            self._ddm_device = HipLattice.ddm(self.max_index_boundary + 1, self.index_boundary[cb],
-                                              self.schur_complements, self.cell_schur_index,
-                                              precond=1 if self.enable_preconditioner else 0)
+            n_nodes = self.max_index_boundary + 1
+            # enable_preconditioner: the reference factorises the assembled Schur matrix (lattice_sim.py:1333-1415).
+            # The device does the same (dense Cholesky, precond = 2) up to DDM_DENSE_MAX dofs; beyond that the CG gets
+            # the Jacobi preconditioner of the same matrix (same solution, more iterations).
+            self._ddm_precond = 0
+            if self.enable_preconditioner:
+                self._ddm_precond = 2 if 6 * n_nodes <= DDM_DENSE_MAX else 1
+            self._ddm_device = HipLattice.ddm(n_nodes, self.index_boundary[cb], self.schur_complements,
+                                              self.cell_schur_index, precond=self._ddm_precond)
+            if self._ddm_precond == 2:
+                self.define_preconditioner()
         return self._ddm_device
+
+    def _define_preconditioner_approximation(self):
+        """lattice_sim.py:1312-1329: the dataset the approximate preconditioners are built from -
+        ``Schur_complement_mean_<geoms>.npz`` ("mean") or ``Schur_complement_<geoms>.npz`` ("nearest_reference") under
+        ``data/outputs/schur_complement/`` of a data root; nothing for "exact"."""
+        if self.preconditioner_type == "exact":
+            return None
+        if self.preconditioner_type not in ("mean", "nearest_reference"):
+            raise NotImplementedError("Not implemented preconditioner approximation method.")
+        stem = "Schur_complement_mean_" if self.preconditioner_type == "mean" else "Schur_complement_"
+        name = stem + "_".join(str(g) for g in self.geom_types) + ".npz"
+        roots = list(self.data_roots or [])
+        if os.environ.get("PYLATTICE_DATA_ROOT"):
+            roots.append(os.environ["PYLATTICE_DATA_ROOT"])
+        roots.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        for root in roots:
+            for sub in (os.path.join("data", "outputs", "schur_complement"), ""):
+                path = os.path.join(root, sub, name)
+                if os.path.isfile(path):
+                    self.used_schur_preconditioner = np.load(path, allow_pickle=True)
+                    return path
+        if self.preconditioner_type == "mean":
+            # the reference's checkout does not carry its Schur_complement_mean_*.npz files: build the mean matrix from
+            # the radius dataset of the same geometries, else from this lattice's own cell matrices
+            full = "Schur_complement_" + "_".join(str(g) for g in self.geom_types) + ".npz"
+            for root in roots:
+                for sub in (os.path.join("data", "outputs", "schur_complement"), ""):
+                    path = os.path.join(root, sub, full)
+                    if os.path.isfile(path):
+                        mats = np.asarray(np.load(path, allow_pickle=True)["schur_matrices"], dtype=float)
+                        self.used_schur_preconditioner = {"schur_matrices": mats.mean(axis=0)}
+                        return path
+            if self.schur_complements is not None:
+                w = np.bincount(self.cell_schur_index, minlength=len(self.schur_complements)).astype(float)
+                self.used_schur_preconditioner = {
+                    "schur_matrices": np.tensordot(w / w.sum(), self.schur_complements, axes=(0, 0))}
+                return None
+        raise FileNotFoundError(f"Schur complement dataset for the '{self.preconditioner_type}' preconditioner not "
+                                f"found: {name} (looked under {roots})")
+
+    def define_preconditioner(self):
+        """lattice_sim.py:1333-1415 (define_preconditioner + build_preconditioner): choose the cell matrices the
+        assembled preconditioner is made of and hand them to the device, which assembles and factorises
+        ``sum_c B_c^T Shat_c B_c`` at the next ``assemble()``.  "exact": the cells' own Schur complements; "mean": the one
+        matrix of the mean dataset for every cell; "nearest_reference": for every cell the dataset matrix whose radii
+        are nearest (Euclidean, first on ties - sklearn's NearestNeighbors(n_neighbors=1) in the reference) to
+        Cell.radii."""
+        dev = self._ddm_device
+        if dev is None or not self.enable_preconditioner or getattr(self, "_ddm_precond", 0) != 2:
+            return
+        if self.preconditioner_type == "exact" or self.preconditioner_type is None:
+            dev.set_ddm_preconditioner(None)
+            return
+        if getattr(self, "used_schur_preconditioner", None) is None:
+            self._define_preconditioner_approximation()
+        data = self.used_schur_preconditioner
+        mats = np.asarray(data["schur_matrices"], dtype=float)
+        if self.preconditioner_type == "mean":
+            dev.set_ddm_preconditioner(mats.reshape(-1, mats.shape[-2], mats.shape[-1])[:1])
+            return
+        pts = np.asarray(data["radius_values"], dtype=float)
+        if pts.ndim == 1:
+            pts = pts[:, None]
+        radii = self._cell_parameter_radii()
+        d2 = ((radii[:, None, :] - pts[None, :, :]) ** 2).sum(axis=2)
+        dev.set_ddm_preconditioner(mats, np.argmin(d2, axis=1).astype(np.int32))
+
+    def _cell_parameter_radii(self):
+        """``Cell.radii`` of the reference for every cell: the radii the cell was GIVEN (preset value,
+        reset_cell_with_new_radii, LatticeOpti), which the preset's radius gradient does not touch - it only scales
+        the struts (cell.py:86,407-412).  The key of the reference's Schur-complement cache and the argument of its
+        surrogates and of the nearest-reference preconditioner."""
+        return self.lattice.cell_radii / self._cell_gfac[:, None]
 
     def solve_DDM(self):
         """Domain-decomposition solve on the cell-boundary nodes (lattice_sim.py:1111-1176): right-hand side
@@ -481,12 +579,12 @@ class LatticeSim:
         (xsol, info, global_displacement_index, b) or four None when b == 0."""
         if not self.domain_decomposition_solver:
             raise ValueError("LatticeSim was not created with enable_domain_decomposition_solver=True")
-        if self.enable_preconditioner and not getattr(self, "_precond_note_done", False):
-            print("solve_DDM: the LU-of-global-Schur preconditioner of the reference is not ported; running "
-                  "Jacobi-preconditioned CG on the device to the same tolerance (max_iterations of the preset then "
-                  "only applies if larger than the default of that solver)")
-            self._precond_note_done = True
         dev = self.ddm_model()
+        if self._ddm_precond == 1 and not getattr(self, "_precond_note_done", False):
+            print(f"solve_DDM: {6 * (self.max_index_boundary + 1)} boundary dofs exceed the {DDM_DENSE_MAX} the device "
+                  "factorises densely for the assembled-Schur preconditioner; running Jacobi-preconditioned CG to the "
+                  "same tolerance (max_iterations of the preset then only applies if larger than 20000)")
+            self._precond_note_done = True
         bn = self._boundary_nodes_by_index()
         fixed = self.fixed_DOF[bn]
         if (~fixed).sum() == 0:
@@ -500,9 +598,9 @@ class LatticeSim:
             print("No external forces or imposed displacements in the lattice. Process aborted.")
             return None, None, None, None
         maxit = self.number_iteration_max or 1000
-        if self.enable_preconditioner:
-            # presets written for the LU-preconditioned CG cap it at a handful of iterations; the plain CG that
-            # replaces it needs O(sqrt(cond)) of them to reach the same 1e-6
+        if self._ddm_precond == 1:
+            # presets written for the LU-preconditioned CG cap it at a handful of iterations; the Jacobi CG that
+            # replaces it above the dense limit needs O(sqrt(cond)) of them to reach the same 1e-6
             maxit = max(maxit, 20000)
         u, st = dev.solve(rtol=1e-6, max_iter=maxit, raise_on_noconv=False)
         self.iteration = st["iterations"]

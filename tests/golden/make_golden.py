@@ -277,6 +277,42 @@ def gen_ddm():
         print(f"ddm_{name}: n={len(xsol)} info={info} its={L.iteration}")
 
 
+def gen_ddm_preconditioned():
+    """Reference DDM solves with its assembled-Schur LU preconditioner (lattice_sim.py:1333-1415): type "exact" (the
+    cells' own matrices) and "nearest_reference" (the dolfinx dataset matrix nearest in radius), on a uniform BCC
+    cantilever and on one whose cells have different radii.  The dataset the second type reads is a data file of the reference (10 matrices, copied
+    next to the outputs under the name the reference looks for)."""
+    import shutil
+    shutil.copyfile(os.path.join(REF, "data", "outputs", "schur_complement", "Schur_complement_BCC.npz"),
+                    os.path.join(OUT, "Schur_complement_BCC.npz"))
+    bcs = {"Displacement": CANTILEVER["Displacement"],
+           "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}
+    res = {}
+    # "varied": every cell gets its own radius through Cell.change_beam_radius, as LatticeOpti does (off the 0.01 grid
+    # of the dataset, so that the nearest-reference matrix is NOT the cell's own)
+    for name, ncell, varied in [("uniform_4x2x2", (4, 2, 2), False), ("varied_6x3x3", (6, 3, 3), True)]:
+        for ptype in ("exact", "nearest_reference"):
+            ddm = {"enable_preconditioner": True, "preconditioner_type": ptype, "max_iterations": 200,
+                   "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}
+            preset = _preset(["BCC"], [0.05], ncell, bcs=bcs, periodicity=False, ddm=ddm)
+            L = _make(preset, enable_domain_decomposition_solver=True)
+            if varied:
+                for c in L.cells:
+                    c.change_beam_radius([0.034 + 0.011 * c.pos[0] + 0.002 * c.pos[2]])
+                _quiet(L.calculate_schur_complement_cells)
+            xsol, info, idx, b = _quiet(L.solve_DDM)
+            key = f"{name}_{ptype}"
+            res[f"{key}_xsol"] = np.asarray(xsol)
+            res[f"{key}_b"] = np.asarray(b)
+            res[f"{key}_info"] = np.array(info)
+            res[f"{key}_iterations"] = np.array(L.iteration)
+            res[f"{key}_preset_json"] = np.array(json.dumps(preset))
+            res[f"{key}_cell_radii"] = np.array([c.radii for c in L.cells])
+            res[f"{key}_cell_pos"] = np.array([c.pos for c in L.cells])
+            print(f"ddm_precond {key}: n={len(xsol)} info={info} its={L.iteration}")
+    np.savez_compressed(os.path.join(OUT, "ddm_preconditioned.npz"), **res)
+
+
 def gen_surrogate():
     """Surrogate Schur complements of the reference (lattice_sim.py:755-813,919-977,1020-1082) evaluated through its
     own reduced basis of the BCC cell: S(r) for the three surrogate kinds (inside, at and outside the training range),
@@ -325,7 +361,9 @@ def gen_greedy():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "surrogate", "greedy"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "surrogate", "greedy"]
+    if "ddm_precond" in which:
+        gen_ddm_preconditioned()
     if "greedy" in which:
         gen_greedy()
     if "surrogate" in which:

@@ -68,15 +68,22 @@ def test_ddm_exact_schur_agrees_with_fem(golden_dir):
 
 @pytest.mark.parametrize("kind", ["nearest_neighbor", "linear", "RBF"])
 def test_ddm_surrogate_kinds_on_a_graded_lattice(golden_dir, kind):
-    """Graded radii (one Schur matrix per distinct radius, evaluated in one batch) with every surrogate kind: the
-    device DDM solution satisfies the assembled condensed system built on the host from the same cell matrices."""
+    """Cells with different radii (one Schur matrix per distinct radius, evaluated in one batch) with every surrogate
+    kind: the device DDM solution satisfies the assembled condensed system built on the host from the same cell
+    matrices."""
     preset = json.loads(str(np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))["preset_json"]))
     preset["simulation_parameters"]["DDM"]["schur_complement_computation"] = {"type": kind, "precision_greedy": 1e-6}
-    preset["gradient"] = {"radii": {"rule": "linear", "direction_x": True, "direction_y": False, "direction_z": False,
+    graded = json.loads(json.dumps(preset))
+    graded["gradient"] = {"radii": {"rule": "linear", "direction_x": True, "direction_y": False, "direction_z": False,
                                     "parameter_x": 0.25, "parameter_y": 0.0, "parameter_z": 0.0}}
+    Lg = LatticeSim(graded, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    # the preset's radius gradient scales the struts but not Cell.radii, the argument of the reference's surrogates
+    # (cell.py:86,407-412; lattice_sim.py:846-919): one matrix for all cells, as in the reference
+    assert len({tuple(np.round(r, 8)) for r in Lg.lattice.cell_radii}) > 1 and Lg.schur_complements.shape[0] == 1
     L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
-    n_distinct = len({tuple(np.round(r, 8)) for r in L.lattice.cell_radii})
-    assert n_distinct > 1 and L.schur_complements.shape == (n_distinct, 48, 48)
+    L.set_cell_radii(0.04 + 0.0125 * L.lattice.cell_pos[:, 0])
+    n_distinct = len({tuple(np.round(r, 8)) for r in L._cell_parameter_radii()})
+    assert n_distinct == 4 and L.schur_complements.shape == (n_distinct, 48, 48)
     xsol, info, idx, b = L.solve_DDM()
     assert info == 0
     # host assembly of sum_c B_c^T S_c B_c on the free dofs, in the ordering of xsol
@@ -92,19 +99,54 @@ def test_ddm_surrogate_kinds_on_a_graded_lattice(golden_dir, kind):
     assert _rel(xsol, np.linalg.solve(Kff, b)) < 1e-3
 
 
-def test_presets_written_for_the_preconditioned_solver_still_converge(golden_dir, capsys):
-    """The reference's DDM presets enable its LU preconditioner and cap CG at a handful of iterations
-    (optimization_DDM_surrogate.json: 10).  The device runs plain CG instead: it must say so once and lift the cap."""
-    preset = json.loads(str(np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))["preset_json"]))
-    ddm = preset["simulation_parameters"]["DDM"]
-    ddm.update(enable_preconditioner=True, preconditioner_type="mean", max_iterations=10)
-    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+@pytest.mark.parametrize("case,iters", [("uniform_4x2x2_exact", 1), ("uniform_4x2x2_nearest_reference", 1),
+                                        ("varied_6x3x3_exact", 1), ("varied_6x3x3_nearest_reference", 10)])
+def test_preconditioned_ddm_reproduces_reference(golden_dir, case, iters):
+    """The reference's assembled-Schur preconditioner (build_preconditioner, lattice_sim.py:1351-1415), factorised on
+    the device: same solution and the same number of CG iterations as the reference's SuperLU-preconditioned solve."""
+    g = np.load(os.path.join(golden_dir, "ddm_preconditioned.npz"))
+    assert int(g[f"{case}_iterations"]) == iters and int(g[f"{case}_info"]) == 0
+    L = LatticeSim(json.loads(str(g[f"{case}_preset_json"])), enable_domain_decomposition_solver=True,
+                   data_roots=[golden_dir])
+    if case.startswith("varied"):
+        pos = L.lattice.cell_pos
+        L.set_cell_radii(0.034 + 0.011 * pos[:, 0] + 0.002 * pos[:, 2])
+        ref = {tuple(p): r for p, r in zip(g[f"{case}_cell_pos"].tolist(), g[f"{case}_cell_radii"].ravel())}
+        assert np.allclose([ref[tuple(p)] for p in pos.tolist()], L._cell_parameter_radii().ravel(), atol=1e-14)
+    xsol, info, _, b = L.solve_DDM()
+    assert L._ddm_precond == 2 and info == 0
+    assert np.allclose(b, g[f"{case}_b"], rtol=1e-9, atol=1e-12 * np.abs(g[f"{case}_b"]).max())
+    assert L.iteration == iters
+    # both stop at ||r|| <= 1e-6 ||b||; with the exact preconditioner the first step already lands on the solution
+    assert _rel(xsol, g[f"{case}_xsol"]) < (1e-9 if iters == 1 else 2e-6)
+
+
+def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeypatch):
+    """preconditioner_type "mean" (what the reference's DDM presets name): its Schur_complement_mean_*.npz is not in
+    the reference's checkout, so the mean of the radius dataset stands in.  Beyond the dense limit the device falls
+    back to Jacobi, says so once and lifts the iteration cap those presets carry (optimization_DDM_surrogate: 10)."""
+    import pylatticedso_amd.lattice_sim as LS
     g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    ddm = preset["simulation_parameters"]["DDM"]
+    ddm.update(enable_preconditioner=True, preconditioner_type="mean", max_iterations=400)
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
     xsol, info, _, _ = L.solve_DDM()
-    L.solve_DDM()
-    assert info == 0 and L.iteration > 10 and _rel(xsol, g["xsol"]) < 1e-5
-    assert L.iteration < int(g["iterations"])            # Jacobi on the assembled diagonal beats the plain CG count
-    assert capsys.readouterr().out.count("not ported") == 1
+    assert L._ddm_precond == 2 and info == 0 and _rel(xsol, g["xsol"]) < 1e-5
+    assert L.iteration < int(g["iterations"]) // 4        # plain CG of the golden: ~200
+    assert "exceed" not in capsys.readouterr().out
+    # Jacobi fallback
+    monkeypatch.setattr(LS, "DDM_DENSE_MAX", 100)
+    ddm["max_iterations"] = 10
+    L3 = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    xsol3, info3, _, _ = L3.solve_DDM()
+    L3.solve_DDM()
+    assert L3._ddm_precond == 1 and info3 == 0 and L3.iteration > 10 and _rel(xsol3, g["xsol"]) < 1e-5
+    assert L3.iteration < int(g["iterations"])            # Jacobi on the assembled diagonal beats the plain CG count
+    assert capsys.readouterr().out.count("exceed") == 1
     ddm.pop("preconditioner_type")
     with pytest.raises(ValueError):
+        LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    ddm["preconditioner_type"] = "something"
+    with pytest.raises(NotImplementedError):
         LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
