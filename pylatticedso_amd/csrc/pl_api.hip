@@ -118,6 +118,7 @@ struct pl_context {
   DevBuf<double> dd_A, dd_Lf, dd_W, dd_Wt, dd_Dinv, dd_tv;
   DevBuf<int> dd_info;
   int dd_n = 0;          // padded order of the dense matrix (0: not allocated)
+  int dd_bw = 0;         // its block bandwidth in the caller's node numbering (from the cells' node spans)
   bool dd_ready = false;
   // record palette (pl_palette.h)
   DevBuf<unsigned long long> pal_keys;
@@ -953,6 +954,14 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   c->B = 0;
   c->ddm_cells = n_cells;
   c->ddm_nb = nb;
+  {   // dofs coupled by a cell are at most 6 * (max - min node id) + 5 apart: the band of the assembled matrix
+    int64_t span = 0;
+    for (int64_t cc = 0; cc < n_cells; ++cc) {
+      const int32_t *nd = cell_nodes + cc * nb;
+      span = std::max<int64_t>(span, *std::max_element(nd, nd + nb) - *std::min_element(nd, nd + nb));
+    }
+    c->dd_bw = (int)((6 * span + 5) / pl::kNB + 1);
+  }
   auto bail = [&](int rc) {
     delete c;
     return rc;
@@ -1056,8 +1065,8 @@ static int ddm_factor_preconditioner(pl_context *h) {
                      h->ddm_nb, h->ddm_cell_nodes.p, h->ddm_have_P ? h->ddm_cell_P.p : h->ddm_cell_S.p,
                      h->ddm_have_P ? h->ddm_Pt.p : h->ddm_St.p, fx, np, h->dd_A.p);
   hipLaunchKernelGGL(pl::k_ddm_dense_unit, dim3((np + 255) / 256), dim3(256), 0, h->stream, n6, np, fx, h->dd_A.p);
-  pl::dense_factor_inverse(h->dd_A.p, h->dd_Lf.p, h->dd_W.p, h->dd_Wt.p, h->dd_Dinv.p, np, np, h->dd_info.p, 0,
-                           h->stream);
+  pl::dense_factor_inverse(h->dd_A.p, h->dd_Lf.p, h->dd_W.p, h->dd_Wt.p, h->dd_Dinv.p, np, np, h->dd_info.p,
+                           h->dd_bw, h->stream);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, h->dd_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
