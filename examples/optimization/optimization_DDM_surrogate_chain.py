@@ -27,9 +27,11 @@ n_iter = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 name_file = "optimization/optimization_DDM_surrogate"
 preset = open_lattice_parameters(name_file)
 tol = preset["simulation_parameters"]["DDM"]["schur_complement_computation"]["precision_greedy"]
-# (the shipped preset enables the preconditioner without naming its type, which LatticeSim rejects - reference and
-# mirror alike, lattice_sim.py:219-221)
-preset["simulation_parameters"]["DDM"].setdefault("preconditioner_type", "mean")
+# The shipped preset enables the preconditioner without naming its type, which LatticeSim rejects - reference and
+# mirror alike (lattice_sim.py:219-221).  "exact" = the assembled matrix of the cells' own Schur complements, factorised
+# on the device: one CG step while that matrix is positive definite; where the spline surrogate leaves its training
+# range and turns indefinite the device falls back to Jacobi CG and lifts the preset's cap of 10 iterations.
+preset["simulation_parameters"]["DDM"].setdefault("preconditioner_type", "exact")
 
 # 1. one periodic cell of the same geometry, exact Schur complements on the GPU
 cell = {"geometry": dict(preset["geometry"], number_of_cells={"x": 1, "y": 1, "z": 1}),
@@ -57,4 +59,4 @@ sol = lattice_object.optimize_lattice()
 hist = lattice_object._history["objective"]
 print(f"optimisation: {sol.nit} SLSQP iterations, {sol.nfev} objective + {sol.njev} gradient evaluations in "
       f"{time.time() - t0:.1f} s; compliance {hist[0]:.4e} -> {hist[-1]:.4e}; relative density "
-      f"{lattice_object.relative_density():.3f}")
+      f"{lattice_object.relative_density():.3f}; last solve_DDM: {lattice_object.iteration} CG iterations")

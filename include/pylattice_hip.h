@@ -89,7 +89,9 @@ typedef struct {
   double ms_assembly;      /* last pl_assemble (+ pl_assemble_bsr) on the device, HIP events */
   double ms_solve;         /* last pl_solve, HIP events around the PCG loop */
   double ms_spmv_avg;      /* average K*x kernel time inside the last pl_solve (HIP events, sampled) */
-  double reserved[8];
+  double precond_used;     /* preconditioner the solve actually ran with (opts->precond numbering): differs from the
+                              request when a dense level was not positive definite and the solve fell back to Jacobi */
+  double reserved[7];
 } pl_stats_t;
 
 void pl_default_opts(pl_opts_t *o);
@@ -118,8 +120,8 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
  * opts->precond = 2 at pl_create_ddm; pl_assemble builds and factorises G for the current Dirichlet mask.
  * Shat_c defaults to the operator's own matrices (preconditioner_type "exact": CG converges in one step); this call
  * installs another palette - one mean matrix ("mean"), or the dataset matrices with the nearest-radius index per
- * cell ("nearest_reference").  S = NULL goes back to the default.  Returns PL_ERR_STATE from pl_assemble when G is
- * not positive definite. */
+ * cell ("nearest_reference").  S = NULL goes back to the default.  When G is not positive definite (an indefinite
+ * surrogate matrix) pl_assemble falls back to Jacobi (the reference: LU -> ILU) and pl_stats_t.precond_used says 1. */
 #define PL_DDM_DENSE_MAX 16384
 int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/,
                               const int32_t *cell_S /*[n_cells]*/);

@@ -42,7 +42,7 @@ class PlOpts(C.Structure):
 class PlStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
-                ("ms_spmv_avg", C.c_double), ("reserved", C.c_double * 8)]
+                ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("reserved", C.c_double * 7)]
 
 
 class PlError(RuntimeError):

@@ -1071,10 +1071,7 @@ static int ddm_factor_preconditioner(pl_context *h) {
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, h->dd_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
-  if (info[0] != 0)
-    return fail(PL_ERR_STATE, "pl_assemble: the assembled Schur preconditioner is not positive definite "
-                              "(unconstrained rigid-body motion, or an indefinite surrogate matrix)");
-  h->dd_ready = true;
+  h->dd_ready = (info[0] == 0);   // not positive definite (e.g. an indefinite surrogate matrix): caller falls back
   return PL_OK;
 }
 
@@ -1174,16 +1171,20 @@ int pl_assemble(pl_handle h) {
       PL_HIP(hipEventRecord(h->ev0, h->stream));
       int rcp = ddm_factor_preconditioner(h);
       if (rcp) return rcp;
-      PL_HIP(hipMemsetAsync(h->dinv.p, 0, h->N * 6 * sizeof(double), h->stream));   // z comes from the dense solve
-      PL_HIP(hipEventRecord(h->ev1, h->stream));
-      PL_HIP(hipEventSynchronize(h->ev1));
-      float ms = 0.f;
-      PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-      h->ms_assembly = ms;
-      h->assembled = true;
-      return PL_OK;
+      if (h->dd_ready) {
+        PL_HIP(hipMemsetAsync(h->dinv.p, 0, h->N * 6 * sizeof(double), h->stream));   // z comes from the dense solve
+        PL_HIP(hipEventRecord(h->ev1, h->stream));
+        PL_HIP(hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->ms_assembly = ms;
+        h->assembled = true;
+        return PL_OK;
+      }
+      // G is not positive definite (the reference falls back from LU to ILU when its factorisation fails,
+      // lattice_sim.py:1406-1413): Jacobi on the assembled diagonal; pl_stats_t.precond_used tells the caller
     }
-    if (h->opt.precond == 1) {
+    if (h->opt.precond >= 1) {
       PL_HIP(hipMemsetAsync(h->diag.p, 0, h->N * 6 * sizeof(double), h->stream));
       const int64_t m = (int64_t)h->ddm_cells * h->ddm_nb * 6;
       hipLaunchKernelGGL(pl::k_ddm_diag, dim3(grid_for(m)), dim3(pl::kBlock), 0, h->stream, h->ddm_cells, h->ddm_nb,
@@ -1361,6 +1362,8 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   st.ms_solve = ms;
   st.ms_assembly = h->ms_assembly;
+  st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->opt.precond >= 1 ? 1 : 0)
+                                   : (h->coarse.ready ? h->opt.precond : 1);
   if (u) {
     rc = download6(h, h->tmp2.p, u);
     if (rc) return rc;

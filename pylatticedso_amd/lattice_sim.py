@@ -530,11 +530,8 @@ class LatticeSim:
                         mats = np.asarray(np.load(path, allow_pickle=True)["schur_matrices"], dtype=float)
                         self.used_schur_preconditioner = {"schur_matrices": mats.mean(axis=0)}
                         return path
-            if self.schur_complements is not None:
-                w = np.bincount(self.cell_schur_index, minlength=len(self.schur_complements)).astype(float)
-                self.used_schur_preconditioner = {
-                    "schur_matrices": np.tensordot(w / w.sum(), self.schur_complements, axes=(0, 0))}
-                return None
+            self._mean_of_own_cells = True      # re-evaluated whenever the cell matrices change (define_preconditioner)
+            return None
         raise FileNotFoundError(f"Schur complement dataset for the '{self.preconditioner_type}' preconditioner not "
                                 f"found: {name} (looked under {roots})")
 
@@ -551,8 +548,12 @@ class LatticeSim:
         if self.preconditioner_type == "exact" or self.preconditioner_type is None:
             dev.set_ddm_preconditioner(None)
             return
-        if getattr(self, "used_schur_preconditioner", None) is None:
+        if self.used_schur_preconditioner is None and not getattr(self, "_mean_of_own_cells", False):
             self._define_preconditioner_approximation()
+        if self.used_schur_preconditioner is None:          # "mean" without any dataset: mean over this lattice's cells
+            w = np.bincount(self.cell_schur_index, minlength=len(self.schur_complements)).astype(float)
+            dev.set_ddm_preconditioner(np.tensordot(w / w.sum(), self.schur_complements, axes=(0, 0)))
+            return
         data = self.used_schur_preconditioner
         mats = np.asarray(data["schur_matrices"], dtype=float)
         if self.preconditioner_type == "mean":
@@ -603,8 +604,20 @@ class LatticeSim:
             # replaces it above the dense limit needs O(sqrt(cond)) of them to reach the same 1e-6
             maxit = max(maxit, 20000)
         u, st = dev.solve(rtol=1e-6, max_iter=maxit, raise_on_noconv=False)
+        if self._ddm_precond == 2 and int(st["precond_used"]) != 2:
+            # the assembled matrix was not positive definite (surrogate matrices far from their training points can be
+            # indefinite): the device ran Jacobi CG; give it the room the factorised preconditioner would not need
+            if not getattr(self, "_spd_note_done", False):
+                print("solve_DDM: the assembled Schur preconditioner is not positive definite (indefinite surrogate "
+                      "matrix?); Jacobi-preconditioned CG instead")
+                self._spd_note_done = True
+            if not st["converged"] and maxit < 20000:
+                u, st = dev.solve(rtol=1e-6, max_iter=20000, raise_on_noconv=False)
         self.iteration = st["iterations"]
         info = 0 if st["converged"] else 1
+        if info and self._verbose > -1:
+            print(f"Conjugate Gradient did not converge ({self.iteration} iterations, relative residual "
+                  f"{st['rel_residual']:.2e}).")
         self.displacement_vector[bn] = u
         self.reaction_force_vector[bn] = dev.reactions(u)
         xsol, idx = self.get_global_displacement()

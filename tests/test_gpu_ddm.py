@@ -135,6 +135,15 @@ def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeyp
     assert L._ddm_precond == 2 and info == 0 and _rel(xsol, g["xsol"]) < 1e-5
     assert L.iteration < int(g["iterations"]) // 4        # plain CG of the golden: ~200
     assert "exceed" not in capsys.readouterr().out
+    # no dataset anywhere: the mean over the lattice's own cell matrices, re-evaluated when the cells change
+    ddm["max_iterations"] = 200
+    L2 = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    L2._mean_of_own_cells = True
+    _, info2, _, _ = L2.solve_DDM()
+    assert info2 == 0 and L2.iteration == 1 and L2.used_schur_preconditioner is None     # one matrix: exact
+    L2.set_cell_radii(0.04 + 0.0125 * L2.lattice.cell_pos[:, 0])
+    x2, info2, _, b2 = L2.solve_DDM()
+    assert info2 == 0 and 1 < L2.iteration < 60
     # Jacobi fallback
     monkeypatch.setattr(LS, "DDM_DENSE_MAX", 100)
     ddm["max_iterations"] = 10
