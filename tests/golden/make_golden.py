@@ -313,6 +313,55 @@ def gen_ddm_preconditioned():
     np.savez_compressed(os.path.join(OUT, "ddm_preconditioned.npz"), **res)
 
 
+def gen_opti():
+    """Objective and gradient of the reference's LatticeOpti in DDM mode (lattice_opti.py:430-465, 701-907): BCC
+    cantilever, RBF surrogate, exact assembled preconditioner (so the equilibrium is converged to ~1e-11), for the three
+    parameterisations and for a compliance and a displacement objective, at a non-uniform parameter vector."""
+    from pyLatticeOpti.lattice_opti import LatticeOpti
+    ddm = {"enable_preconditioner": True, "preconditioner_type": "exact", "max_iterations": 200,
+           "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}
+    res = {}
+    cases = [("unit_cell_compliance", {"type": "unit_cell", "hybrid": False}, "compliance", None),
+             ("constant_compliance", {"type": "constant", "hybrid": False}, "compliance", None),
+             ("linear_x_compliance", {"type": "linear", "direction": "x", "hybrid": False}, "compliance", None),
+             ("unit_cell_displacement", {"type": "unit_cell", "hybrid": False}, "displacement",
+              {"Surface": ["Xmax"], "DOF": ["Z"]})]
+    for name, par, otype, odata in cases:
+        preset = _preset(["BCC"], [0.05], (4, 2, 2), bcs=CANTILEVER, periodicity=False, ddm=ddm)
+        info = {"objective_function": "min", "objective_type": otype, "max_iterations": 5,
+                "optimization_parameters": par, "constraints": {"relative_density": {"value": 0.2}},
+                "enable_parameter_normalization": True, "simulation_type": "DDM", "enable_gradient_computing": True}
+        if odata is not None:
+            info["objective_data"] = odata
+        preset["optimization_informations"] = info
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(preset, f)
+        f.close()
+        try:
+            L = _quiet(LatticeOpti, f.name, verbose=0)
+        finally:
+            os.unlink(f.name)
+        _quiet(L._initialize_optimization_solver)
+        x0 = np.array(L.initial_parameters, dtype=float)
+        if par["type"] == "linear":
+            x = x0 + np.array([0.2] * (len(x0) - 1) + [0.05])
+        else:
+            x = x0 + 0.15 * np.sin(1.0 + np.arange(len(x0)))
+        obj = _quiet(L.objective, list(x))
+        grad = np.asarray(_quiet(L.gradient, list(x)), dtype=float)
+        res[f"{name}_preset_json"] = np.array(json.dumps(preset))
+        res[f"{name}_x0"] = x0
+        res[f"{name}_x"] = x
+        res[f"{name}_objective_norm"] = np.array(obj)
+        res[f"{name}_objective"] = np.array(L.denorm_objective)
+        res[f"{name}_scale"] = np.array(L.initial_value_objective)
+        res[f"{name}_gradient"] = grad
+        res[f"{name}_cell_radii"] = np.array([c.radii for c in L.cells])
+        res[f"{name}_cell_pos"] = np.array([c.pos for c in L.cells])
+        print(f"opti {name}: n={len(x)} objective={L.denorm_objective:.6e} |grad|={np.linalg.norm(grad):.4e}")
+    np.savez_compressed(os.path.join(OUT, "opti_ddm.npz"), **res)
+
+
 def gen_surrogate():
     """Surrogate Schur complements of the reference (lattice_sim.py:755-813,919-977,1020-1082) evaluated through its
     own reduced basis of the BCC cell: S(r) for the three surrogate kinds (inside, at and outside the training range),
@@ -361,7 +410,9 @@ def gen_greedy():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "surrogate", "greedy"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "opti", "surrogate", "greedy"]
+    if "opti" in which:
+        gen_opti()
     if "ddm_precond" in which:
         gen_ddm_preconditioned()
     if "greedy" in which:
