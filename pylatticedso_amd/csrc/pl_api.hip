@@ -70,7 +70,8 @@ struct pl_context {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool assembled = false, have_bc = false, have_bsr = false;
-  int pal_host_flags[2] = {1, 0};
+  int pal_fallback_flags[2] = {1, 0};
+  int *pal_host_flags = pal_fallback_flags;   // pinned once the palette is in use: a D2H copy into pageable memory blocks the host
   bool want_bsr = false;   // pl_assemble_bsr was called once: pl_assemble keeps the explicit matrix current
   int bsr_with_bc = 0;
 
@@ -288,6 +289,11 @@ int launch_palette(pl_context *c, hipStream_t st) {
     PL_HIP(c->pal_flags.alloc(2));
     PL_HIP(c->pal_id.alloc(c->B));
     PL_HIP(c->palette.alloc(pl::kPalSize));
+    void *pinned = nullptr;
+    PL_HIP(hipHostMalloc(&pinned, 2 * sizeof(int), hipHostMallocDefault));
+    c->pal_host_flags = static_cast<int *>(pinned);
+    c->pal_host_flags[0] = 1;
+    c->pal_host_flags[1] = 0;
   }
   PL_HIP(hipMemsetAsync(c->pal_keys.p, 0xFF, pl::kPalSize * sizeof(unsigned long long), st));
   PL_HIP(hipMemsetAsync(c->pal_owner.p, 0x7F, pl::kPalSize * sizeof(int), st));
@@ -378,7 +384,8 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   cs.ready = false;
   if (!cs.enabled || !c->have_bc) return PL_OK;
   const int n = cs.ncp;
-  PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
+  if (!cs.ac_clean) PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
+  cs.ac_clean = false;
   PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
   if (cs.n_fix < 0) {   // Dirichlet set changed: list the in-aggregate struts that touch it, grouped by aggregate
     if (!cs.fix_count) PL_HIP(hipMalloc((void **)&cs.fix_count, sizeof(int)));
@@ -824,8 +831,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     if (_e != hipSuccess)                                                              \
       return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
-  PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  PL_HIPC(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  {   // the main stream carries the latency-bound chains (dense factorisation, PCG): it goes ahead of the bulk fills
+    int prio_low = 0, prio_high = 0;
+    PL_HIPC(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    PL_HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high));
+    PL_HIPC(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_low));
+  }
   PL_HIPC(hipEventCreate(&c->ev0));
   PL_HIPC(hipEventCreate(&c->ev1));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -972,8 +983,12 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
     if (_e != hipSuccess)                                                              \
       return bail(fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
-  PL_HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  PL_HIPC(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  {   // the main stream carries the latency-bound chains (dense factorisation, PCG): it goes ahead of the bulk fills
+    int prio_low = 0, prio_high = 0;
+    PL_HIPC(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    PL_HIPC(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high));
+    PL_HIPC(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_low));
+  }
   PL_HIPC(hipEventCreate(&c->ev0));
   PL_HIPC(hipEventCreate(&c->ev1));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1080,6 +1095,7 @@ void pl_destroy(pl_handle h) {
   (void)hipSetDevice(h->opt.device);
   (void)hipStreamSynchronize(h->stream);
   pl::dist_destroy(h->dist);
+  if (h->pal_host_flags != h->pal_fallback_flags) (void)hipHostFree(h->pal_host_flags);
   delete h;
 }
 
@@ -1229,6 +1245,13 @@ int pl_assemble(pl_handle h) {
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
   finish_palette(h);
+  // the factorisation has consumed A_c: zero it now, behind the caller's back, instead of at the head of the next
+  // assembly's critical chain (34 MB; it would sit in front of the coarse assembly there)
+  for (pl::Coarse *cs : {&h->coarse, &h->coarseL})
+    if (cs->ready && cs->Ac) {
+      PL_HIP(hipMemsetAsync(cs->Ac, 0, (size_t)cs->ncp * cs->ncp * sizeof(double), h->stream));
+      cs->ac_clean = true;
+    }
   float ms = 0.f;
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->ms_assembly = ms;

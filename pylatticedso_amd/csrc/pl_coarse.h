@@ -44,6 +44,7 @@ struct Coarse {
   float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
   double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
+  bool ac_clean = false;   // Ac was zeroed after the previous factorisation (off the critical path of pl_assemble)
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
   std::vector<int32_t> h_tile_start;
@@ -153,6 +154,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   c.ncp = (c.nc + kNB - 1) / kNB * kNB;
   const size_t n2 = (size_t)c.ncp * c.ncp;
   if (hipMalloc((void **)&c.Ac, n2 * sizeof(double)) != hipSuccess) return 2;
+  c.ac_clean = false;
   if (hipMalloc((void **)&c.W, n2 * sizeof(float)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.Lf, n2 * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.Lf, 0, n2 * sizeof(double)) != hipSuccess) return 2;
