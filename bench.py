@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--precond", type=int, default=0,
                     help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level, 4 = 3 + "
                          "rank-local dense level; 0 = 3")
+    ap.add_argument("--coarse-max-dofs", type=int, default=0,
+                    help="upper bound on the dofs of the dense coarse level (0 = library default, 3072)")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--cpu-cells", type=int, default=36,
                     help="edge of the CPU-baseline sample (0 = skip); 36 = 1.1 M struts, ~10-15 s on one core")
@@ -146,7 +148,7 @@ def main():
         grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
-                           tile_nodes=args.tile_nodes)
+                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world
