@@ -98,6 +98,15 @@ void pl_default_opts(pl_opts_t *o);
 const char *pl_last_error(void);
 const char *pl_version(void);
 
+/* Joint-penalisation length L_zone at both ends of every strut of a NON-periodic lattice, lzone[2*b + end] (end 0 =
+ * beam_conn[2b]): over the other struts meeting at that node, the largest r_other / tan(angle / 2); 1e-7 where the
+ * angle exceeds 170 degrees, 0 where no other strut meets the node.  Replaces the per-node double loop of
+ * Lattice.define_angles_between_beams (lattice.py:871-904) with Beam.get_angle_between_beams (beam.py:204-277) and
+ * function_penalization_Lzone (utils.py:432-453).  Stand-alone (no handle): the result decides seg_len / seg_nsub of
+ * pl_mesh_t.  Periodic single cells (Schur datasets) keep the host restatement. */
+int pl_lzone(int device, int64_t n_nodes, int64_t n_beams, const double *node_xyz, const int32_t *beam_conn,
+             const double *beam_radius, double *lzone);
+
 /* Upload topology + geometry; builds the node->strut incidence.  Replaces BeamModel.__init__ /
  * latticeGeneration (beam_model.py:57-105, lattice_generation.py:64-175). */
 int pl_create(const pl_mesh_t *mesh, const pl_opts_t *opts, pl_handle *out);

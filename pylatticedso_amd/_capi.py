@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpylattice_hip.so")
 PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
-EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_create", "pl_create_ddm",
+EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
            "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_schur",
@@ -69,7 +69,7 @@ def load_library(path: str | None = None):
     lib.pl_destroy.restype = None
     lib.pl_default_opts.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
-    sig = {"pl_default_opts": [V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
+    sig = {"pl_default_opts": [V], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
            "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
            "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
@@ -99,6 +99,17 @@ def _check(lib, rc, allow=()):
     if rc != PL_OK and rc not in allow:
         raise PlError(rc, lib.pl_last_error().decode())
     return rc
+
+
+def lzone(node_xyz, beam_conn, beam_radius, device=0):
+    """(B, 2) joint-penalisation lengths of a non-periodic lattice on the device (pl_lzone)."""
+    lib = load_library()
+    xyz = _f64(np.asarray(node_xyz).reshape(-1))
+    conn = np.ascontiguousarray(beam_conn, dtype=np.int32).reshape(-1)
+    rad = _f64(np.asarray(beam_radius).reshape(-1), len(conn) // 2)
+    out = np.empty(len(conn), np.float64)
+    _check(lib, lib.pl_lzone(int(device), len(xyz) // 3, len(conn) // 2, _ptr(xyz), _ptr(conn), _ptr(rad), _ptr(out)))
+    return out.reshape(-1, 2)
 
 
 def debug_spd_solve(A, b, device=0, fp32_factor=False):

@@ -16,6 +16,7 @@
 #include "pl_coarse.h"
 #include "pl_palette.h"
 #include "pl_ddm.h"
+#include "pl_lzone.h"
 
 namespace {
 
@@ -1552,6 +1553,49 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
                        int32_t fp32_factor) {
   return fp32_factor ? debug_spd_solve_t<float>(device, n, A, b, x, quad)
                      : debug_spd_solve_t<double>(device, n, A, b, x, quad);
+}
+
+int pl_lzone(int device, int64_t n_nodes, int64_t n_beams, const double *node_xyz, const int32_t *beam_conn,
+             const double *beam_radius, double *lzone) {
+  if (n_nodes <= 0 || n_beams <= 0 || !node_xyz || !beam_conn || !beam_radius || !lzone)
+    return fail(PL_ERR_ARG, "pl_lzone: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PL_ERR_NODEVICE, "pl_lzone: no HIP device visible (libpylattice_hip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(PL_ERR_ARG, "pl_lzone: bad device ordinal");
+  const int64_t nh = 2 * n_beams;
+  std::vector<int64_t> ptr((size_t)n_nodes + 1, 0);
+  for (int64_t h = 0; h < nh; ++h) {
+    const int32_t v = beam_conn[h];
+    if (v < 0 || v >= n_nodes) return fail(PL_ERR_ARG, "pl_lzone: node id out of range");
+    ptr[(size_t)v + 1]++;
+  }
+  for (int64_t i = 0; i < n_nodes; ++i) ptr[i + 1] += ptr[i];
+  std::vector<int32_t> half((size_t)nh);
+  {
+    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t h = 0; h < nh; ++h) half[(size_t)fill[beam_conn[h]]++] = (int32_t)h;
+  }
+  PL_HIP(hipSetDevice(device));
+  DevBuf<double> dx, dr, dl;
+  DevBuf<int32_t> dc, dh;
+  DevBuf<int64_t> dp;
+  PL_HIP(dx.alloc((size_t)n_nodes * 3));
+  PL_HIP(dr.alloc(n_beams));
+  PL_HIP(dl.alloc(nh));
+  PL_HIP(dc.alloc(nh));
+  PL_HIP(dh.alloc(nh));
+  PL_HIP(dp.alloc(n_nodes + 1));
+  PL_HIP(hipMemcpy(dx.p, node_xyz, (size_t)n_nodes * 3 * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(dr.p, beam_radius, n_beams * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(dc.p, beam_conn, nh * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(dh.p, half.data(), nh * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(dp.p, ptr.data(), (n_nodes + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pl::k_lzone, dim3(grid_for(nh)), dim3(pl::kBlock), 0, nullptr, nh, dx.p, dc.p, dr.p, dp.p, dh.p,
+                     dl.p);
+  PL_HIP(hipGetLastError());
+  PL_HIP(hipMemcpy(lzone, dl.p, nh * sizeof(double), hipMemcpyDeviceToHost));
+  return PL_OK;
 }
 
 int pl_dist_unique_id_bytes(void) { return pl::dist_unique_id_bytes(); }

@@ -247,7 +247,13 @@ class LatticeSim:
 
     # ------------------------------------------------------------------------------------------------
     def define_angles_between_beams(self):
-        self.lzone = LA.compute_lzone(self.lattice, bool(self.enable_periodicity))
+        """lattice.py:805-904.  Large non-periodic lattices take the device kernel (pl_lzone: the valence^2 angle search
+        is 10^7-10^8 pair evaluations at 10^6 struts); small ones and periodic single cells the numpy restatement."""
+        if not self.enable_periodicity and self.lattice.n_nodes >= 20000:
+            from ._capi import lzone
+            self.lzone = lzone(self.lattice.node_xyz, self.lattice.beam_conn, self.lattice.beam_radius)
+        else:
+            self.lzone = LA.compute_lzone(self.lattice, bool(self.enable_periodicity))
 
     def set_penalized_beams(self):
         self.penalized = LA.penalize(self.lattice, self.lzone)

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import c_oracle, timoshenko_oracle as O   # noqa: E402
-from pylatticedso_amd import _capi                      # noqa: E402
+from pylatticedso_amd import _capi, lattice_arrays as LA   # noqa: E402
 from pylatticedso_amd.lattice_sim import LatticeSim     # noqa: E402
 from pylatticedso_amd.utils_schur import get_schur_complement  # noqa: E402
 from pylatticedso_amd.utils_simulation import solve_FEM_FenicsX  # noqa: E402
@@ -535,3 +535,50 @@ def test_record_palette_matches_plain_records(golden_dir, name):
         y2 = dev.spmv(x)
     assert _rel(y1, y0) < 1e-11
     assert _rel(y2, y0) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_3x2x2_gradradius"])
+def test_device_lzone_matches_reference_golden(golden_dir, name):
+    """pl_lzone against the penalisation lengths the reference itself computed (golden base_beam_lzone), and against
+    the numpy restatement."""
+    g, L = _sim(golden_dir, name)
+    lat = L.lattice
+    dev = _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius)
+    host = LA.compute_lzone(lat, False)
+    assert dev.shape == host.shape == (lat.n_beams, 2)
+    assert np.allclose(dev, host, rtol=1e-13, atol=1e-18)
+    # reference: Lzone per base beam, matched through the end-point coordinates
+    key = lambda a, b: tuple(np.round(np.r_[a, b], 9))
+    ref = {key(g["base_node_xyz"][a], g["base_node_xyz"][b]): lz
+           for (a, b), lz in zip(g["base_beam_conn"], g["base_beam_lzone"])}
+    hit = 0
+    for (a, b), lz in zip(lat.beam_conn, dev):
+        k1, k2 = key(lat.node_xyz[a], lat.node_xyz[b]), key(lat.node_xyz[b], lat.node_xyz[a])
+        if k1 in ref:
+            assert np.allclose(lz, ref[k1], rtol=1e-12, atol=1e-15)
+            hit += 1
+        elif k2 in ref:
+            assert np.allclose(lz[::-1], ref[k2], rtol=1e-12, atol=1e-15)
+            hit += 1
+    assert hit == lat.n_beams
+
+
+def test_device_lzone_large_and_errors():
+    lat = LA.generate((1, 1, 1), (24, 24, 24), ["BCC", "Octet"], [0.04, 0.03])
+    import time
+    t0 = time.perf_counter()
+    host = LA.compute_lzone(lat, False)
+    t1 = time.perf_counter()
+    dev = _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius)
+    t2 = time.perf_counter()
+    assert np.allclose(dev, host, rtol=1e-13, atol=1e-18) and (dev >= 0).all()
+    print(f"L_zone of {lat.n_beams} struts: numpy {t1 - t0:.2f} s, device (incl. transfers) {t2 - t1:.3f} s")
+    # a strut alone at its nodes has no neighbour: 0; collinear continuation: 1e-7
+    xyz = np.array([[0.0, 0, 0], [1, 0, 0], [2, 0, 0], [5, 5, 5], [6, 5, 5]])
+    conn = np.array([[0, 1], [1, 2], [3, 4]], np.int32)
+    lz = _capi.lzone(xyz, conn, np.array([0.1, 0.2, 0.3]))
+    assert np.array_equal(lz, [[0.0, 1e-7], [1e-7, 0.0], [0.0, 0.0]])
+    bad = conn.copy()
+    bad[0, 0] = 9
+    with pytest.raises(_capi.PlError):
+        _capi.lzone(xyz, bad, np.array([0.1, 0.2, 0.3]))
