@@ -86,3 +86,26 @@ def test_periodic_partners_by_coordinates_reproduce_the_tag_groups(golden_dir, n
         assert np.allclose(eps, expect, atol=1e-12)
     with pytest.raises(ValueError):
         imposed_displacement(7, xyz)
+
+
+def test_engineering_constants_and_directional_modulus_of_an_isotropic_solid():
+    """Post-processing of HomogenizedCell on a matrix with a known answer: isotropic C (tensorial-shear convention of
+    the reference: C44 = 2 G) -> Ex = E, nu, G, and the same directional modulus in every direction."""
+    from pylatticedso_amd.homogenization_cell import HomogenizedCell, directional_modulus
+    Em, nu = 10.0, 0.3
+    lam, G = Em * nu / ((1 + nu) * (1 - 2 * nu)), Em / (2 * (1 + nu))
+    C = np.zeros((6, 6))
+    C[:3, :3] = lam
+    C[np.arange(3), np.arange(3)] = lam + 2 * G
+    C[np.arange(3, 6), np.arange(3, 6)] = 2 * G
+    H = HomogenizedCell.__new__(HomogenizedCell)
+    H.homogenizeMatrix = C
+    H.convert_to_orthotropic_form()
+    H.compute_errors()
+    M = H.orthotropicMatrix
+    assert np.allclose([M[0, 0], M[1, 1], M[2, 2]], Em) and np.allclose([M[3, 3], M[4, 4], M[5, 5]], G)
+    assert np.allclose([M[0, 1], M[0, 2], M[1, 2]], nu) and H._symmetryError == 0.0
+    S = H.get_S_orthotropic()
+    assert np.allclose(S[:3, :3] @ C[:3, :3], np.eye(3)) and np.allclose(np.diag(S)[3:], 1 / G)
+    for theta, phi in [(90, 0), (90, 45), (54.7356, 45), (30, 200), (0, 0)]:
+        assert np.isclose(np.linalg.norm(directional_modulus(S, theta, phi)), Em, rtol=1e-12)

@@ -142,3 +142,44 @@ def test_greedy_1e6_reproduces_the_committed_reduced_basis():
     sign = np.sign((basis * ref["basis_reduced_ortho"]).sum(axis=0))
     assert np.abs(basis * sign - ref["basis_reduced_ortho"]).max() < 1e-8
     assert _rel(alpha * sign[:, None], ref["alpha_ortho"]) < 1e-8
+
+
+def test_preconditioner_dataset_lookup_and_cell_parameter_radii(golden_dir):
+    """Host side of the reference's DDM preconditioner (lattice_sim.py:1312-1329,1351-1415): which dataset each
+    preconditioner_type reads, the fall-backs of "mean", and Cell.radii (un-graded) as the key of everything."""
+    import json
+    import os
+    from pylatticedso_amd.lattice_sim import LatticeSim
+    preset = json.loads(str(np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))["preset_json"]))
+    ddm = preset["simulation_parameters"]["DDM"]
+    ddm.update(enable_preconditioner=True, preconditioner_type="nearest_reference")
+    preset["gradient"] = {"radii": {"rule": "linear", "direction_x": True, "direction_y": False, "direction_z": False,
+                                    "parameter_x": 0.25, "parameter_y": 0.0, "parameter_z": 0.0}}
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    # the preset gradient scales the struts, not Cell.radii: one surrogate matrix, parameter radii all 0.05
+    assert len({tuple(np.round(r, 8)) for r in L.lattice.cell_radii}) > 1
+    assert np.allclose(L._cell_parameter_radii(), 0.05) and L.schur_complements.shape[0] == 1
+    path = L._define_preconditioner_approximation()
+    assert path.endswith("Schur_complement_BCC.npz") and L.used_schur_preconditioner["schur_matrices"].shape == (10, 48, 48)
+    L.preconditioner_type, L.used_schur_preconditioner = "mean", None
+    path = L._define_preconditioner_approximation()          # no Schur_complement_mean_BCC.npz: mean of the dataset
+    d = np.load(os.path.join(golden_dir, "Schur_complement_BCC.npz"))
+    assert path.endswith("Schur_complement_BCC.npz")
+    assert np.allclose(L.used_schur_preconditioner["schur_matrices"], d["schur_matrices"].mean(axis=0))
+    L.data_roots, L.used_schur_preconditioner = [], None
+    os.environ.pop("PYLATTICE_DATA_ROOT", None)
+    assert L._define_preconditioner_approximation() is None and L._mean_of_own_cells     # nothing on disk
+    L.preconditioner_type = "exact"
+    assert L._define_preconditioner_approximation() is None
+    L.preconditioner_type = "nearest_reference"
+    with pytest.raises(FileNotFoundError):
+        L._define_preconditioner_approximation()
+    ddm["preconditioner_type"] = "nonsense"
+    with pytest.raises(NotImplementedError):
+        LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    # per-cell radii the way LatticeOpti sets them
+    ddm["preconditioner_type"] = "exact"
+    preset.pop("gradient")
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    L.set_cell_radii(0.04 + 0.0125 * L.lattice.cell_pos[:, 0])
+    assert L.schur_complements.shape[0] == 4 and np.allclose(np.unique(L._cell_parameter_radii()), [0.04, 0.0525, 0.065, 0.0775])
