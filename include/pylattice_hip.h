@@ -68,7 +68,8 @@ typedef struct {
   int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
   int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
   int32_t tile_nodes;    /* target nodes per brick/tile of the spatial reordering, <= 512 (0 -> 256) */
-  int32_t coarse_max_dofs; /* precond = 2/3: upper bound on 6 * (number of aggregates) (0 -> 3072) */
+  int32_t coarse_max_dofs; /* precond = 2/3: upper bound on 6 * (number of aggregates) (0 -> 2100 below 10^6 nodes
+                              on one GPU, 3072 otherwise) */
   int32_t palette;       /* 1: K*p (LDS-tile kernel) reads 2-byte palette ids instead of 64-byte records when the lattice
                             has <= ~30 000 distinct records (compared on 40 mantissa bits, i.e. to 1e-12) */
   int32_t local_max_dofs;  /* precond = 4: upper bound on 6 * (aggregates of the rank-local level) (0 -> 3072) */

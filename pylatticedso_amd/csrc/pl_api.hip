@@ -904,7 +904,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (o->precond >= 2 && o->precond <= 4) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
     c->coarse.tile_level = (o->precond >= 3);
-    const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : 3072;
+    // default size of the dense level: its factorisation is a ~45 us-per-64-dofs latency chain in every assembly, its
+    // benefit grows with the cost of an iteration - up to 1 M nodes on one GPU the optimum is ~2 000 dofs (measured on
+    // 50^3 Octet: 7^3 aggregates 18.9 ms per step, 8^3 20.7 ms), beyond that and in multi-rank runs (collectives in
+    // every iteration) the full 3 072
+    const bool multi_rank = o->grid_nodes > 0;
+    const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : ((multi_rank || N >= 1000000) ? 3072 : 2100);
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
     PL_HIPC(c->sharedbits.alloc(N));

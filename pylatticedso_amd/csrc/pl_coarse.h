@@ -76,15 +76,18 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
                         const std::vector<int32_t> &conn, bool local = false) {
   const int64_t T = (int64_t)tile_start.size() - 1;
   const int64_t *nbrick = grid.nb;
-  auto grid_agg = [&](int64_t key, int g, const int64_t *na) {
+  // aggregate index of a brick along axis k: floor(b * na_k / nb_k) - groups of bricks whose sizes differ by at most one,
+  // so that the aggregate grid can use the dofs it is allowed (13 bricks per axis -> 8 aggregates, not ceil(13/2) = 7)
+  auto grid_agg = [&](int64_t key, int /*g*/, const int64_t *na) {
     const int64_t b2 = key % nbrick[2], b1 = (key / nbrick[2]) % nbrick[1], b0 = key / (nbrick[2] * nbrick[1]);
-    return ((b0 / g) * na[1] + (b1 / g)) * na[2] + (b2 / g);
+    return ((b0 * na[0] / nbrick[0]) * na[1] + (b1 * na[1] / nbrick[1])) * na[2] + (b2 * na[2] / nbrick[2]);
   };
   int g = 2;
   int64_t na[3];
   std::vector<int64_t> used;                       // local: sorted grid ids of the aggregates that hold tiles
-  for (;; ++g) {
-    for (int k = 0; k < 3; ++k) na[k] = (nbrick[k] + g - 1) / g;
+  for (int step = 0;; ++step) {
+    const double scale = 1.5 + 0.125 * step;       // bricks per aggregate and axis, at least 1.5
+    for (int k = 0; k < 3; ++k) na[k] = std::max<int64_t>(1, (int64_t)std::floor((double)nbrick[k] / scale));
     int64_t count = na[0] * na[1] * na[2];
     if (local) {
       used.clear();
@@ -93,7 +96,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
       used.erase(std::unique(used.begin(), used.end()), used.end());
       count = (int64_t)used.size();
     }
-    if (count * 6 <= max_dofs || g > 64) break;
+    if (count * 6 <= max_dofs || scale > 64.0) break;
   }
   const int n_agg = local ? (int)used.size() : (int)(na[0] * na[1] * na[2]);
   std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
@@ -101,7 +104,10 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   for (int a = 0; a < n_agg; ++a) {
     const int64_t ga = local ? used[a] : a;
     const int64_t ai[3] = {ga / (na[1] * na[2]), (ga / na[2]) % na[1], ga % na[2]};
-    for (int k = 0; k < 3; ++k) cen[3 * a + k] = grid.lo[k] + (ai[k] + 0.5) * g * grid.side;
+    for (int k = 0; k < 3; ++k) {   // centre of the aggregate's range of bricks
+      const int64_t b_lo = (ai[k] * nbrick[k] + na[k] - 1) / na[k], b_hi = ((ai[k] + 1) * nbrick[k] + na[k] - 1) / na[k];
+      cen[3 * a + k] = grid.lo[k] + 0.5 * (double)(b_lo + b_hi) * grid.side;
+    }
   }
   for (int64_t t = 0; t < T; ++t) {
     const int64_t ga = grid_agg(tile_brick[t], g, na);
