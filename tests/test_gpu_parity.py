@@ -441,7 +441,8 @@ def test_two_rank_workload_emulated_on_one_gpu():
     (u0, s0), (u1, s1) = out
     assert s0["converged"] == 1 and s1["converged"] == 1
     assert _rel(u1, u0) < 1e-6
-    assert s0["iterations"] <= 195 and s1["iterations"] <= 200          # measured: 188 and 191
+    print("iterations without / with the interface plane declared shared:", s0["iterations"], s1["iterations"])
+    assert s0["iterations"] <= 170 and s1["iterations"] <= 175          # measured: 152 and 155
 
 
 @pytest.mark.parametrize("name", ["bcc_4x4x4", "bcc_6x3x3_flexion"])
