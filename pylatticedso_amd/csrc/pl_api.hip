@@ -429,8 +429,18 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
                        cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
                        mask, n, cs.Ac);
   if (reduce && c->dist.active) {   // every rank holds the contribution of ITS struts; all ranks then factor the same matrix
-    if (pl::dist_sum_scalars(c->dist, cs.Ac, n * n, c->stream))
+    const int nb = n / pl::kNB;
+    if (cs.bw_blocks > 0 && cs.bw_blocks + 1 < nb) {   // only the block band of the lower triangle travels (L_f is free)
+      const int64_t cnt = (int64_t)n * (cs.bw_blocks + 1) * pl::kNB;
+      hipLaunchKernelGGL(pl::k_band_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, n, n,
+                         cs.bw_blocks, cs.Ac, cs.Lf);
+      if (pl::dist_sum_scalars(c->dist, cs.Lf, (int)cnt, c->stream))
+        return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
+      hipLaunchKernelGGL(pl::k_band_unpack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, n, n,
+                         cs.bw_blocks, cs.Lf, cs.Ac);
+    } else if (pl::dist_sum_scalars(c->dist, cs.Ac, n * n, c->stream)) {
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse operator failed");
+    }
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
   pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);

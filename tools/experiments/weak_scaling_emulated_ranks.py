@@ -21,4 +21,5 @@ for pc, lmax in ((3, 0), (4, 2200 * N)):
         t0 = time.time(); dev.assemble(); ta = time.time() - t0
         st = dev.solve(rtol=1e-8, max_iter=20000, download=False)
         st = st[-1] if isinstance(st, tuple) else st
-        print(f"N={N} precond {pc}: iterations {st['iterations']} converged {st['converged']} (assemble {ta:.2f} s)", flush=True)
+        print(f"N={N} precond {pc}: iterations {st['iterations']} converged {st['converged']} "
+              f"(device assembly {st['ms_assembly']:.2f} ms, solve {st['ms_solve']:.1f} ms)", flush=True)
