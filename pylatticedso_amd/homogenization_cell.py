@@ -24,8 +24,8 @@ Two deliberate differences, both only visible where the reference misbehaves: pe
 coordinates modulo the cell size (the reference pairs ``locate_dofs_topological`` results of equal boundary tags in
 index order, right only for one node per tag), and reactions are summed over every boundary node (the reference takes
 the first vertex of each tag).  Cells without a vertex at the centre (e.g. Octet) leave the reference's matrix with
-three translational null vectors; here the first master node is anchored instead, and likewise one node of every
-further connected part of a hybrid cell whose geometries do not touch (macro stresses do not depend on either).
+three translational null vectors; here the first master node is anchored instead (macro stresses do not depend on
+it).  A cell that is not connected (a mechanism) raises.
 """
 from __future__ import annotations
 
@@ -135,16 +135,10 @@ class HomogenizedCell:
         cols = (6 * node_slot[:, None] + np.arange(6)).ravel()
         P = sp.csr_matrix((np.ones(6 * N), (np.arange(6 * N), cols)), shape=(6 * N, 6 * len(masters)))
         Kr = (P.T @ K @ P).toarray()
-        # one translation anchor per connected part of the periodic cell: the centre vertex where the reference puts
-        # its Dirichlet condition, else the first node of the part (hybrid cells made of geometries that do not touch
-        # would otherwise keep a relative rigid translation, which no macro stress depends on)
-        from scipy.sparse.csgraph import connected_components
-        blocks = sp.csr_matrix(np.abs(Kr).reshape(len(masters), 6, len(masters), 6).sum(axis=(1, 3)) > 0)
-        n_parts, part = connected_components(blocks, directed=False)
-        anchors = [int(np.flatnonzero(part == c)[0]) for c in range(n_parts)]
-        if self._anchor is not None:
-            anchors[part[node_slot[self._anchor]]] = int(node_slot[self._anchor])
-        fixed = (6 * np.asarray(anchors)[:, None] + np.arange(3)).ravel()
+        # translation anchor: the centre vertex where the reference puts its Dirichlet condition, else the first
+        # master node (macro stresses do not depend on it)
+        anchor = int(node_slot[self._anchor]) if self._anchor is not None else 0
+        fixed = 6 * anchor + np.arange(3)
         free = np.setdiff1d(np.arange(Kr.shape[0]), fixed)
         try:
             factor = scipy.linalg.cho_factor(Kr[np.ix_(free, free)])

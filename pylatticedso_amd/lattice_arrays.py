@@ -185,15 +185,122 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     beam_conn = conn_u[border].astype(np.int32)
     bid = brank[binv]                                           # (C*nb,) beam index of each created strut
 
-    cb_ptr, cb_idx = _csr_from_pairs(cell_of, bid, C)
+    beam_radius, beam_type, beam_cell0 = rad_u[border], typ_u[border].astype(np.int32), cell0_u[border].astype(np.int32)
+    pair_cell, pair_beam = cell_of, bid
+    if len(geom_types) > 1:                                      # lattice.py:482-483
+        split = _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, beam_type, beam_cell0)
+        if split is not None:
+            beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx = split
+            # every (cell, strut) membership goes to all segments of that strut (per_cell_add, lattice.py:1188-1195)
+            cnt = np.diff(new_of_old_ptr)[pair_beam]
+            start = new_of_old_ptr[pair_beam]
+            pair_cell = np.repeat(pair_cell, cnt)
+            within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            pair_beam = new_of_old_idx[np.repeat(start, cnt) + within]
+
+    cb_ptr, cb_idx = _csr_from_pairs(pair_cell, pair_beam, C)
     cn_ptr, cn_idx = _csr_from_pairs(np.repeat(np.arange(C), nb * 2), pid.ravel(), C)
     bbox = np.array([node_xyz[:, 0].min(), node_xyz[:, 0].max(), node_xyz[:, 1].min(), node_xyz[:, 1].max(),
                      node_xyz[:, 2].min(), node_xyz[:, 2].max()])
-    return LatticeArrays(node_xyz=node_xyz, beam_conn=beam_conn, beam_radius=rad_u[border],
-                         beam_type=typ_u[border].astype(np.int32), beam_cell0=cell0_u[border].astype(np.int32),
+    return LatticeArrays(node_xyz=node_xyz, beam_conn=beam_conn, beam_radius=beam_radius,
+                         beam_type=beam_type, beam_cell0=beam_cell0,
                          cell_pos=pos, cell_coord=coord, cell_size=size, cell_radii=cell_radii,
                          cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr, cell_node_idx=cn_idx,
                          bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)))
+
+
+def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, beam_type, beam_cell0):
+    """Lattice.check_hybrid_collision (lattice.py:1111-1215): in a hybrid lattice a strut of one geometry that passes
+    through a node of another geometry OF THE SAME CELL is replaced by the chain of segments between those nodes
+    (same radius, type and owner cells; orientation of the original strut).  Returns None when nothing is cut, else the
+    re-indexed strut arrays (define_beam_node_index order, lattice.py:665-685) plus a CSR map old strut -> new struts.
+
+    Two passes: (1) on the unit-cell template, with a tolerance, the few (strut, template point) pairs that can
+    collide at all; (2) for those pairs only, in every cell, the reference's exact floating-point tests on the actual
+    node coordinates (AABB with 1e-12, Beam.is_point_on_beam beam.py:332-362 with its exact-zero cross product, and
+    1e-12 < t < 1 - 1e-12)."""
+    C, nb, _ = pid.shape
+    # (1) template points and candidate pairs
+    tpts, tinv = np.unique(np.round(tmpl.reshape(-1, 3), 9), axis=0, return_inverse=True)
+    tp = tinv.ravel().reshape(nb, 2)                               # template point id of every template strut end
+    a, b = tpts[tp[:, 0]], tpts[tp[:, 1]]
+    v = b - a                                                      # (nb, 3)
+    w = tpts[None, :, :] - a[:, None, :]                           # (nb, npt, 3)
+    L2 = (v * v).sum(axis=1)
+    cr = np.cross(np.broadcast_to(v[:, None, :], w.shape), w)
+    t = (w * v[:, None, :]).sum(axis=2) / np.where(L2 > 0, L2, 1.0)[:, None]
+    cand = (np.abs(cr).max(axis=2) <= 1e-9) & (t > 1e-9) & (t < 1 - 1e-9) & (L2 > 0)[:, None]
+    cs, cq = np.nonzero(cand)
+    if len(cs) == 0:
+        return None
+    # node id of template point q in every cell: any (strut, end) that carries it
+    first_slot = np.full(len(tpts), -1, np.int64)
+    flat_tp = tp.ravel()
+    first_slot[flat_tp[::-1]] = np.arange(len(flat_tp))[::-1]
+    pid_flat = pid.reshape(C, nb * 2)
+    node_q = pid_flat[:, first_slot[cq]]                          # (C, ncand)
+    beam_c = bid.reshape(C, nb)[:, cs]                            # (C, ncand) strut (index before the split)
+    p1, p2 = beam_conn[beam_c, 0].astype(np.int64), beam_conn[beam_c, 1].astype(np.int64)
+    # (2) exact tests
+    A, B_, Nn = node_xyz[p1], node_xyz[p2], node_xyz[node_q]
+    vx, vy, vz = B_[..., 0] - A[..., 0], B_[..., 1] - A[..., 1], B_[..., 2] - A[..., 2]
+    wx, wy, wz = Nn[..., 0] - A[..., 0], Nn[..., 1] - A[..., 1], Nn[..., 2] - A[..., 2]
+    L2 = vx * vx + vy * vy + vz * vz
+    tol = 1e-12
+    ok = (node_q != p1) & (node_q != p2) & (L2 > 0.0)
+    for ax in range(3):
+        lo, hi = np.minimum(A[..., ax], B_[..., ax]), np.maximum(A[..., ax], B_[..., ax])
+        ok &= (lo - tol <= Nn[..., ax]) & (Nn[..., ax] <= hi + tol)
+    ok &= ~((Nn == A).all(axis=-1) | (Nn == B_).all(axis=-1))
+    ok &= (vy * wz - vz * wy == 0) & (vz * wx - vx * wz == 0) & (vx * wy - vy * wx == 0)
+    dot = wx * vx + wy * vy + wz * vz
+    ok &= (0 <= dot) & (dot <= vx ** 2 + vy ** 2 + vz ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tt = dot / L2
+    ok &= (tt > 1e-12) & (tt < 1.0 - 1e-12)
+    if not ok.any():
+        return None
+    cut_beam, cut_node, cut_t = beam_c[ok], node_q[ok], tt[ok]
+    # a strut shared by several cells is cut once per owner cell in the reference, which leaves every segment twice
+    # in the lattice (Beam objects hash by identity): an ill-defined model that is not reproduced here
+    ncell_of_beam = np.bincount(np.unique(np.stack([np.repeat(np.arange(C), nb), bid]), axis=1)[1],
+                                minlength=len(beam_conn))
+    if (ncell_of_beam[cut_beam] > 1).any():
+        raise NotImplementedError(
+            "hybrid collision on a strut shared by several cells: the reference (lattice.py:1111-1215) splits it once "
+            "per owner cell and keeps every copy, i.e. duplicate struts; this lattice is outside the accelerated path")
+    key = np.unique(np.stack([cut_beam, cut_node]), axis=1, return_index=True)[1]
+    cut_beam, cut_node, cut_t = cut_beam[key], cut_node[key], cut_t[key]
+    order = np.lexsort((cut_t, cut_beam))                        # internal.sort(key=t), lattice.py:1176
+    cut_beam, cut_node = cut_beam[order], cut_node[order]
+    M = len(cut_beam)
+    first = np.ones(M, bool)
+    first[1:] = cut_beam[1:] != cut_beam[:-1]
+    last = np.ones(M, bool)
+    last[:-1] = cut_beam[:-1] != cut_beam[1:]
+    seg_a = np.where(first, beam_conn[cut_beam, 0], np.concatenate([[0], cut_node[:-1]]))
+    seg_b = cut_node
+    tail_a, tail_b = cut_node[last], beam_conn[cut_beam[last], 1]
+    parent = np.concatenate([cut_beam, cut_beam[last]])
+    sconn = np.stack([np.concatenate([seg_a, tail_a]), np.concatenate([seg_b, tail_b])], axis=1)
+    is_cut = np.zeros(len(beam_conn), bool)
+    is_cut[cut_beam] = True
+    keep = np.flatnonzero(~is_cut)
+    conn = np.concatenate([beam_conn[keep].astype(np.int64), sconn])
+    src = np.concatenate([keep, parent])                          # strut (old numbering) every new strut comes from
+    rad, typ, cell0 = beam_radius[src], beam_type[src], beam_cell0[src]
+    lo, hi = conn.min(axis=1), conn.max(axis=1)
+    pair = lo * len(node_xyz) + hi
+    if len(np.unique(pair)) != len(pair):
+        raise NotImplementedError("hybrid collision produces a segment that coincides with another strut (the reference "
+                                  "keeps both); this lattice is outside the accelerated path")
+    border = np.lexsort((rad, hi, lo))                            # beam_key, lattice.py:675-680
+    rank = np.empty(len(border), np.int64)
+    rank[border] = np.arange(len(border))
+    o = np.argsort(src, kind="stable")
+    ptr = np.zeros(len(beam_conn) + 1, np.int64)
+    np.add.at(ptr, src + 1, 1)
+    return (conn[border].astype(np.int32), rad[border], typ[border], cell0[border], np.cumsum(ptr), rank[o])
 
 
 # ------------------------------------------------------------------------------------------------

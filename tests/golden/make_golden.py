@@ -204,8 +204,19 @@ def gen_lattice_states():
                                                             "direction_y": False, "direction_z": False,
                                                             "parameter_x": 0.5, "parameter_y": 0.0,
                                                             "parameter_z": 0.0}}),
+        # hybrids whose struts are cut by another geometry's node (check_hybrid_collision, lattice.py:1111-1215):
+        # every BCC diagonal passes through an octant point of Hybrid1 / Hybrid4
+        "bcchybrid1_1x1x1_periodic": _preset(["BCC", "Hybrid1"], [0.05, 0.03], (1, 1, 1), periodicity=True),
+        "bcchybrid1_2x2x2": _preset(["BCC", "Hybrid1"], [0.05, 0.03], (2, 2, 2), bcs=CANTILEVER),
+        "bcchybrid4_1x1x1_periodic": _preset(["BCC", "Hybrid4"], [0.05, 0.03], (1, 1, 1), periodicity=True),
+        "bcchybrid4_2x2x2": _preset(["BCC", "Hybrid4"], [0.04, 0.03], (2, 2, 2), bcs=CANTILEVER),
+        "bcchybrid1hybrid4_3x2x1_size": _preset(["BCC", "Hybrid1", "Hybrid4"], [0.05, 0.04, 0.03], (3, 2, 1),
+                                                cell_size=(1.5, 1.0, 0.7), bcs=CANTILEVER),
     }
+    only = [a[len("lattice_"):] for a in sys.argv[1:] if a.startswith("lattice_")]
     for name, preset in cases.items():
+        if only and name not in only:
+            continue
         L = _make(preset)
         st = _dump_state(L)
         st.update(_dump_angles(preset))
@@ -419,7 +430,7 @@ if __name__ == "__main__":
         gen_greedy()
     if "surrogate" in which:
         gen_surrogate()
-    if "lattice" in which:
+    if "lattice" in which or any(w.startswith("lattice_") for w in which):
         gen_lattice_states()
     if "schur" in which:
         gen_schur()

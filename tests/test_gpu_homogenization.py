@@ -23,7 +23,7 @@ def _oracle(g):
     return O.homogenize_submeshed(K, V, g["node_tag"])
 
 
-@pytest.mark.parametrize("name", ["bcc", "hybrid4"])
+@pytest.mark.parametrize("name", ["bcc", "hybrid4", "bcchybrid1", "bcchybrid4"])
 def test_homogenized_matrix_matches_oracle(golden_dir, name, capsys):
     g = np.load(os.path.join(golden_dir, f"lattice_{name}_1x1x1_periodic.npz"))
     L = LatticeSim(json.loads(str(g["preset_json"])))

@@ -40,7 +40,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_3x2x2_gradradius",
-                                  "hybrid4_1x1x1_periodic"])
+                                  "hybrid4_1x1x1_periodic", "bcchybrid1_2x2x2", "bcchybrid4_1x1x1_periodic",
+                                  "bcchybrid1hybrid4_3x2x1_size"])
 def test_records_match_oracle(golden_dir, name):
     _, L = _sim(golden_dir, name)
     with _device(L) as dev:
@@ -56,7 +57,8 @@ def test_records_match_oracle(golden_dir, name):
 
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("reorder", [0, 1])
-@pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_1x1x1_periodic"])
+@pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_1x1x1_periodic",
+                                  "bcchybrid1_2x2x2", "bcchybrid1hybrid4_3x2x1_size"])
 def test_spmv_matches_oracle(golden_dir, name, kernel, reorder):
     _, L = _sim(golden_dir, name)
     lat = L.lattice
@@ -127,7 +129,8 @@ def test_bsr_assembly_matches_oracle(golden_dir, name):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("name", ["bcc_2x2x2", "bcc_4x4x4", "bcc_6x3x3_flexion", "bcc_3x2x2_gradradius"])
+@pytest.mark.parametrize("name", ["bcc_2x2x2", "bcc_4x4x4", "bcc_6x3x3_flexion", "bcc_3x2x2_gradradius",
+                                  "bcchybrid1_2x2x2", "bcchybrid4_2x2x2", "bcchybrid1hybrid4_3x2x1_size"])
 def test_solve_matches_reference_faithful_direct_solve(golden_dir, name, kernel):
     """GPU PCG on condensed struts vs sparse-direct solve of the reference-faithful sub-meshed model built from
     the segments / BCs the reference itself produced (golden state).  Bar: 1e-6 relative L2 (we get ~1e-9)."""
