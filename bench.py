@@ -15,7 +15,9 @@ preconditioner and its dense factorisation) + explicit BSR(6x6) global-K assembl
 ||r|| <= rtol ||b|| — all on data already resident in HBM.
 value = struts of the whole job * steps / time.  The roofline object prices the dominant kernel (K*p) with the
 algorithmic bytes of SURVEY.md 8(d) and a HIP-event timing taken on the library's own stream; cpu_baseline is the
-plain-C oracle (oracle/beam_pcg.c, 1 thread) on a bounded sample of the same workload.
+plain-C oracle (oracle/beam_pcg.c) on all host cores, plus the reference-faithful sub-meshed + sparse-LU leg, on
+bounded samples of the same workload; end_to_end_s is the wall clock of the drop-in call site (LatticeSim +
+solve_FEM_FenicsX) for the same lattice.
 """
 import argparse
 import json
@@ -53,20 +55,94 @@ def dev_kernel_name(kernel, reorder):
     return {1: "k_spmv_atomic", 2: "k_spmv_gather", 3: "k_spmv_tile"}[k]
 
 
-def cpu_baseline(cells, radius, rtol):
-    """Plain-C oracle (1 thread) on a bounded sample of the same workload: same lattice type / BCs, fewer cells."""
-    from oracle import c_oracle
+def cpu_baseline(cells, radius, rtol, splu_cells):
+    """CPU legs on the host cores of this box, on bounded samples of the same workload (same lattice type / BCs, fewer
+    cells).  (ii) of SURVEY 8(d): the plain-C oracle - condensed struts, matrix-free Jacobi-PCG - on ALL cores (OpenMP,
+    thread count reported) and on one; (i): the reference-faithful discretisation - every penalised segment sub-meshed
+    like gmsh does, scipy CSR assembly + SuperLU (stand-in for PETSc preonly/lu) - on a size it can finish."""
+    from oracle import c_oracle, timoshenko_oracle as O
     from pylatticedso_amd import lattice_arrays as LA
     lat = LA.generate((1, 1, 1), (cells,) * 3, ["Octet"], [radius])
     pen = LA.penalize(lat, LA.compute_lzone(lat))
     fixed, f, _ = cantilever_bc(lat.node_xyz, float(cells))
+    legs = {}
+    u = None
+    for name, mt in (("all_cores", True), ("one_core", False)):
+        t0 = time.perf_counter()
+        sc = c_oracle.condense_unique(lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU)
+        u, it, rel = c_oracle.pcg(lat.node_xyz, lat.beam_conn, sc, fixed, np.zeros_like(f), f, rtol=rtol, maxit=100000,
+                                  all_cores=mt)
+        legs[name] = (lat.n_beams / (time.perf_counter() - t0), time.perf_counter() - t0, abs(it))
+    threads = c_oracle.num_threads()
+    out = {"value": legs["all_cores"][0], "unit": "beams/s", "cores": threads, "kind": "port",
+           "sample": f"{cells}^3 Octet r={radius} cantilever, {lat.n_beams} struts, {legs['all_cores'][2]} Jacobi-PCG "
+                     f"iterations to rtol {rtol:g} in {legs['all_cores'][1]:.1f} s (oracle/beam_pcg.c oracle_pcg_mt, gcc -O2 "
+                     f"-fopenmp, {threads} threads of {os.cpu_count()} host CPUs; the GPU runs a multi-level PCG with "
+                     f"4x fewer iterations - a different preconditioner, see config.preconditioner)",
+           "one_core": {"value": legs["one_core"][0], "unit": "beams/s", "cores": 1,
+                        "sample": f"same sample, oracle_pcg (scatter form), {legs['one_core'][1]:.1f} s"}}
+    if splu_cells > 0:
+        sl = LA.generate((1, 1, 1), (splu_cells,) * 3, ["Octet"], [radius])
+        sp_ = LA.penalize(sl, LA.compute_lzone(sl))
+        xyz, conn, rad = penalised_segments(sl, sp_)
+        n_load = int((sl.node_xyz[:, 0] == float(splu_cells)).sum())
+        t0 = time.perf_counter()
+        K, nv = O.assemble_submeshed_fast(xyz, conn, rad, E, NU, 0.05)
+        t1 = time.perf_counter()
+        fx = np.zeros((nv, 6), bool)
+        ff = np.zeros((nv, 6))
+        fx[:sl.n_nodes][sl.node_xyz[:, 0] == 0.0] = True
+        ff[:sl.n_nodes][sl.node_xyz[:, 0] == float(splu_cells), 2] = -0.1 / n_load
+        O.solve_dirichlet(K, fx, np.zeros((nv, 6)), ff)
+        t2 = time.perf_counter()
+        out["reference_faithful"] = {
+            "value": sl.n_beams / (t2 - t0), "unit": "beams/s", "kind": "port",
+            "cores": "scipy SuperLU (1 thread)",
+            "sample": f"{splu_cells}^3 Octet r={radius} cantilever, {sl.n_beams} struts -> {len(conn)} penalised segments "
+                      f"-> {6 * nv} dofs on the gmsh-like sub-mesh: CSR assembly {t1 - t0:.1f} s + splu factor/solve "
+                      f"{t2 - t1:.1f} s (oracle/timoshenko_oracle.py; stand-in for dolfinx + PETSc LU, which are not "
+                      f"installable here)"}
+    return out, u
+
+
+def penalised_segments(lat, pen):
+    """Explicit node / segment list of the penalised lattice (what the reference hands to gmsh): lattice nodes first,
+    then the penalisation points; segments [pen@point1 | middle | pen@point2] with their actual radii."""
+    B, nid = lat.n_beams, lat.n_nodes
+    has1, has2 = pen.seg_len[:, 0] > 0, pen.seg_len[:, 2] > 0
+    q1, q2 = np.full(B, -1, np.int64), np.full(B, -1, np.int64)
+    q1[has1] = nid + np.arange(has1.sum())
+    nid += int(has1.sum())
+    q2[has2] = nid + np.arange(has2.sum())
+    a, b = lat.beam_conn[:, 0].astype(np.int64), lat.beam_conn[:, 1].astype(np.int64)
+    s, e = np.where(has1, q1, a), np.where(has2, q2, b)
+    xyz = np.concatenate([lat.node_xyz, pen.pen_xyz[has1, 0], pen.pen_xyz[has2, 1]])
+    conn = np.concatenate([np.c_[a[has1], q1[has1]], np.c_[s, e], np.c_[q2[has2], b[has2]]])
+    rad = np.concatenate([1.5 * lat.beam_radius[has1], lat.beam_radius, 1.5 * lat.beam_radius[has2]])
+    return xyz, conn, rad
+
+
+def end_to_end(cells, geom, radius, rtol):
+    """What a user of the drop-in call site waits for: LatticeSim(preset) (host lattice build, penalisation, BCs) +
+    solve_FEM_FenicsX (pl_create, upload, assembly, solve, reactions, write-back), wall clock, once."""
+    from pylatticedso_amd.lattice_sim import LatticeSim
+    from pylatticedso_amd.utils_simulation import solve_FEM_FenicsX
+    preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": cells, "y": cells, "z": cells},
+                           "radii": [radius], "geom_types": [geom]},
+              "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False},
+              "boundary_conditions": {
+                  "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"],
+                                             "Value": [0, 0, 0, 0, 0, 0]}},
+                  "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}}
     t0 = time.perf_counter()
-    sc = c_oracle.condense_unique(lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU)
-    u, it, rel = c_oracle.pcg(lat.node_xyz, lat.beam_conn, sc, fixed, np.zeros_like(f), f, rtol=rtol, maxit=100000)
-    dt = time.perf_counter() - t0
-    return {"value": lat.n_beams / dt, "unit": "beams/s", "cores": 1, "kind": "port",
-            "sample": f"{cells}^3 Octet r={radius} cantilever, {lat.n_beams} struts, {abs(it)} Jacobi-PCG iterations "
-                      f"to rtol {rtol:g} in {dt:.1f} s (oracle/beam_pcg.c, gcc -O2, 1 thread)"}, u
+    L = LatticeSim(preset)
+    t1 = time.perf_counter()
+    xsol, model = solve_FEM_FenicsX(L, rtol=rtol)
+    t2 = time.perf_counter()
+    L._device.close()
+    return {"total_s": t2 - t0, "lattice_sim_s": t1 - t0, "solve_fem_s": t2 - t1,
+            "what": "LatticeSim(preset) + solve_FEM_FenicsX(lattice) through the drop-in call site, first call "
+                    "(includes pl_create, topology upload, reactions, write-back)"}
 
 
 def main():
@@ -89,8 +165,13 @@ def main():
     ap.add_argument("--coarse-max-dofs", type=int, default=0,
                     help="upper bound on the dofs of the dense coarse level (0 = library default, 3072)")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
+    ap.add_argument("--precision", type=int, default=0,
+                    help="0 = fp64 (headline), 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only")
     ap.add_argument("--cpu-cells", type=int, default=36,
                     help="edge of the CPU-baseline sample (0 = skip); 36 = 1.1 M struts, ~10-15 s on one core")
+    ap.add_argument("--splu-cells", type=int, default=5,
+                    help="edge of the reference-faithful (sub-meshed + sparse LU) CPU sample (0 = skip); 5 = ~15 s")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing through solve_FEM_FenicsX")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (slab build, RCCL communicator) even with one rank (rehearsal)")
@@ -120,7 +201,11 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # host-side bootstrap only (unique id, counts, barrier, max of the timings): gloo.  The data path's RCCL
+        # communicator lives inside libpylattice_hip (pl_dist_init) - ONE communicator and one librccl per process
+        # (torch's bundled librccl.so and /opt/rocm/lib/librccl.so share the soname librccl.so.1, so the loader maps
+        # whichever came first exactly once).
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from pylatticedso_amd import _capi, lattice_arrays as LA, partition as PT
     if not os.path.exists(_capi.LIB_PATH):
@@ -143,12 +228,12 @@ def main():
     grid = None
     if multi:
         # every rank must cut the same brick / aggregate grid: hand over the box and node count of the whole lattice
-        nn = torch.tensor([float(len(xyz))], dtype=torch.float64, device="cuda")
+        nn = torch.tensor([float(len(xyz))], dtype=torch.float64)
         dist.all_reduce(nn)
         grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
-                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs)
+                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world
@@ -162,7 +247,7 @@ def main():
         if rank > 0:
             lower_plane[slab.iface_local[ok][slab.iface_key[ok][:, 0] == slab.layers[0]]] = True
         cnt = torch.tensor([float(((xyz[:, 0] == float(n)) & ~lower_plane).sum()), float(len(conn))],
-                           dtype=torch.float64, device="cuda")
+                           dtype=torch.float64)
         dist.all_reduce(cnt)
         n_tgt, n_beams_total = int(cnt[0].item()), int(cnt[1].item())
     fixed, f, _ = cantilever_bc(xyz, float(n), n_tgt)
@@ -175,7 +260,7 @@ def main():
         return dev.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
 
     def sync():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()     # device-wide: covers the library's own streams
         if multi:
             dist.barrier()
             torch.cuda.synchronize()
@@ -189,7 +274,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -198,6 +283,10 @@ def main():
     ms_iter = dev.time_kernel(3, 50)
     ms_rec = dev.time_kernel(1, 20)
     ms_bsr = dev.time_kernel(2, 10) if not args.no_bsr else None
+    ms_f32 = None
+    if args.precond >= 2 and args.kernel in (0, 3) and args.reorder:
+        ms_f32 = {"spmv_f32_storage": dev.time_kernel(7, 50), "pcg_iteration_precision1": dev.time_kernel(8, 50),
+                  "pcg_iteration_precision2": dev.time_kernel(9, 50)}
     # the two collectives of an iteration, alone (every rank makes the same calls; rank 0's clock is reported)
     ms_coll = {"interface_allreduce": dev.time_kernel(5, 50), "coarse_allreduce": dev.time_kernel(6, 50)} if multi else None
     ab = dev.algorithmic_bytes()
@@ -205,24 +294,30 @@ def main():
     # HBM bytes per K*p launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
     # gfx950: FETCH_SIZE counts half of 16-B/lane streaming reads - see profiles/README.md).  Valid for the default
     # single-GPU workload only.
-    traffic = None
+    traffic = traffic_src = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
     if world == 1 and n == 50 and args.geom == "Octet" and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         if pmc.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder) and \
                 pmc.get("record_palette", 0) == args.palette:
             traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
+            traffic_src = {"file": "profiles/pmc_spmv_latest.json", "measured_on": pmc.get("build", "unknown build"),
+                           "note": "PMC counters cannot be read inside this run (rocprofv3 --pmc is a separate "
+                                   "pass); this is the committed pass for this workload / kernel / palette setting"}
 
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {0: "f64", 1: "f32 storage + f64 refinement (f64 arithmetic)", 2: "f32 p/Kp storage, f64 x/r"}[args.precision],
+        "data": "synthetic",
         "config": {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {args.geom} r={args.radius} cantilever "
                                f"(BASELINE.json configs[1] per GPU)",
                    "struts": n_beams_total, "struts_per_gpu": len(conn), "nodes_per_gpu": len(xyz),
                    "partition": "single GPU" if world == 1 else f"{world} y-slabs, RCCL interface all-reduce",
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
-                   "rel_residual": st["rel_residual"],
+                   "rel_residual": st["rel_residual"], "precision": args.precision,
+                   "inner_solves": st.get("restarts", 0.0),
                    "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
                                       3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)",
                                       4: "multi-level (Jacobi + tile blocks + rank-local dense level + all-reduced "
@@ -232,19 +327,21 @@ def main():
                    "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv},
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
-                       "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"]},
+                       "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
     }
     if ms_coll is not None:
         out["collectives_ms"] = ms_coll
+    dev.close()
     if rank == 0 and world == 1 and args.cpu_cells > 0:
-        cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol)
+        cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol, args.splu_cells)
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None
-    dev.close()
+    if rank == 0 and world == 1 and not args.no_e2e and not args.force_dist:
+        out["end_to_end_s"] = end_to_end(n, args.geom, args.radius, args.rtol)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:

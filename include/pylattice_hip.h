@@ -65,7 +65,8 @@ typedef struct {
                             multi-GPU runs, where the all-reduced global level has to coarsen with the rank count.
                             2, 3 and 4 need reorder = 1 */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
-  int32_t check_every;   /* PCG: iterations between host-side convergence checks (0 -> 32) */
+  int32_t check_every;   /* PCG: iterations between host-side convergence checks; 0 = adaptive (32 while far from
+                            the threshold, then what the observed decay rate predicts is still needed) */
   int32_t lanes_per_node;/* gather kernels: wave lanes sharing one node, 1/2/4/8/16 (0 -> 4) */
   int32_t tile_nodes;    /* target nodes per brick/tile of the spatial reordering, <= 512 (0 -> 256) */
   int32_t coarse_max_dofs; /* precond = 2/3: upper bound on 6 * (number of aggregates) (0 -> 2100 below 10^6 nodes
@@ -73,7 +74,13 @@ typedef struct {
   int32_t palette;       /* 1: K*p (LDS-tile kernel) reads 2-byte palette ids instead of 64-byte records when the lattice
                             has <= ~30 000 distinct records (compared on 40 mantissa bits, i.e. to 1e-12) */
   int32_t local_max_dofs;  /* precond = 4: upper bound on 6 * (aggregates of the rank-local level) (0 -> 3072) */
-  int32_t reserved[2];
+  int32_t precision;     /* storage precision of the PCG vectors (multi-level PCG on the LDS-tile kernel, i.e. precond >=
+                            2 with reorder = 1; any other configuration runs fp64).  0 = fp64.  1 = fp32 inner PCG with
+                            fp64 refinement: x, r, p, K*p stored in fp32, restart from the TRUE fp64 residual
+                            P(f - K u) every ~4 decades.  2 = only p and K*p stored in fp32, x and the residual
+                            recurrence in fp64, true residual verified at the end.  All products and sums are evaluated
+                            in fp64 in every mode; rtol always refers to the true fp64 residual in modes 1 and 2 */
+  int32_t reserved[1];
   double alpha_max;      /* > 0: clamp the CG step like conjugate_gradient_solver.py:79 (DDM solves use 100) */
   /* Multi-GPU only: bounding box and node count of the WHOLE lattice, so that every rank cuts the same brick /
    * aggregate grid (all zero -> derived from this handle's own nodes). */
@@ -92,7 +99,9 @@ typedef struct {
   double ms_spmv_avg;      /* average K*x kernel time inside the last pl_solve (HIP events, sampled) */
   double precond_used;     /* preconditioner the solve actually ran with (opts->precond numbering): differs from the
                               request when a dense level was not positive definite and the solve fell back to Jacobi */
-  double reserved[7];
+  double restarts;         /* precision = 1 / 2: inner solves taken (each ends with a true-residual evaluation) */
+  double precision_used;   /* precision mode the solve ran in (0 when the request did not apply) */
+  double reserved[5];
 } pl_stats_t;
 
 void pl_default_opts(pl_opts_t *o);
@@ -130,7 +139,8 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
  * opts->precond = 2 at pl_create_ddm; pl_assemble builds and factorises G for the current Dirichlet mask.
  * Shat_c defaults to the operator's own matrices (preconditioner_type "exact": CG converges in one step); this call
  * installs another palette - one mean matrix ("mean"), or the dataset matrices with the nearest-radius index per
- * cell ("nearest_reference").  S = NULL goes back to the default.  When G is not positive definite (an indefinite
+ * cell ("nearest_reference").  pl_set_bc on an assembled precond = 2 handle invalidates the factorisation (it
+ * depends on the Dirichlet mask): call pl_assemble again before pl_solve.  S = NULL goes back to the default.  When G is not positive definite (an indefinite
  * surrogate matrix) pl_assemble falls back to Jacobi (the reference: LU -> ILU) and pl_stats_t.precond_used says 1. */
 #define PL_DDM_DENSE_MAX 16384
 int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/,
@@ -194,7 +204,9 @@ int pl_get_records(pl_handle h, double *rec);
 /* Measurement hooks (bench.py): run `reps` launches of one kernel on the handle's stream between two HIP
  * events and return the average milliseconds.  which: 0 = K*p (PCG operator), 1 = record build,
  * 2 = BSR fill, 3 = one full PCG iteration, 4 = BSR SpMV; on a multi-GPU handle also 5 = the interface all-reduce of
- * one K*p (staging kernels + RCCL) and 6 = the coarse-residual all-reduce - collective calls, every rank must make them. */
+ * one K*p (staging kernels + RCCL) and 6 = the coarse-residual all-reduce - collective calls, every rank must make them.
+ * With the multi-level PCG: 7 = K*p on fp32-stored vectors, 8 = one iteration of the fp32 inner PCG (precision 1),
+ * 9 = one iteration of the mixed PCG (precision 2). */
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
 /* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr. */
 int pl_algorithmic_bytes(pl_handle h, double *out3);

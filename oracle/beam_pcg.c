@@ -7,12 +7,17 @@
  *   - Dirichlet handling with dolfinx semantics (simulation_base.py:465-514),
  *   - Jacobi-preconditioned CG in the textbook form (x0 = 0, stop on ||r|| <= rtol ||b||).
  * Pinned against the numpy oracle (itself pinned by the reference's dolfinx Schur goldens) in
- * tests/test_oracle_c.py.  Single-threaded on purpose: bench.py reports it with "cores": 1.
+ * tests/test_oracle_c.py.  oracle_pcg is single-threaded (bitwise reproducible: the checker of smoke() and of the
+ * tests); oracle_pcg_mt is the same Jacobi-PCG on all host cores (OpenMP; per-node gather over the incident struts
+ * instead of the scatter, so no two threads write one row) - the "cores": C leg of bench.py's cpu_baseline.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define PI 3.14159265358979323846
 
@@ -159,5 +164,124 @@ int oracle_pcg(int64_t N, int64_t B, const double *xyz, const int32_t *conn, con
   for (int64_t i = 0; i < n; ++i) u[i] = fixed[i] ? ubar[i] : x[i];
   if (relres_out) *relres_out = bb > 0.0 ? sqrt(rr / bb) : 0.0;
   free(buf);
+  return conv ? it : -it;
+}
+
+
+/* ---- all-cores variant ------------------------------------------------------------------------------------ */
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* force / moment strut b applies to its end `tip` (0: point1, 1: point2) for the field x */
+static inline void strut_end_force(int64_t b, int tip, const double *xyz, const int32_t *conn, const double *sc,
+                                   const double *x, double *out6) {
+  const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+  const double ka = sc[5 * b], kt = sc[5 * b + 1], a = sc[5 * b + 2], bb = sc[5 * b + 3], c = sc[5 * b + 4];
+  double d[3] = {xyz[3 * ib] - xyz[3 * ia], xyz[3 * ib + 1] - xyz[3 * ia + 1], xyz[3 * ib + 2] - xyz[3 * ia + 2]};
+  const double L = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double t[3] = {d[0] / L, d[1] / L, d[2] / L};
+  const double *xa = x + 6 * ia, *xb = x + 6 * ib;
+  double dxt[3], du[3], dth[3], tc[3], tu[3], F[3], M[3], dF[3];
+  cross3(d, xa + 3, dxt);
+  for (int k = 0; k < 3; ++k) {
+    du[k] = xb[k] - xa[k] + dxt[k];
+    dth[k] = xb[3 + k] - xa[3 + k];
+  }
+  const double dut = du[0] * t[0] + du[1] * t[1] + du[2] * t[2];
+  const double dtt = dth[0] * t[0] + dth[1] * t[1] + dth[2] * t[2];
+  cross3(t, dth, tc);
+  cross3(t, du, tu);
+  for (int k = 0; k < 3; ++k) {
+    F[k] = (ka - a) * dut * t[k] + a * du[k] + bb * tc[k];
+    M[k] = (kt - c) * dtt * t[k] + c * dth[k] - bb * tu[k];
+  }
+  if (tip) {
+    for (int k = 0; k < 3; ++k) { out6[k] = F[k]; out6[3 + k] = M[k]; }
+  } else {
+    cross3(d, F, dF);
+    for (int k = 0; k < 3; ++k) { out6[k] = -F[k]; out6[3 + k] = -M[k] - dF[k]; }
+  }
+}
+
+/* y = mask .* (K x) by rows: ptr/inc = CSR node -> (strut << 1 | end) */
+static void spmv_gather(int64_t N, const int64_t *ptr, const int64_t *inc, const double *xyz, const int32_t *conn,
+                        const double *sc, const uint8_t *fixed, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    double acc[6] = {0, 0, 0, 0, 0, 0}, f6[6];
+    for (int64_t q = ptr[i]; q < ptr[i + 1]; ++q) {
+      strut_end_force(inc[q] >> 1, (int)(inc[q] & 1), xyz, conn, sc, x, f6);
+      for (int k = 0; k < 6; ++k) acc[k] += f6[k];
+    }
+    for (int k = 0; k < 6; ++k) y[6 * i + k] = (fixed && fixed[6 * i + k]) ? 0.0 : acc[k];
+  }
+}
+
+int oracle_pcg_mt(int64_t N, int64_t B, const double *xyz, const int32_t *conn, const double *sc,
+                  const uint8_t *fixed, const double *ubar, const double *f, double rtol, int maxit, double *u,
+                  double *relres_out) {
+  const int64_t n = 6 * N;
+  double *buf = (double *)calloc((size_t)n * 7, sizeof(double));
+  int64_t *ptr = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
+  int64_t *inc = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)B);
+  int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+  if (!buf || !ptr || !inc || !fill) return -1000000;
+  for (int64_t b = 0; b < B; ++b) { ptr[conn[2 * b] + 1]++; ptr[conn[2 * b + 1] + 1]++; }
+  for (int64_t i = 0; i < N; ++i) { ptr[i + 1] += ptr[i]; fill[i] = ptr[i]; }
+  for (int64_t b = 0; b < B; ++b) { inc[fill[conn[2 * b]]++] = b << 1; inc[fill[conn[2 * b + 1]]++] = (b << 1) | 1; }
+  double *x = buf, *r = buf + n, *z = buf + 2 * n, *p = buf + 3 * n, *Ap = buf + 4 * n, *dinv = buf + 5 * n,
+         *ub = buf + 6 * n;
+  oracle_diag(N, B, xyz, conn, sc, dinv);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    dinv[i] = (fixed[i] || dinv[i] == 0.0) ? 0.0 : 1.0 / dinv[i];
+    ub[i] = fixed[i] ? ubar[i] : 0.0;
+  }
+  spmv_gather(N, ptr, inc, xyz, conn, sc, NULL, ub, Ap);
+  double bb = 0.0, rz = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : bb, rz)
+  for (int64_t i = 0; i < n; ++i) {
+    r[i] = fixed[i] ? 0.0 : f[i] - Ap[i];
+    z[i] = dinv[i] * r[i];
+    p[i] = z[i];
+    bb += r[i] * r[i];
+    rz += r[i] * z[i];
+  }
+  int it = 0, conv = 0;
+  double rr = bb;
+  if (bb > 0.0) {
+    for (it = 1; it <= maxit; ++it) {
+      spmv_gather(N, ptr, inc, xyz, conn, sc, fixed, p, Ap);
+      double pAp = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : pAp)
+      for (int64_t i = 0; i < n; ++i) pAp += p[i] * Ap[i];
+      const double alpha = rz / pAp;
+      double rz_new = 0.0;
+      rr = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rz_new, rr)
+      for (int64_t i = 0; i < n; ++i) {
+        x[i] += alpha * p[i];
+        r[i] -= alpha * Ap[i];
+        z[i] = dinv[i] * r[i];
+        rz_new += r[i] * z[i];
+        rr += r[i] * r[i];
+      }
+      if (rr <= rtol * rtol * bb) { conv = 1; break; }
+      const double beta = rz_new / rz;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+      rz = rz_new;
+    }
+  } else {
+    conv = 1;
+  }
+  for (int64_t i = 0; i < n; ++i) u[i] = fixed[i] ? ubar[i] : x[i];
+  if (relres_out) *relres_out = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+  free(buf); free(ptr); free(inc); free(fill);
   return conv ? it : -it;
 }

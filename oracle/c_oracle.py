@@ -58,8 +58,17 @@ def spmv(xyz, conn, scalars, x):
     return y.reshape(-1, 6)
 
 
-def pcg(xyz, conn, scalars, fixed, ubar, f, rtol=1e-10, maxit=100000):
+def num_threads():
     lib = _lib()
+    lib.oracle_num_threads.restype = C.c_int
+    return int(lib.oracle_num_threads())
+
+
+def pcg(xyz, conn, scalars, fixed, ubar, f, rtol=1e-10, maxit=100000, all_cores=False):
+    """Jacobi-PCG on the condensed struts; all_cores=True runs the OpenMP variant (same algorithm, per-node gather)."""
+    lib = _lib()
+    if all_cores:
+        lib.oracle_pcg = lib.oracle_pcg_mt
     lib.oracle_pcg.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     lib.oracle_pcg.restype = C.c_int
     xyz = np.ascontiguousarray(xyz, np.float64)

@@ -136,6 +136,56 @@ def assemble_submeshed(node_xyz, seg_conn, seg_radius, E, nu, h, kappa=KAPPA):
     return K, nv
 
 
+def assemble_submeshed_fast(node_xyz, seg_conn, seg_radius, E, nu, h, kappa=KAPPA):
+    """Same matrix and vertex numbering as assemble_submeshed, built with array operations (one 12x12 per SEGMENT,
+    repeated over its sub-elements) - the form bench.py's reference-faithful CPU leg times, so that the Python loop
+    above does not count against the reference's compiled dolfinx assembly."""
+    node_xyz = np.asarray(node_xyz, float)
+    conn = np.asarray(seg_conn, dtype=np.int64)
+    rad = np.asarray(seg_radius, float)
+    N, S = len(node_xyz), len(conn)
+    xa, xb = node_xyz[conn[:, 0]], node_xyz[conn[:, 1]]
+    d = xb - xa
+    L = np.sqrt((d * d).sum(axis=1))
+    n = np.maximum(1, np.floor(L / h + 0.99).astype(np.int64))
+    l = L / n
+    # frames (beam_model.py:197-216), vectorised local_frame
+    t = d / L[:, None]
+    ex, ey, ez = np.eye(3)
+    e1 = np.where((np.abs(t[:, 1]) < np.abs(t[:, 0]))[:, None], ey, ex)
+    te1 = (t * e1).sum(axis=1)
+    e2 = np.where((np.abs(t[:, 2]) < np.abs(te1))[:, None], ez, e1)
+    a1 = np.cross(t, e2)
+    a1 /= np.sqrt((a1 * a1).sum(axis=1))[:, None]
+    a2 = np.cross(t, a1)
+    a2 /= np.sqrt((a2 * a2).sum(axis=1))[:, None]
+    G = E / (2.0 * (1.0 + nu))
+    Sx = math.pi * rad ** 2
+    I = math.pi * rad ** 4 / 4.0
+    C = np.stack([E * Sx, G * kappa * Sx, G * kappa * Sx, G * 2.0 * I, E * I, E * I], axis=1)      # (S, 6)
+    Bm = np.zeros((S, 6, 12))
+    il = (1.0 / l)[:, None]
+    for row, v in ((0, t), (1, a1), (2, a2)):
+        Bm[:, row, 0:3], Bm[:, row, 6:9] = -v * il, v * il
+        Bm[:, row + 3, 3:6], Bm[:, row + 3, 9:12] = -v * il, v * il
+    Bm[:, 1, 3:6] = Bm[:, 1, 9:12] = -0.5 * a2
+    Bm[:, 2, 3:6] = Bm[:, 2, 9:12] = 0.5 * a1
+    Ke = np.einsum("s,sik,si,sil->skl", l, Bm, C, Bm)                                              # (S, 12, 12)
+    # vertex ids of every sub-element: lattice nodes first, interior sub-nodes segment by segment
+    first_new = N + np.concatenate([[0], np.cumsum(n - 1)[:-1]])
+    nel = int(n.sum())
+    seg_of = np.repeat(np.arange(S), n)
+    e_in = np.arange(nel) - np.repeat(np.cumsum(n) - n, n)
+    va = np.where(e_in == 0, conn[seg_of, 0], first_new[seg_of] + e_in - 1)
+    vb = np.where(e_in == n[seg_of] - 1, conn[seg_of, 1], first_new[seg_of] + e_in)
+    dofs = np.concatenate([6 * va[:, None] + np.arange(6), 6 * vb[:, None] + np.arange(6)], axis=1)  # (nel, 12)
+    rows = np.repeat(dofs, 12, axis=1).ravel()
+    cols = np.tile(dofs, (1, 12)).ravel()
+    nv = N + int((n - 1).sum())
+    K = sp.coo_matrix((Ke[seg_of].ravel(), (rows, cols)), shape=(6 * nv, 6 * nv)).tocsr()
+    return K, nv
+
+
 def schur_complement(K, boundary_dofs):
     """S = K_BB - K_BI K_II^-1 K_IB (schur_complement.py:75-147), dense."""
     n = K.shape[0]

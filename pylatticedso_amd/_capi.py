@@ -34,7 +34,7 @@ class PlOpts(C.Structure):
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
                 ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("palette", C.c_int32),
-                ("local_max_dofs", C.c_int32), ("reserved", C.c_int32 * 2),
+                ("local_max_dofs", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 1),
                 ("alpha_max", C.c_double), ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3),
                 ("grid_nodes", C.c_int64)]
 
@@ -42,7 +42,8 @@ class PlOpts(C.Structure):
 class PlStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
-                ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("reserved", C.c_double * 7)]
+                ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("restarts", C.c_double),
+                ("precision_used", C.c_double), ("reserved", C.c_double * 5)]
 
 
 class PlError(RuntimeError):
@@ -128,8 +129,8 @@ class HipLattice:
     """Owner of one device handle: the condensed lattice operator + its PCG on one MI355X."""
 
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
-                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=32, lanes_per_node=0, tile_nodes=0, precond=1,
-                 coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0):
+                 pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=0, lanes_per_node=0, tile_nodes=0, precond=1,
+                 coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0, precision=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -149,6 +150,7 @@ class HipLattice:
         opts.precond, opts.coarse_max_dofs = precond, coarse_max_dofs
         opts.local_max_dofs = local_max_dofs
         opts.palette = palette
+        opts.precision = precision            # 0 fp64, 1 fp32 inner PCG + fp64 refinement, 2 fp32 p / K*p only
         if grid is not None:                       # (lo[3], hi[3], n_nodes) of the whole lattice (multi-GPU)
             lo, hi, nn = grid
             for k in range(3):

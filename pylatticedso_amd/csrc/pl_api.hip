@@ -263,6 +263,22 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
   return PL_OK;
 }
 
+// K*p of the fp32 solver modes: tile kernel only, fp32-stored x / y, fp64 arithmetic (pl_tile.h)
+int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double *dot_dev) {
+  if (c->pal_ready)
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
+                                dot_dev, c->stream);
+  else
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y,
+                                dot_dev, c->stream);
+  if (c->dist.active) {
+    int rc = pl::dist_sum_shared<float>(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
+    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+  }
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
 int ensure_hist(pl_context *c, int cap) {
   if (cap <= c->hist_cap) return PL_OK;
   PL_HIP(c->hist.alloc((size_t)cap));
@@ -474,28 +490,30 @@ int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
 }
 
 // Everything of a two-level PCG iteration after K*p: update + restriction, coarse solve, new direction.
-int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
+template <typename PT, typename RT>
+int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-  hipLaunchKernelGGL(pl::k_pcg_update_tile, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, c->Ap.p, cs.dinv32,
-                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, c->r.p, cur,
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,
+                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
                      cs.ncp);
+  if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
+              // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
+    pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
+                    (const double *)nullptr, c->stream);
   if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cs.rc + cs.ncp + pl::kSlots, c->stream);
-  if (useL)   // rank-local level: no communication; r.z += r_L . A_L^-1 r_L
-    pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cur + pl::S_RZ_NEW * pl::kSlots,
-                    (const double *)nullptr, c->stream);
-  hipLaunchKernelGGL(pl::k_pcg_direction_coarse, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
-                     c->tile.tile_start.p, c->r.p, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
-                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, c->p.p, c->x.p, cur,
+  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+                     c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur,
                      nxt,
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
@@ -503,6 +521,10 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
                      cl.ncp);
   PL_HIP(hipGetLastError());
   return PL_OK;
+}
+
+int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
+  return pcg_tail_coarse_t<double, double>(c, cur, nxt, hist_slot, c->p.p, (const double *)c->Ap.p, c->x.p, c->r.p);
 }
 
 // One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
@@ -526,7 +548,8 @@ int pcg_iteration(pl_context *c, int k) {
   if (c->dist.active) {
     pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
                                    c->stream);
-    pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream);
+    if (pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the PCG scalars failed");
   } else {
     hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
                        c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max);
@@ -552,8 +575,9 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
   PL_HIP(hipGetLastError());
   if (c->dist.active) {
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream);
-    pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream);
+    if (pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream) ||
+        pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
   }
   if (c->dd_ready) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
     pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
@@ -626,6 +650,166 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     }
   }
   if (!st->converged) st->iterations = k;
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// fp32 solver modes (opts.precision; multi-level PCG on the tile kernel only):
+//   1  inner PCG on fp32-stored x, r, p, Ap; the fp64 solution accumulates the inner corrections and every restart
+//      begins from the TRUE fp64 residual P(f - K(ubar + x)) (classical iterative refinement);
+//   2  only the search direction p and K*p are stored in fp32, x and the residual recurrence stay fp64: no restart
+//      is needed to reach fp64 accuracy, the true residual is verified once the recurrence says "converged" (the
+//      fp32 rounding of K*p lets the two drift apart by ~6e-8 of the accumulated steps).
+// In both modes every product and sum is evaluated in fp64 (pl_tile.h, pl_coarse.h): fp32 only halves the bytes.
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(pl::kBlock) void k_mp_true_residual(int64_t n6, const double *__restrict__ f,
+                                                                const double *__restrict__ Kubar,
+                                                                const double *__restrict__ Kx /* may be null */,
+                                                                const uint8_t *__restrict__ fixed,
+                                                                const double *__restrict__ w /* may be null */,
+                                                                double *__restrict__ r, double *__restrict__ rr_slots) {
+  __shared__ double red[pl::kBlock / pl::kWave];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock) {
+    const double v = fixed[i] ? 0.0 : f[i] - Kubar[i] - (Kx ? Kx[i] : 0.0);
+    r[i] = v;
+    acc += (w ? w[i] : 1.0) * v * v;
+  }
+  const double t = pl::block_sum(acc, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(rr_slots + (blockIdx.x & (pl::kSlots - 1)), t);
+}
+// start of an fp32 inner solve: r32 = r, x32 = 0
+__global__ __launch_bounds__(pl::kBlock) void k_mp_restart(int64_t n6, const double *__restrict__ r,
+                                                          float *__restrict__ r32, float *__restrict__ x32) {
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock) {
+    r32[i] = (float)r[i];
+    x32[i] = 0.f;
+  }
+}
+__global__ __launch_bounds__(pl::kBlock) void k_mp_accumulate(int64_t n6, const float *__restrict__ x32,
+                                                             double *__restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock)
+    x[i] += (double)x32[i];
+}
+
+int read_slots(pl_context *c, const double *dev, double *sum) {
+  double h[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  *sum = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) *sum += h[k];
+  return PL_OK;
+}
+
+template <typename RT>
+int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+                   pl_stats_t *st) {
+  constexpr bool kAll32 = sizeof(RT) == 4;
+  const int64_t n6 = c->N * 6;
+  const int set = pl::S_COUNT * pl::kSlots;
+  int rc = ensure_hist(c, max_iter + 2);
+  if (rc) return rc;
+  float *p32 = reinterpret_cast<float *>(c->p.p), *Ap32 = reinterpret_cast<float *>(c->Ap.p);
+  // mode 1: the inner iterate / residual live in the (otherwise unused) z buffer
+  RT *xi = kAll32 ? reinterpret_cast<RT *>(c->z.p) : reinterpret_cast<RT *>(c->x.p);
+  RT *ri = kAll32 ? reinterpret_cast<RT *>(c->z.p) + n6 : reinterpret_cast<RT *>(c->r.p);
+  const double *w = c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr;
+  double *aux = c->scal.p + pl::S_AUX * pl::kSlots;   // slots outside the two per-parity sets' live entries
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * set * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->x.p, 0, n6 * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_mp_true_residual, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                     (const double *)nullptr, c->fixed.p, w, c->r.p, aux);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, aux, pl::kSlots, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of ||b||^2 failed");
+  double bb = 0.0;
+  rc = read_slots(c, aux, &bb);
+  if (rc) return rc;
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  if (!(bb > 0.0)) {
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  // an fp32 residual recurrence is trustworthy over ~4 decades: restart from the true residual after that
+  const double inner_drop = kAll32 ? 1e-8 : 0.0;      // on ||r||^2
+  double rr_true = bb;
+  int k = 0;                      // iterations over all inner solves
+  std::vector<double> h_hist(32);
+  for (int outer = 0; outer < 40 && k < max_iter; ++outer) {
+    // ---- (re)start: p = M^-1 r through the tail of an iteration "-1" (alpha = 0) on scalar set 1
+    PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * set * sizeof(double), c->stream));
+    if (kAll32)
+      hipLaunchKernelGGL(k_mp_restart, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, c->r.p,
+                         reinterpret_cast<float *>(ri), reinterpret_cast<float *>(xi));
+    PL_HIP(hipMemsetAsync(p32, 0, n6 * sizeof(float), c->stream));
+    PL_HIP(hipMemsetAsync(Ap32, 0, n6 * sizeof(float), c->stream));
+    rc = pcg_tail_coarse_t<float, RT>(c, c->scal.p + set, c->scal.p, max_iter + 1, p32, (const float *)Ap32, xi, ri);
+    if (rc) return rc;
+    const double stop = std::max(thresh, inner_drop * rr_true);
+    bool inner_done = false;
+    int j = 0, next = 32;
+    double rr_prev = rr_true;
+    int j_prev = 0;
+    while (!inner_done && k < max_iter) {
+      const int todo = std::min(next, max_iter - k);
+      for (int q = 0; q < todo; ++q) {
+        double *cur = c->scal.p + ((j + q) & 1) * set, *nxt = c->scal.p + ((j + q + 1) & 1) * set;
+        rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        if (rc) return rc;
+        rc = pcg_tail_coarse_t<float, RT>(c, cur, nxt, k + q, p32, (const float *)Ap32, xi, ri);
+        if (rc) return rc;
+      }
+      PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipStreamSynchronize(c->stream));
+      int used = todo;
+      for (int q = 0; q < todo; ++q) {
+        const double rr = h_hist[q];
+        if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+        if (rr <= stop) { inner_done = true; used = q + 1; break; }
+      }
+      // (the device has run the whole chunk: x holds the iterate after `todo` iterations, which is what is kept)
+      const double rr_end = h_hist[todo - 1];
+      j += todo;
+      k += todo;
+      (void)used;
+      if (!inner_done) {
+        next = 32;
+        if (rr_end < rr_prev && rr_end > stop) {
+          const double per_it = std::log(rr_end / rr_prev) / (double)(j - j_prev);
+          const double need = std::log(stop / rr_end) / per_it;
+          if (need < 64.0) next = std::max(2, std::min(32, (int)std::ceil(0.75 * need)));
+        }
+        rr_prev = rr_end;
+        j_prev = j;
+      }
+    }
+    // ---- true residual of the accumulated solution
+    if (kAll32)
+      hipLaunchKernelGGL(k_mp_accumulate, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         reinterpret_cast<const float *>(xi), c->x.p);
+    rc = launch_spmv(c, c->x.p, c->tmp2.p, true, nullptr);
+    if (rc) return rc;
+    PL_HIP(hipMemsetAsync(aux, 0, pl::kSlots * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_mp_true_residual, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       (const double *)c->tmp2.p, c->fixed.p, w, c->r.p, aux);
+    PL_HIP(hipGetLastError());
+    if (c->dist.active && pl::dist_sum_scalars(c->dist, aux, pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the true residual failed");
+    rc = read_slots(c, aux, &rr_true);
+    if (rc) return rc;
+    if (std::isnan(rr_true) || std::isinf(rr_true)) return fail(PL_ERR_NAN, "NaN/Inf in the true residual");
+    st->rel_residual = std::sqrt(rr_true / bb);
+    st->restarts = (double)(outer + 1);     // restarts (inner solves) taken
+    if (rr_true <= thresh * 1.0000001) {
+      st->converged = 1;
+      break;
+    }
+  }
+  st->iterations = k;
   return PL_OK;
 }
 
@@ -790,7 +974,7 @@ void pl_default_opts(pl_opts_t *o) {
   o->spmv_kernel = 0;
   o->precond = 1;
   o->reorder = 1;
-  o->check_every = 32;
+  o->check_every = 0;   // adaptive
 }
 
 int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
@@ -920,7 +1104,11 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     // every iteration) the full 3 072
     const bool multi_rank = o->grid_nodes > 0;
     const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : ((multi_rank || N >= 1000000) ? 3072 : 2100);
-    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn);
+    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn, false, multi_rank);
+    if (rc == 4)
+      return bail(fail(PL_ERR_ARG, "pl_create: a strut spans more than neighbouring aggregates; the band-packed "
+                                   "all-reduce of the coarse operator of a multi-GPU handle cannot hold it (use "
+                                   "precond = 1 or a smaller coarse_max_dofs)"));
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
     PL_HIPC(c->sharedbits.alloc(N));
     PL_HIPC(c->maskL.alloc(N));
@@ -1142,8 +1330,14 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   h->coarse.n_fix = -1;
   h->coarseL.n_fix = -1;
   if (h->assembled && h->opkind == 1) {
-    pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
-    PL_HIP(hipStreamSynchronize(h->stream));
+    if (h->opt.precond == 2) {
+      // the factorised G was built for the old Dirichlet mask (and dinv must stay 0 next to it): build it again
+      h->assembled = false;
+      h->dd_ready = false;
+    } else {
+      pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
+      PL_HIP(hipStreamSynchronize(h->stream));
+    }
   } else if (h->assembled) {   // the Jacobi inverse and the coarse operator depend on the mask
     int rc = launch_diag(h, h->stream);
     if (rc) return rc;
@@ -1391,8 +1585,13 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   // lifting: tmp = K ubar (ubar is zero on free dofs)
   int rc = launch_spmv(h, h->ubar.p, h->tmp.p, false, nullptr);
   if (rc) return rc;
-  rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+  // fp32 solver modes need the multi-level preconditioner on the tile kernel; anything else runs the fp64 PCG
+  const bool mp = h->opt.precision != 0 && h->opkind == 0 && h->coarse.ready && choose_kernel(h) == 3 && h->tile.ready;
+  if (mp && h->opt.precision == 1) rc = pcg_solve_mp_t<float>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+  else if (mp) rc = pcg_solve_mp_t<double>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+  else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;
+  st.precision_used = mp ? (double)h->opt.precision : 0.0;     // precision mode the solve ran in
   hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,
                      h->ubar.p, h->x.p, h->tmp2.p);
   PL_HIP(hipEventRecord(h->ev1, h->stream));
@@ -1523,6 +1722,11 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   if (rc) return rc;
   // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (which >= 7 && which <= 9) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp
+    hipLaunchKernelGGL(pl::k_to_float, dim3(grid_for(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->dinv.p,
+                       reinterpret_cast<float *>(h->z.p));
+    PL_HIP(hipMemsetAsync(h->tmp.p, 0, n6 * sizeof(double), h->stream));
+  }
   auto one = [&](int k) -> int {
     switch (which) {
       case 0: return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots);
@@ -1544,6 +1748,21 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
         if (!h->dist.active || !h->coarse.ready) return fail(PL_ERR_STATE, "pl_time_kernel: 6 needs a coarse level");
         return pl::dist_sum_scalars(h->dist, h->coarse.tv, h->coarse.ncp, h->stream)
                    ? fail(PL_ERR_HIP, "RCCL all-reduce failed") : PL_OK;
+      case 7:   // K*p on fp32-stored vectors (the operator of opts.precision = 1 / 2)
+      case 8:   // one whole iteration of the fp32 inner PCG (precision = 1)
+      case 9: { // one whole iteration of the mixed PCG (precision = 2: p, K*p fp32; x, r fp64)
+        if (!(h->coarse.ready && h->tile.ready && choose_kernel(h) == 3))
+          return fail(PL_ERR_STATE, "pl_time_kernel: 7/8/9 need the multi-level PCG on the tile kernel");
+        float *p32 = reinterpret_cast<float *>(h->z.p), *Ap32 = p32 + n6;
+        double *cur = h->scal.p + (k & 1) * pl::S_COUNT * pl::kSlots, *nxt = h->scal.p + ((k + 1) & 1) * pl::S_COUNT * pl::kSlots;
+        int r7 = launch_spmv_f32(h, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        if (r7 || which == 7) return r7;
+        if (which == 8) {
+          float *x32 = reinterpret_cast<float *>(h->tmp.p), *r32 = x32 + n6;
+          return pcg_tail_coarse_t<float, float>(h, cur, nxt, k, p32, (const float *)Ap32, x32, r32);
+        }
+        return pcg_tail_coarse_t<float, double>(h, cur, nxt, k, p32, (const float *)Ap32, h->x.p, h->r.p);
+      }
       default: return fail(PL_ERR_ARG, "pl_time_kernel: unknown kernel id");
     }
   };

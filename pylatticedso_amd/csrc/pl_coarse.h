@@ -73,7 +73,7 @@ struct Coarse {
 // handle are numbered, and g is chosen from their count - the level is never summed over ranks.
 inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const std::vector<int64_t> &tile_brick,
                         const BrickGrid &grid, const double *xyz_dev_order, int64_t N, int max_dofs,
-                        const std::vector<int32_t> &conn, bool local = false) {
+                        const std::vector<int32_t> &conn, bool local = false, bool multi_rank = false) {
   const int64_t T = (int64_t)tile_start.size() - 1;
   const int64_t *nbrick = grid.nb;
   // aggregate index of a brick along axis k: floor(b * na_k / nb_k) - groups of bricks whose sizes differ by at most one,
@@ -150,7 +150,12 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     }
     c.bw_blocks = (int)((6 * (max_diff + 1) + kNB - 1) / kNB + 1);
     for (const auto &pr : cross)   // struts longer than an aggregate (degenerate tiling): no band assumption
-      if (std::abs(pr.first / n_agg - pr.first % n_agg) > max_diff) c.bw_blocks = 0;
+      if (std::abs(pr.first / n_agg - pr.first % n_agg) > max_diff) {
+        // ... on one GPU.  On several, bw_blocks decides the size of the all-reduce of A_c and must be the same on
+        // every rank, but only the ranks that hold such a strut would see it: refuse instead of hanging in RCCL
+        if (multi_rank && !local) return 4;
+        c.bw_blocks = 0;
+      }
     std::sort(cross.begin(), cross.end());
     // every ordered pair starts at a wave boundary (padding = -1), so no wave mixes two coarse blocks
     std::vector<int32_t> idx2;
@@ -546,14 +551,17 @@ __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__
   if (i < n) y[i] = (float)x[i];
 }
 
+// PT = storage type of the search direction p and of Ap, RT = of the iterate x and the residual r (double / float:
+// opts.precision).  Every sum is accumulated in fp64 whatever the storage.
+template <typename PT, typename RT>
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
                                                             const double *__restrict__ xyz,
-                                                            const double *__restrict__ Ap,
+                                                            const PT *__restrict__ Ap,
                                                             const float *__restrict__ dinv32,
                                                             const double *__restrict__ w /* may be null */,
-                                                            double *__restrict__ r,
+                                                            RT *__restrict__ r,
                                                             double *__restrict__ scal, double *__restrict__ rc,
                                                             const double *__restrict__ Bt_inv /* may be null */,
                                                             double *__restrict__ yt,
@@ -589,12 +597,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
     // (x += alpha p is done by k_pcg_direction_coarse, which reads p anyway: one vector pass less per iteration)
     double av[6], dv[6], rv[6];
-    const double2 *a2 = reinterpret_cast<const double2 *>(Ap + 6 * (int64_t)i);
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
-    double2 *r2 = reinterpret_cast<double2 *>(r + 6 * (int64_t)i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double2 aa = a2[k], rr = r2[k];
+      const double2 aa = load_pair(Ap, 3 * (int64_t)i + k), rr = load_pair(r, 3 * (int64_t)i + k);
       const float2 dd = d2[k];
       av[2 * k] = aa.x; av[2 * k + 1] = aa.y;
       dv[2 * k] = dd.x; dv[2 * k + 1] = dd.y;
@@ -603,7 +609,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
 #pragma unroll
     for (int k = 0; k < 6; ++k) rv[k] -= alpha * av[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r2[k] = {rv[2 * k], rv[2 * k + 1]};
+    for (int k = 0; k < 3; ++k) store_pair(r, 3 * (int64_t)i + k, double2{rv[2 * k], rv[2 * k + 1]});
+    if (sizeof(RT) == 4) {   // the sums below must see the residual as it is stored
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rv[k] = (double)(float)rv[k];
+    }
     double wt[6] = {1, 1, 1, 1, 1, 1};
     if (w) {
 #pragma unroll
@@ -705,8 +715,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
 
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
 // One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
+template <typename PT, typename RT>
 __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *__restrict__ tile_start,
-                                                                 const double *__restrict__ r,
+                                                                 const RT *__restrict__ r,
                                                                  const float *__restrict__ dinv32,
                                                                  const double *__restrict__ xyz,
                                                                  const int32_t *__restrict__ agg_of_tile,
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ yc,
                                                                  const double *__restrict__ yt /* may be null */,
                                                                  const uint8_t *__restrict__ fixedbits,
-                                                                 double *__restrict__ p, double *__restrict__ x,
+                                                                 PT *__restrict__ p, RT *__restrict__ x,
                                                                  const double *__restrict__ scal,
                                                                  double *__restrict__ scal_next,
                                                                  double *__restrict__ hist, int k,
@@ -792,24 +803,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       zc[5] += L[5];
     }
     const unsigned fb = fixedbits[i];
-    const double2 *r2 = reinterpret_cast<const double2 *>(r + 6 * i);
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);
-    double2 *p2 = reinterpret_cast<double2 *>(p + 6 * i);
-    double2 *x2 = reinterpret_cast<double2 *>(x + 6 * i);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const double2 rr = r2[q];
+      const double2 rr = load_pair(r, 3 * i + q);
       const float2 dd = d2[q];
-      double2 pp = p2[q];
-      double2 xx = x2[q];
+      double2 pp = load_pair(p, 3 * i + q);
+      double2 xx = load_pair(x, 3 * i + q);
       xx.x += alpha * pp.x;
       xx.y += alpha * pp.y;
-      x2[q] = xx;
+      store_pair(x, 3 * i + q, xx);
       const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
       const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);
       pp.x = z0 + beta * pp.x;
       pp.y = z1 + beta * pp.y;
-      p2[q] = pp;
+      store_pair(p, 3 * i + q, pp);
     }
   }
 }

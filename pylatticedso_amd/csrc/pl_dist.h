@@ -39,26 +39,28 @@ struct Dist {
 
 // One kernel fills the whole message: interface rows this rank holds (others zero: the all-reduce sums ranks), then
 // the optional scalar tail.  slot2loc[g] = local node of global interface slot g, or -1.
-__global__ void k_pack_message(int64_t nrow, const int32_t *__restrict__ slot2loc, const double *__restrict__ y,
+template <typename VT>
+__global__ void k_pack_message(int64_t nrow, const int32_t *__restrict__ slot2loc, const VT *__restrict__ y,
                                const double *__restrict__ scal, int nscal, double *__restrict__ pack) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nrow) {
     const int64_t g = i / 6, k = i - 6 * g;
     const int32_t l = slot2loc[g];
-    pack[i] = l >= 0 ? y[6 * (int64_t)l + k] : 0.0;
+    pack[i] = l >= 0 ? (double)y[6 * (int64_t)l + k] : 0.0;
   } else if (i < nrow + nscal) {
     pack[i] = scal[i - nrow];
   }
 }
 // ... and one kernel takes it apart again.
+template <typename VT>
 __global__ void k_unpack_message(int32_t n, const int32_t *__restrict__ loc, const int32_t *__restrict__ glob,
-                                 const double *__restrict__ pack, double *__restrict__ y, int64_t nrow,
+                                 const double *__restrict__ pack, VT *__restrict__ y, int64_t nrow,
                                  double *__restrict__ scal, int nscal) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n6 = (int64_t)n * 6;
   if (i < n6) {
     const int64_t s = i / 6, k = i - 6 * s;
-    y[6 * (int64_t)loc[s] + k] = pack[6 * (int64_t)glob[s] + k];
+    y[6 * (int64_t)loc[s] + k] = (VT)pack[6 * (int64_t)glob[s] + k];
   } else if (i < n6 + nscal) {
     scal[i - n6] = pack[nrow + (i - n6)];
   }
@@ -83,18 +85,20 @@ inline int dist_unique_id(void *out) {
 // y[shared] <- sum over ranks of y[shared]; optionally `nscal` device scalars (e.g. the 32 slots of a LOCAL partial
 // dot product) ride in the tail of the same message and are summed over ranks too: ONE collective, one kernel
 // before it and one after.
-inline int dist_sum_shared(Dist &d, double *y, hipStream_t s, double *scal = nullptr, int nscal = 0) {
+// (VT = float: the fp32 solver modes; the message itself stays fp64 - it is small and latency-bound)
+template <typename VT>
+inline int dist_sum_shared(Dist &d, VT *y, hipStream_t s, double *scal = nullptr, int nscal = 0) {
   if (!d.active) return 0;
   const int64_t nrow = (int64_t)d.n_shared_global * 6;
   if (!scal) nscal = 0;
   const int64_t n = nrow + nscal;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_pack_message, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nrow, d.slot2loc.p, y, scal,
+  hipLaunchKernelGGL(k_pack_message<VT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nrow, d.slot2loc.p, y, scal,
                      nscal, d.pack.p);
   if (ncclAllReduce(d.pack.p, d.pack.p, (size_t)n, ncclDouble, ncclSum, d.comm, s) != ncclSuccess) return 2;
   const int64_t m = (int64_t)d.n_shared * 6 + nscal;
   if (m > 0)
-    hipLaunchKernelGGL(k_unpack_message, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d.n_shared,
+    hipLaunchKernelGGL(k_unpack_message<VT>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d.n_shared,
                        d.local_idx.p, d.global_idx.p, d.pack.p, y, nrow, scal, nscal);
   return 0;
 }

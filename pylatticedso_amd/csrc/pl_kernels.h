@@ -59,6 +59,28 @@ __device__ __forceinline__ void load6(const double *__restrict__ p, V3 &u, V3 &t
   t = {b.y, c.x, c.y};
 }
 
+// fp32-stored vectors (opts.precision = 1 / 2): rows are 24 B, read as three float2; all arithmetic stays fp64.
+__device__ __forceinline__ void load6(const float *__restrict__ p, V3 &u, V3 &t) {
+  const float2 *q = reinterpret_cast<const float2 *>(p);
+  const float2 a = q[0], b = q[1], c = q[2];
+  u = {(double)a.x, (double)a.y, (double)b.x};
+  t = {(double)b.y, (double)c.x, (double)c.y};
+}
+// third `part` (0..2) of node row `node` of a node-major [N][6] vector, as two doubles
+__device__ __forceinline__ double2 load_pair(const double *v, int64_t pair) {
+  return reinterpret_cast<const double2 *>(v)[pair];
+}
+__device__ __forceinline__ double2 load_pair(const float *v, int64_t pair) {
+  const float2 f = reinterpret_cast<const float2 *>(v)[pair];
+  return {(double)f.x, (double)f.y};
+}
+__device__ __forceinline__ void store_pair(double *v, int64_t pair, double2 a) {
+  reinterpret_cast<double2 *>(v)[pair] = a;
+}
+__device__ __forceinline__ void store_pair(float *v, int64_t pair, double2 a) {
+  reinterpret_cast<float2 *>(v)[pair] = {(float)a.x, (float)a.y};
+}
+
 __device__ __forceinline__ Record load_record(const Record *__restrict__ rec, int64_t i) {
   const double2 *q = reinterpret_cast<const double2 *>(rec + i);
   const double2 a = q[0], b = q[1], c = q[2], d = q[3];

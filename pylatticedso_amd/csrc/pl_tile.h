@@ -205,10 +205,10 @@ __device__ __forceinline__ void lds_add6(double *dst, int stride, V3 f, V3 m) {
 }
 
 // PAL: the record comes from the palette table through a 2-byte id (pl_palette.h) instead of rec[b].
-template <bool PAL>
+template <bool PAL, typename VT>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
-                                           const double *__restrict__ x, double *ys, int stride) {
+                                           const VT *__restrict__ x, double *ys, int stride) {
   const int2 c = conn2[b];
   const Record r = PAL ? load_record(rec, pal[b]) : load_record(rec, b);
   V3 uA, tA, uB, tB, F, M;
@@ -226,7 +226,10 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
 // threads -> 45.9 / 40.6 / 39.7 / 36.2 / 47.8 / 42.8 / 55.0 us: with 512 a tile's ~1900 strut visits are 3-4 per thread, so a
 // workgroup lives half as long while 4 of them still fit a CU.
 constexpr int kTileBlock = 512;
-template <bool MASK, bool DOT, bool PAL>
+// VT = storage type of x and y (double, or float for the fp32 solver modes: the strut forces are still evaluated
+// and accumulated in fp64 - the forces on a node nearly cancel for the smooth fields a solve is made of, so rounding
+// them to fp32 before the sum would cost cond(K) * 6e-8, rounding the stored result costs 6e-8).
+template <bool MASK, bool DOT, bool PAL, typename VT>
 __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ home_ptr,
                                                       const int64_t *__restrict__ foreign_ptr,
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
                                                       const int2 *__restrict__ conn2, const Record *__restrict__ rec,
                                                       const uint16_t *__restrict__ pal,
                                                       const uint8_t *__restrict__ fixedbits,
-                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      const VT *__restrict__ x, VT *__restrict__ y,
                                                       double *__restrict__ dot_out, int stride) {
   extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
   __shared__ double red[kTileBlock / kWave];
@@ -245,15 +248,15 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 4
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock) tile_strut<PAL>(b, n0, n1, conn2, rec, pal, x, ys, stride);
+  for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock)
+    tile_strut<PAL, VT>(b, n0, n1, conn2, rec, pal, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 4
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
-    tile_strut<PAL>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys, stride);
+    tile_strut<PAL, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys, stride);
   __syncthreads();
   double acc = 0.0;
-  double2 *y2 = reinterpret_cast<double2 *>(y) + 3 * (int64_t)n0;
-  const double2 *x2 = reinterpret_cast<const double2 *>(x) + 3 * (int64_t)n0;
+  const int64_t pair0 = 3 * (int64_t)n0;
   for (int i = threadIdx.x; i < nn * 3; i += kTileBlock) {
     const int node = i / 3, part = i - 3 * node;
     double2 v = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
@@ -262,9 +265,9 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
       if (fb & 1u) v.x = 0.0;
       if (fb & 2u) v.y = 0.0;
     }
-    y2[i] = v;
+    store_pair(y, pair0 + i, v);
     if (DOT) {
-      const double2 xv = x2[i];
+      const double2 xv = load_pair(x, pair0 + i);
       acc += xv.x * v.x + xv.y * v.y;
     }
   }
@@ -280,14 +283,15 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
 }
 
 // pal != nullptr: `rec` is the palette table and pal[b] the strut's entry.
+template <typename VT>
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
-                             const uint8_t *fixedbits, const double *x, double *y, double *dot_dev, hipStream_t s) {
+                             const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s) {
   const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
 #define PL_T(M, D, P)                                                                                          \
-  hipLaunchKernelGGL((k_spmv_tile<M, D, P>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
+  hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
                      plan.foreign_idx.p, conn2, rec, pal, fixedbits, x, y, dot_dev, stride)
   if (pal) {
     if (fixedbits && dot_dev) PL_T(true, true, true);

@@ -138,7 +138,8 @@ def test_solve_matches_reference_faithful_direct_solve(golden_dir, name, kernel)
     L._device = _device(L, spmv_kernel=kernel)
     xsol, model = solve_FEM_FenicsX(L)
     keep = ~g["beam_dup"]
-    K, nv = O.assemble_submeshed(g["node_xyz"], g["beam_conn"][keep], g["beam_radius"][keep], E, NU, 0.05)
+    h = 0.05 * L.cell_size_x                                  # latticeGeneration.find_mesh_size (lattice_generation.py:50-60)
+    K, nv = O.assemble_submeshed(g["node_xyz"], g["beam_conn"][keep], g["beam_radius"][keep], E, NU, h)
     n0, N = len(g["node_xyz"]), L.lattice.n_nodes
     fixed = np.zeros((nv, 6), bool)
     ubar = np.zeros((nv, 6))
@@ -502,6 +503,64 @@ def test_tile_level_reduces_iterations_octet16():
             res[pc] = dev.solve(rtol=1e-10, max_iter=20000)
     assert _rel(res[4][0], out[1][0]) < 1e-7 and res[4][1]["converged"] == 1
     assert res[4][1]["iterations"] < res[3][1]["iterations"]
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "bcchybrid1hybrid4_3x2x1_size"])
+def test_fp32_solver_modes_match_oracle(golden_dir, name, precision):
+    """opts.precision = 1 (fp32 inner PCG + fp64 refinement) and 2 (fp32 search direction and K*p, fp64 iterate and
+    residual) against the CPU oracle (sparse-direct solve of the condensed model): BASELINE.json's bar, 1e-6 relative
+    L2 on the displacements; rtol refers to the TRUE fp64 residual in these modes."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, precision=precision) as dev:
+        dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+        dev.assemble()
+        u, st = dev.solve(rtol=1e-9, max_iter=20000)
+        assert st["converged"] == 1 and int(st["precision_used"]) == precision and st["restarts"] >= 1
+        assert _rel(u, uref) < 1e-6
+        res = np.where(L.fixed_DOF, 0.0, f - dev.spmv(u))
+        b = np.where(L.fixed_DOF, 0.0, f - dev.spmv(ubar))
+        assert np.linalg.norm(res) <= 2e-9 * np.linalg.norm(b)
+    # a Jacobi handle ignores the request and says so
+    with _device(L, precond=1, precision=precision) as dev:
+        dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+        dev.assemble()
+        u1, st1 = dev.solve(rtol=1e-10, max_iter=20000)
+        assert int(st1["precision_used"]) == 0 and _rel(u1, uref) < 1e-6
+
+
+def test_fp32_solver_quarter_of_config5():
+    """A quarter of BASELINE.json configs[4] (100 x 100 x 50 BCC + Octet, r = [0.04, 0.03], 16 M struts) with the fp32
+    inner PCG + fp64 refinement and with the mixed mode: true residual, Clapeyron, and agreement with the fp64 solve."""
+    from pylatticedso_amd import lattice_arrays as LA
+    lat = LA.generate((1, 1, 1), (100, 100, 50), ["BCC", "Octet"], [0.04, 0.03])
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == 100.0
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    out = {}
+    for precision in (0, 1, 2):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, palette=1, precision=precision) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-8, max_iter=20000)
+            assert st["converged"] == 1 and int(st["precision_used"]) == precision
+            res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8
+            assert abs((f * u).sum() - 2.0 * dev.energy(u)) < 1e-7 * abs((f * u).sum())
+            out[precision] = (u, st)
+            print(f"precision {precision}: {st['iterations']} iterations, {st['restarts']:.0f} inner solves, "
+                  f"{st['ms_solve']:.1f} ms, true rel. residual {np.linalg.norm(res) / np.linalg.norm(f):.2e}")
+    assert _rel(out[1][0], out[0][0]) < 1e-6 and _rel(out[2][0], out[0][0]) < 1e-6
 
 
 @pytest.mark.parametrize("n", [5, 64, 100, 700])
