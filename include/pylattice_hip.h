@@ -80,13 +80,18 @@ typedef struct {
                             P(f - K u) every ~4 decades.  2 = only p and K*p stored in fp32, x and the residual
                             recurrence in fp64, true residual verified at the end.  All products and sums are evaluated
                             in fp64 in every mode; rtol always refers to the true fp64 residual in modes 1 and 2 */
-  int32_t reserved[1];
+  int32_t restart_every; /* > 0: every restart_every-th iteration rebuilds the search direction as the reference's CG does
+                            (conjugate_gradient_solver.py:96-97; solve_DDM passes 500000).  Jacobi / DDM paths */
   double alpha_max;      /* > 0: clamp the CG step like conjugate_gradient_solver.py:79 (DDM solves use 100) */
   /* Multi-GPU only: bounding box and node count of the WHOLE lattice, so that every rank cuts the same brick /
    * aggregate grid (all zero -> derived from this handle's own nodes). */
   double grid_lo[3];
   double grid_hi[3];
   int64_t grid_nodes;
+  double mintol;         /* > 0: also stop (converged, pl_stats_t.stop_reason = 1) when ||p|| < mintol (||x|| + 1e-12), the
+                            reference's "direction norm" test (conjugate_gradient_solver.py:102-105; solve_DDM passes
+                            1e-12), and report info = 2 when a step length fell below 1e-6 (:107-109).  These tests need
+                            the host to see every iteration: use check_every = 1.  Jacobi / DDM paths */
 } pl_opts_t;
 
 typedef struct {
@@ -101,7 +106,10 @@ typedef struct {
                               request when a dense level was not positive definite and the solve fell back to Jacobi */
   double restarts;         /* precision = 1 / 2: inner solves taken (each ends with a true-residual evaluation) */
   double precision_used;   /* precision mode the solve ran in (0 when the request did not apply) */
-  double reserved[5];
+  double info;             /* the reference CG's return code (conjugate_gradient_solver.py:75,99-109): 0 converged,
+                              1 not converged, 2 not converged and a step length fell below 1e-6 */
+  double stop_reason;      /* which test ended a converged solve: 0 ||r|| <= rtol ||b||, 1 direction norm (mintol) */
+  double reserved[3];
 } pl_stats_t;
 
 void pl_default_opts(pl_opts_t *o);

@@ -34,16 +34,17 @@ class PlOpts(C.Structure):
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
                 ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("palette", C.c_int32),
-                ("local_max_dofs", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 1),
+                ("local_max_dofs", C.c_int32), ("precision", C.c_int32), ("restart_every", C.c_int32),
                 ("alpha_max", C.c_double), ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3),
-                ("grid_nodes", C.c_int64)]
+                ("grid_nodes", C.c_int64), ("mintol", C.c_double)]
 
 
 class PlStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
                 ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("restarts", C.c_double),
-                ("precision_used", C.c_double), ("reserved", C.c_double * 5)]
+                ("precision_used", C.c_double), ("info", C.c_double), ("stop_reason", C.c_double),
+                ("reserved", C.c_double * 3)]
 
 
 class PlError(RuntimeError):
@@ -160,7 +161,8 @@ class HipLattice:
         self.last_stats = None
 
     @classmethod
-    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0):
+    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0, mintol=0.0,
+            restart_every=0):
         """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm).  precond = 0: plain CG as the
         reference's default; 1: Jacobi on the assembled diagonal; 2: the reference's factorised assembled matrix
         (of the operator's own cell matrices unless ``set_ddm_preconditioner`` installs others)."""
@@ -177,6 +179,7 @@ class HipLattice:
         self._lib.pl_default_opts(C.byref(opts))
         opts.device, opts.alpha_max, opts.check_every = device, alpha_max, check_every
         opts.precond = precond
+        opts.mintol, opts.restart_every = float(mintol), int(restart_every)   # conjugate_gradient_solver.py:96-109
         _check(self._lib, self._lib.pl_create_ddm(self.n_nodes, cn.shape[0], cn.shape[1], _ptr(cn), Sm.shape[0],
                                                   _ptr(Sm), _ptr(cs), C.byref(opts), C.byref(self._h)))
         self.last_stats = None

@@ -279,12 +279,15 @@ int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double
   return PL_OK;
 }
 
+// residual history + (reference-CG mode) direction norm, solution norm and step length of every iteration
 int ensure_hist(pl_context *c, int cap) {
   if (cap <= c->hist_cap) return PL_OK;
-  PL_HIP(c->hist.alloc((size_t)cap));
+  PL_HIP(c->hist.alloc((size_t)cap * 4));
   c->hist_cap = cap;
   return PL_OK;
 }
+// the reference's CG extras are on when the caller asked for any of them (pl_opts_t.mintol / restart_every)
+inline bool ref_cg(const pl_context *c) { return c->opt.mintol > 0.0 || c->opt.restart_every > 0; }
 
 int launch_records(pl_context *c) {
   hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
@@ -535,13 +538,33 @@ int pcg_iteration(pl_context *c, int k) {
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
   if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
+  // reference-CG mode (conjugate_gradient_solver.py:79-109): every restart_every-th iteration the direction is rebuilt
+  // on the PREVIOUS z (with a preconditioner; kept in tmp) or on the updated residual (without one: z aliases r there)
+  const bool ref = ref_cg(c) && !c->dist.active;
+  const bool restart = ref && c->opt.restart_every > 0 && k > 0 && (k % c->opt.restart_every) == 0;
+  const bool has_M = c->dd_ready || c->opt.precond >= 1;
+  const double *pn = c->p.p, *psrc = nullptr;
+  if (restart) {
+    if (has_M) {
+      PL_HIP(hipMemcpyAsync(c->tmp.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      pn = psrc = c->tmp.p;
+    } else {
+      pn = nullptr;        // ||r_new||
+      psrc = c->z.p;       // = r_new once the update kernel has run (dinv = 1 on free dofs)
+    }
+  }
+  const int hcap = ref ? c->hist_cap : 0;
   if (c->dd_ready) {   // DDM with the factorised assembled matrix: update leaves z = 0, r.z = 0; then z = G^-1 r
-    hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max);
+    if (ref)
+      hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
+    else
+      hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
     pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
                     cur + pl::S_RZ_NEW * pl::kSlots, (const double *)nullptr, c->stream);
     hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
-                       c->p.p, cur, nxt, c->hist.p, k);
+                       c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
     PL_HIP(hipGetLastError());
     return PL_OK;
   }
@@ -550,12 +573,15 @@ int pcg_iteration(pl_context *c, int k) {
                                    c->stream);
     if (pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the PCG scalars failed");
+  } else if (ref) {
+    hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
   } else {
-    hipLaunchKernelGGL(pl::k_pcg_update, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max);
+    hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
   }
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
-                     c->p.p, cur, nxt, c->hist.p, k);
+                     c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -614,7 +640,10 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   // the same all-reduced history, hence takes the same decisions.)
   const bool adaptive = c->opt.check_every <= 0;
   const int chunk = adaptive ? 32 : c->opt.check_every;
-  std::vector<double> h_hist(chunk);
+  const bool ref = ref_cg(c) && !c->dist.active && !c->coarse.ready;
+  const int hcap = c->hist_cap;
+  std::vector<double> h_hist(chunk), h_pp(ref ? chunk : 0), h_xx(ref ? chunk : 0), h_al(ref ? chunk : 0);
+  st->info = 1.0;
   int k = 0, next = chunk;
   double rr_prev = bb;
   int k_prev = 0;
@@ -625,14 +654,32 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
       if (rc) return rc;
     }
     PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (ref) {
+      PL_HIP(hipMemcpyAsync(h_pp.data(), c->hist.p + hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipMemcpyAsync(h_xx.data(), c->hist.p + 2 * (size_t)hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipMemcpyAsync(h_al.data(), c->hist.p + 3 * (size_t)hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     PL_HIP(hipStreamSynchronize(c->stream));
     for (int j = 0; j < todo; ++j) {
       const double rr = h_hist[j];
       if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
-      st->rel_residual = std::sqrt(rr / bb);
+      if (!st->converged) st->rel_residual = std::sqrt(rr / bb);
       if (rr <= thresh && !st->converged) {
         st->converged = 1;
         st->iterations = k + j + 1;
+        st->info = 0.0;
+        st->stop_reason = 0.0;
+      }
+      if (ref && !st->converged) {
+        // conjugate_gradient_solver.py:102-109, in its order: the direction-norm stop, then the "tiny step" flag
+        if (c->opt.mintol > 0.0 && std::sqrt(h_pp[j]) < c->opt.mintol * (std::sqrt(h_xx[j]) + 1e-12)) {
+          st->converged = 1;
+          st->iterations = k + j + 1;
+          st->info = 0.0;
+          st->stop_reason = 1.0;
+        } else if (h_al[j] < 1e-6) {
+          st->info = 2.0;
+        }
       }
     }
     k += todo;
@@ -1591,7 +1638,9 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   else if (mp) rc = pcg_solve_mp_t<double>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;
-  st.precision_used = mp ? (double)h->opt.precision : 0.0;     // precision mode the solve ran in
+  st.precision_used = mp ? (double)h->opt.precision : 0.0;
+  if (st.converged) st.info = 0.0;
+  else if (st.info != 2.0) st.info = 1.0;     // precision mode the solve ran in
   hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,
                      h->ubar.p, h->x.p, h->tmp2.p);
   PL_HIP(hipEventRecord(h->ev1, h->stream));

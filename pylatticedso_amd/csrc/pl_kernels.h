@@ -342,20 +342,26 @@ __global__ __launch_bounds__(kBlock) void k_bsr_spmv(int64_t N, const int64_t *_
 // ---------------------------------------------------------------------------------------------------------
 // PCG vector kernels.  Reduction scalars live on the device as kSlots partial sums each: scal[which*kSlots + slot].
 // ---------------------------------------------------------------------------------------------------------
-enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_AUX = 5, S_COUNT = 8 };
+enum { S_RZ_OLD = 0, S_PAP = 1, S_RZ_NEW = 2, S_RR = 3, S_BB = 4, S_AUX = 5, S_PP = 5, S_XX = 6, S_ALPHA = 7, S_COUNT = 8 };
 
 // x += alpha p ; r -= alpha Ap ; z = dinv r ; rz_new += r.z ; rr += r.r      (alpha = rz_old / pAp)
 // alpha_max > 0 clamps the step like the reference's conjugate_gradient_solver.py:79 (used by the DDM solve).
+// REF: the extra bookkeeping of the reference's hand-written CG (conjugate_gradient_solver.py:96-109): ||x||^2 and the
+// "direction norm" ||pn||^2 (pn = the search direction, or the vector a restart replaces it with; null: the restart
+// source is the updated residual itself, its norm is r.r) into the S_XX / S_PP slots, the step length into S_ALPHA.
+template <bool REF>
 __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double *__restrict__ p,
                                                        const double *__restrict__ Ap,
                                                        const double *__restrict__ dinv, double *__restrict__ x,
                                                        double *__restrict__ r, double *__restrict__ z,
-                                                       double *__restrict__ scal, double alpha_max) {
-  __shared__ double red[2][kBlock / kWave];
+                                                       double *__restrict__ scal, double alpha_max,
+                                                       const double *__restrict__ pn) {
+  __shared__ double red[4][kBlock / kWave];
   const double pap = scalar_read(scal, S_PAP);
   double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
   if (alpha_max > 0.0 && alpha > alpha_max) alpha = alpha_max;
-  double rz = 0.0, rr = 0.0;
+  double rz = 0.0, rr = 0.0, xx = 0.0, pp = 0.0;
+  if (REF && blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA * kSlots] = alpha;
   const int64_t n2 = n6 >> 1;   // n6 is even (6 per node)
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     const double2 pv = reinterpret_cast<const double2 *>(p)[i];
@@ -371,44 +377,80 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
     reinterpret_cast<double2 *>(z)[i] = zv;
     rz += rv.x * zv.x + rv.y * zv.y;
     rr += rv.x * rv.x + rv.y * rv.y;
+    if (REF) {
+      xx += xv.x * xv.x + xv.y * xv.y;
+      if (pn) {
+        const double2 q = reinterpret_cast<const double2 *>(pn)[i];
+        pp += q.x * q.x + q.y * q.y;
+      }
+    }
   }
   rz = wave_sum(rz);
   rr = wave_sum(rr);
+  if (REF) {
+    xx = wave_sum(xx);
+    pp = wave_sum(pp);
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) { red[0][w] = rz; red[1][w] = rr; }
+  if (lane == 0) { red[0][w] = rz; red[1][w] = rr; red[2][w] = xx; red[3][w] = pp; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; }
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; d += red[3][k]; }
     scalar_add(scal, S_RZ_NEW, a);
     scalar_add(scal, S_RR, b);
+    if (REF) {
+      scalar_add(scal, S_XX, c);
+      scalar_add(scal, S_PP, pn ? d : b);
+    }
   }
 }
 
 // p = z + beta p   (beta = rz_new / rz_old), and the end-of-iteration scalar bookkeeping: the reduction scalars are
 // double-buffered by iteration parity, so block 0 can record ||r||^2 and prepare the NEXT iteration's set
 // (rz_old <- rz_new, accumulators zeroed) while the other blocks still read the current one.
+// psrc (may be null = p): the vector the new direction is built on, p = z + beta psrc - on a restart iteration of the
+// reference CG that is the previous z (with a preconditioner) or the updated residual (without: z aliases r there).
+// hist_cap > 0: also record ||psrc||^2, ||x||^2 and the step length (slots filled by k_pcg_update<true>) behind the
+// residual history, at hist[hist_cap + k], hist[2 hist_cap + k], hist[3 hist_cap + k].
 __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const double *__restrict__ z,
-                                                          double *__restrict__ p, const double *__restrict__ scal,
+                                                          double *p, const double *__restrict__ scal,
                                                           double *__restrict__ scal_next, double *__restrict__ hist,
-                                                          int k) {
+                                                          int k, const double *psrc, int hist_cap) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
     const double rr = scalar_read(scal, S_RR);
+    double pp = 0.0, xx = 0.0;
+    if (hist_cap > 0) {
+      pp = scalar_read(scal, S_PP);
+      xx = scalar_read(scal, S_XX);
+    }
     const int s = threadIdx.x;
-    if (s == 0) hist[k] = rr;
+    if (s == 0) {
+      hist[k] = rr;
+      if (hist_cap > 0) {
+        hist[hist_cap + k] = pp;
+        hist[2 * hist_cap + k] = xx;
+        hist[3 * hist_cap + k] = scal[S_ALPHA * kSlots];
+      }
+    }
     if (s < kSlots) {
       scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
       scal_next[S_RZ_NEW * kSlots + s] = 0.0;
       scal_next[S_RR * kSlots + s] = 0.0;
       scal_next[S_PAP * kSlots + s] = 0.0;
+      if (hist_cap > 0) {
+        scal_next[S_PP * kSlots + s] = 0.0;
+        scal_next[S_XX * kSlots + s] = 0.0;
+      }
     }
   }
+  if (!psrc) psrc = p;
   const int64_t n2 = n6 >> 1;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     const double2 zv = reinterpret_cast<const double2 *>(z)[i];
-    double2 pv = reinterpret_cast<double2 *>(p)[i];
+    double2 pv = reinterpret_cast<const double2 *>(psrc)[i];
     pv.x = zv.x + beta * pv.x;
     pv.y = zv.y + beta * pv.y;
     reinterpret_cast<double2 *>(p)[i] = pv;

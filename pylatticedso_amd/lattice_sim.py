@@ -499,8 +499,11 @@ class LatticeSim:
             self._ddm_precond = 0
             if self.enable_preconditioner:
                 self._ddm_precond = 2 if 6 * n_nodes <= DDM_DENSE_MAX else 1
+            # CG parameters of the reference's solve_DDM (lattice_sim.py:1156-1159): alpha clamp 100, direction-norm
+            # stop 1e-12, restart every 500 000 iterations
             self._ddm_device = HipLattice.ddm(n_nodes, self.index_boundary[cb], self.schur_complements,
-                                              self.cell_schur_index, precond=self._ddm_precond)
+                                              self.cell_schur_index, precond=self._ddm_precond, alpha_max=100.0,
+                                              mintol=1e-12, restart_every=500000)
             if self._ddm_precond == 2:
                 self.define_preconditioner()
         return self._ddm_device
@@ -620,7 +623,7 @@ class LatticeSim:
             if not st["converged"] and maxit < 20000:
                 u, st = dev.solve(rtol=1e-6, max_iter=20000, raise_on_noconv=False)
         self.iteration = st["iterations"]
-        info = 0 if st["converged"] else 1
+        info = int(st["info"])               # 0 converged, 1 not, 2 not and a step fell below 1e-6 (the reference's codes)
         if info and self._verbose > -1:
             print(f"Conjugate Gradient did not converge ({self.iteration} iterations, relative residual "
                   f"{st['rel_residual']:.2e}).")

@@ -254,6 +254,11 @@ def gen_cg():
     for tag, kw in {"plain": dict(M=None, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100),
                     "jacobi": dict(M=Minv, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100),
                     "clamped": dict(M=None, maxiter=25, tol=1e-10, mintol=1e-14, restart_every=7, alpha_max=0.01),
+                    # the direction-norm stop (conjugate_gradient_solver.py:102-105), restarts every 5 iterations with
+                    # a preconditioner, and the "step too small" flag info = 2 (:107-109)
+                    "dirstop": dict(M=None, maxiter=200, tol=1e-14, mintol=2e-4, restart_every=500000, alpha_max=100),
+                    "restart_jacobi": dict(M=Minv, maxiter=40, tol=1e-9, mintol=1e-14, restart_every=5, alpha_max=100),
+                    "tiny_step": dict(M=None, maxiter=12, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=5e-7),
                     }.items():
         trace = []
         x, info = _quiet(conjugate_gradient_solver, A, b.copy(), callback=lambda xk: trace.append(xk.copy()), **kw)

@@ -8,6 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from pylatticedso_amd import _capi                     # noqa: E402
 from pylatticedso_amd.lattice_sim import LatticeSim   # noqa: E402
 
 
@@ -159,3 +160,32 @@ def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeyp
     ddm["preconditioner_type"] = "something"
     with pytest.raises(NotImplementedError):
         LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("plain", dict(M=False, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100)),
+    ("jacobi", dict(M=True, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100)),
+    ("clamped", dict(M=False, maxiter=25, tol=1e-10, mintol=1e-14, restart_every=7, alpha_max=0.01)),
+    ("dirstop", dict(M=False, maxiter=200, tol=1e-14, mintol=2e-4, restart_every=500000, alpha_max=100)),
+    ("restart_jacobi", dict(M=True, maxiter=40, tol=1e-9, mintol=1e-14, restart_every=5, alpha_max=100)),
+    ("tiny_step", dict(M=False, maxiter=12, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=5e-7)),
+])
+def test_device_cg_has_the_reference_semantics(golden_dir, tag, kw):
+    """The device CG against runs of the reference's conjugate_gradient_solver (cg_trace.npz, dumped from the running
+    reference): alpha clamp, restart (on the previous z with a preconditioner, on the updated residual without), the
+    direction-norm stop and the info codes 0 / 1 / 2 (conjugate_gradient_solver.py:79,96-109).  The 60 x 60 SPD matrix
+    is handed over as the Schur complement of one 10-node "cell"; its Jacobi preconditioner is precond = 1."""
+    g = np.load(os.path.join(golden_dir, "cg_trace.npz"))
+    A, b = g["A"], g["b"]
+    dev = _capi.HipLattice.ddm(10, np.arange(10)[None, :], A, np.zeros(1, np.int32), precond=1 if kw["M"] else 0,
+                               alpha_max=kw["alpha_max"], mintol=kw["mintol"], restart_every=kw["restart_every"],
+                               check_every=1)
+    with dev:
+        dev.set_bc(np.zeros((10, 6), bool), None, b.reshape(10, 6))
+        dev.assemble()
+        x, st = dev.solve(rtol=kw["tol"], max_iter=kw["maxiter"], raise_on_noconv=False)
+    assert int(st["info"]) == int(g[f"{tag}_info"])
+    assert st["iterations"] == len(g[f"{tag}_trace"])
+    assert np.allclose(x.ravel(), g[f"{tag}_x"], rtol=1e-8, atol=1e-12)
+    if tag == "dirstop":
+        assert int(st["stop_reason"]) == 1 and st["converged"] == 1

@@ -102,6 +102,9 @@ def test_closed_form_condensation_matches_submeshed_chain(seed):
     ("plain", dict(M=False, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100)),
     ("jacobi", dict(M=True, maxiter=200, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=100)),
     ("clamped", dict(M=False, maxiter=25, tol=1e-10, mintol=1e-14, restart_every=7, alpha_max=0.01)),
+    ("dirstop", dict(M=False, maxiter=200, tol=1e-14, mintol=2e-4, restart_every=500000, alpha_max=100)),
+    ("restart_jacobi", dict(M=True, maxiter=40, tol=1e-9, mintol=1e-14, restart_every=5, alpha_max=100)),
+    ("tiny_step", dict(M=False, maxiter=12, tol=1e-10, mintol=1e-14, restart_every=500000, alpha_max=5e-7)),
 ])
 def test_reference_cg_trace(golden_dir, tag, kw):
     g = np.load(os.path.join(golden_dir, "cg_trace.npz"))
