@@ -49,6 +49,6 @@ for it in range(iters):
     theta = np.clip((np.clip(rr, 0.01, 0.1) - 0.01) / 0.09, 0.0, 1.0)
 t_loop = time.perf_counter() - t_loop
 print(json.dumps({"workload": f"{n}^3 BCC graded radius, unit_cell parameterisation ({L.number_parameters} parameters)",
-                  "struts": L.get_number_beams(), "iterations": iters, "setup_s": t_setup, "loop_s": t_loop,
+                  "struts": L.lattice.n_beams, "iterations": iters, "setup_s": t_setup, "loop_s": t_loop,
                   "s_per_objective_plus_gradient": t_loop / iters, "compliance_first": hist[0],
                   "compliance_last": hist[-1], "last_pcg_iterations": L._model.stats["iterations"]}))

@@ -13,7 +13,7 @@ from pyLatticeSim.utils_simulation import solve_FEM_FenicsX                     
 name_file = "simulation/simulation_beam_flexion"
 lattice_Sim_object = LatticeSim(name_file)
 sol, simulation_lattice = solve_FEM_FenicsX(lattice_Sim_object)
-print(f"{lattice_Sim_object.get_number_beams()} struts, {len(sol)} free boundary dofs, "
+print(f"{lattice_Sim_object.lattice.n_beams} struts, {len(sol)} free boundary dofs, "
       f"{simulation_lattice.stats['iterations']} PCG iterations, max |u| = {abs(sol).max():.4e}")
 
 vizualizer = LatticePlotting()

@@ -198,6 +198,14 @@ int pl_reactions(pl_handle h, const double *u, double *R);
  * Material.compute_gradient (material_definition.py:163-231). */
 int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr);
 
+/* Displacements of the penalisation points ("node_mod" points: the junctions between the penalised end segments and the
+ * middle segment of every strut, LatticeSim.set_penalized_beams lattice_sim.py:245-308, which the reference meshes as
+ * FE vertices and reads back in set_result_diplacement_on_lattice_object, full_scale_lattice_simulation.py:77-107).
+ * They are interior points of the condensed strut: recovered in closed form from the end displacements u[6N].
+ * out[12*b ..] = [u(q1)(3) th(q1)(3) u(q2)(3) th(q2)(3)], q1 next to beam_conn[2b], q2 next to beam_conn[2b+1]; an absent
+ * segment gives the end node's own values. */
+int pl_node_mod(pl_handle h, const double *u, double *out);
+
 /* Strain energy 1/2 u^T K u (LatticeOpti.compute_compliance, lattice_opti.py:645-663 uses u^T K u). */
 int pl_energy(pl_handle h, const double *u, double *energy);
 

@@ -1688,6 +1688,26 @@ int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
   return PL_OK;
 }
 
+int pl_node_mod(pl_handle h, const double *u, double *out) {
+  if (!valid(h) || !u || !out) return fail(PL_ERR_ARG, "pl_node_mod: null argument");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_node_mod: not available on a DDM handle");
+  if (!h->assembled) return fail(PL_ERR_STATE, "pl_node_mod: call pl_assemble first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  std::vector<double> stage;
+  int rc = upload6(h, u, h->tmp.p, stage);
+  if (rc) return rc;
+  DevBuf<double> dev;
+  PL_HIP(dev.alloc((size_t)h->B * 12));
+  hipLaunchKernelGGL(pl::k_node_mod, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
+                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mat, h->rec.p, h->tmp.p, dev.p);
+  PL_HIP(hipGetLastError());
+  std::vector<double> tmp((size_t)h->B * 12);
+  PL_HIP(hipMemcpyAsync(tmp.data(), dev.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  for (int64_t b = 0; b < h->B; ++b) std::memcpy(out + 12 * (size_t)h->bperm[b], &tmp[12 * (size_t)b], 12 * sizeof(double));
+  return PL_OK;
+}
+
 int pl_energy(pl_handle h, const double *u, double *energy) {
   if (!valid(h) || !u || !energy) return fail(PL_ERR_ARG, "pl_energy: null argument");
   if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_energy: not available on a DDM handle");

@@ -528,6 +528,73 @@ __global__ __launch_bounds__(kBlock) void k_sens(int64_t B, const double *__rest
   out[b] = dot(F, dlu) + dot(M, dlt);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Back-substitution of the penalisation points ("node_mod" points of LatticeSim.set_penalized_beams,
+// lattice_sim.py:245-308): the strut carries no load between its ends, so the section force F is constant along it and
+// the moment about a point Q is M_B + (x_B - x_Q) x F; the junctions q1 (end of the penalised segment at point1) and q2
+// (start of the one at point2) follow by integrating the segment flexibilities from end A:
+//     u_Q = u_P + th_P x (x_Q - x_P) + du,   th_Q = th_P + dth
+//     du  = fa (F.t) t + f11 F_perp + f12 (M_Q x t),   dth = ft (M_Q.t) t + f12 (t x F) + f22 M_Q_perp
+// with the closed-form chain flexibilities of pl_device.h.  out[b] = [u(q1) th(q1) u(q2) th(q2)] (12 doubles); an absent
+// segment returns the end node's own values.  One thread per strut, no scatter.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void segment_step(double l, int nsub, double R, const Material &m, V3 t, V3 F, V3 MQ,
+                                             V3 &u, V3 &th) {
+  const double PI = 3.14159265358979323846;
+  const double S = PI * R * R, I = 0.25 * PI * R * R * R * R;
+  const double ES = m.E * S, GS = m.G * m.kappa * S, EI = m.E * I, GJ = m.G * 2.0 * I;
+  const double n = (double)nsub;
+  const double fa = l / ES, ft = l / GJ;
+  const double f11 = l / GS + l * l * l / (3.0 * EI) * (1.0 - 1.0 / (4.0 * n * n));
+  const double f12 = l * l / (2.0 * EI), f22 = l / EI;
+  const double Ft = dot(F, t), Mt = dot(MQ, t);
+  const V3 Fp = F - Ft * t, Mp = MQ - Mt * t;
+  const V3 du = (fa * Ft) * t + f11 * Fp + f12 * cross(MQ, t);
+  const V3 dth = (ft * Mt) * t + f12 * cross(t, F) + f22 * Mp;
+  u = u + l * cross(th, t) + du;      // rigid part uses the rotation at the segment's start
+  th = th + dth;
+}
+
+__global__ __launch_bounds__(kBlock) void k_node_mod(int64_t B, const double *__restrict__ xyz,
+                                                     const int32_t *__restrict__ conn,
+                                                     const double *__restrict__ radius,
+                                                     const double *__restrict__ seg_len,
+                                                     const int32_t *__restrict__ seg_nsub, Material m,
+                                                     const Record *__restrict__ rec, const double *__restrict__ u,
+                                                     double *__restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+  const Record r = load_record(rec, b);
+  V3 uA, tA, uB, tB, F, M;
+  load6(u + 6 * ia, uA, tA);
+  load6(u + 6 * ib, uB, tB);
+  tip_force(r, uA, tA, uB, tB, F, M);                      // load at end B that holds this deformation
+  const V3 d = {r.dx, r.dy, r.dz};
+  const double L = sqrt(dot(d, d));
+  const V3 t = (1.0 / L) * d;
+  const double l1 = seg_len[3 * b], l2 = seg_len[3 * b + 1], l3 = seg_len[3 * b + 2];
+  (void)l3;
+  const double rr = radius[b];
+  V3 uq = uA, tq = tA;
+  double s = 0.0;
+  double *o = out + 12 * b;
+  if (l1 > 0.0) {
+    s = l1;
+    const V3 MQ = M + (L - s) * cross(t, F);               // moment about q1
+    segment_step(l1, seg_nsub[3 * b], m.pen * rr, m, t, F, MQ, uq, tq);
+  }
+  o[0] = uq.x; o[1] = uq.y; o[2] = uq.z; o[3] = tq.x; o[4] = tq.y; o[5] = tq.z;
+  if (seg_len[3 * b + 2] > 0.0) {
+    s += l2;
+    const V3 MQ = M + (L - s) * cross(t, F);               // moment about q2
+    segment_step(l2, seg_nsub[3 * b + 1], rr, m, t, F, MQ, uq, tq);
+    o[6] = uq.x; o[7] = uq.y; o[8] = uq.z; o[9] = tq.x; o[10] = tq.y; o[11] = tq.z;
+  } else {
+    o[6] = uB.x; o[7] = uB.y; o[8] = uB.z; o[9] = tB.x; o[10] = tB.y; o[11] = tB.z;
+  }
+}
+
 // partial strain energies 1/2 e^T K e per strut, block-reduced and atomically added.
 __global__ __launch_bounds__(kBlock) void k_energy(int64_t B, const int32_t *__restrict__ conn,
                                                    const Record *__restrict__ rec, const double *__restrict__ u,

@@ -21,6 +21,8 @@ from pathlib import Path
 import numpy as np
 
 from . import lattice_arrays as LA
+from .timing import timing
+from .views import LatticeViews
 
 DDM_DENSE_MAX = 16384      # PL_DDM_DENSE_MAX of include/pylattice_hip.h
 
@@ -59,7 +61,7 @@ def material_properties(name):
     raise FileNotFoundError(f"Material file not found: {name}.json")
 
 
-class LatticeSim:
+class LatticeSim(LatticeViews):
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0,
                  enable_domain_decomposition_solver: bool = False, data_roots=None):
         """Same arguments as the reference (lattice_sim.py:44-47) plus ``data_roots``: extra directories in which the
@@ -174,6 +176,8 @@ class LatticeSim:
         self.young_modulus, self.poisson_ratio = material_properties(self.material_name)
 
     # ------------------------------------------------------------------------------------------------
+    @timing.category("simulation")
+    @timing.timeit
     def reset_cell_with_new_radii(self, new_radii, index_cell: int = 0):
         """lattice_sim.py:1421-1497: give one cell new base radii and redo everything that depends on them - the
         struts of that cell, the penalisation lengths (L_zone depends on the neighbours' radii), boundary indices and
@@ -188,6 +192,8 @@ class LatticeSim:
         self._cell_radii_override[index_cell] = self.radii
         self._generate_and_prepare()
 
+    @timing.category("simulation")
+    @timing.timeit
     def set_cell_radii(self, radii):
         """Give every cell its own radii, (C, n_geometries) in the cell order of ``lattice.cell_pos`` - what a loop of
         ``Cell.change_beam_radius`` (cell.py:896-917) does in the reference (LatticeOpti works this way).  The lattice
@@ -198,6 +204,8 @@ class LatticeSim:
         if self.domain_decomposition_solver:
             self.calculate_schur_complement_cells()
 
+    @timing.category("design")
+    @timing.timeit
     def _generate_and_prepare(self):
         """Lattice arrays + penalisation + boundary indices + boundary conditions from the current parameters."""
         for dev in (getattr(self, "_device", None), getattr(self, "_ddm_device", None)):
@@ -236,16 +244,12 @@ class LatticeSim:
     def get_number_cells(self):
         return self.lattice.n_cells
 
-    def get_number_beams(self):
-        return self.lattice.n_beams
-
-    def get_number_nodes(self):
-        return self.lattice.n_nodes
-
     def get_lattice_boundary_box(self):
         return [self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max]
 
     # ------------------------------------------------------------------------------------------------
+    @timing.category("design")
+    @timing.timeit
     def define_angles_between_beams(self):
         """lattice.py:805-904.  Large non-periodic lattices take the device kernel (pl_lzone: the valence^2 angle search
         is 10^7-10^8 pair evaluations at 10^6 struts); small ones and periodic single cells the numpy restatement."""
@@ -255,10 +259,14 @@ class LatticeSim:
         else:
             self.lzone = LA.compute_lzone(self.lattice, bool(self.enable_periodicity))
 
+    @timing.category("simulation")
+    @timing.timeit
     def set_penalized_beams(self):
         self.penalized = LA.penalize(self.lattice, self.lzone)
         self.is_penalized = True
 
+    @timing.category("simulation")
+    @timing.timeit
     def define_node_index_boundary(self):
         """Boundary index of every node lying on the box of one of its cells (lattice_sim.py:546-563), numbered in
         the order get_global_displacement visits them (cells in order, nodes by rounded coordinates)."""
@@ -347,6 +355,8 @@ class LatticeSim:
             else:
                 raise ValueError("Invalid type of constraint. Use 'Displacement' or 'Force'.")
 
+    @timing.category("simulation")
+    @timing.timeit
     def set_boundary_conditions(self):
         """lattice_sim.py:460-494."""
         for key, block in self.boundary_conditions.items():
@@ -372,6 +382,8 @@ class LatticeSim:
                                              key, data.get("SurfaceCells", None))
 
     # ------------------------------------------------------------------------------------------------
+    @timing.category("simulation")
+    @timing.timeit
     def get_global_displacement(self, withFixed: bool = False, OnlyImposed: bool = False):
         """lattice_sim.py:502-542: free dofs of the cell-boundary nodes in visit order."""
         V = np.asarray(self._boundary_visit_order, dtype=np.int64)
@@ -428,6 +440,8 @@ class LatticeSim:
             self._ddm_device.close()
             self._ddm_device = None
 
+    @timing.category("simulation")
+    @timing.timeit
     def calculate_schur_complement_cells(self):
         """Exact Schur complement of one representative cell per (geometry, radii) group (lattice_sim.py:846-919),
         condensed on the device (pl_schur) from that cell's own struts with their penalised segments."""
@@ -544,6 +558,8 @@ class LatticeSim:
         raise FileNotFoundError(f"Schur complement dataset for the '{self.preconditioner_type}' preconditioner not "
                                 f"found: {name} (looked under {roots})")
 
+    @timing.category("simulation")
+    @timing.timeit
     def define_preconditioner(self):
         """lattice_sim.py:1333-1415 (define_preconditioner + build_preconditioner): choose the cell matrices the
         assembled preconditioner is made of and hand them to the device, which assembles and factorises
@@ -582,6 +598,8 @@ class LatticeSim:
         surrogates and of the nearest-reference preconditioner."""
         return self.lattice.cell_radii / self._cell_gfac[:, None]
 
+    @timing.category("simulation")
+    @timing.timeit
     def solve_DDM(self):
         """Domain-decomposition solve on the cell-boundary nodes (lattice_sim.py:1111-1176): right-hand side
         b = f_free - (S u_imposed)_free, plain CG with the reference's parameters (tol 1e-6, alpha clamp 100,

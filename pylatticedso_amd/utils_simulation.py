@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .timing import timing
+
 DEFAULT_RTOL = 1e-9       # on ||r||/||b||; gives <1e-9 relative L2 error on displacements in the parity tests
 DEFAULT_MAX_ITER = 200000
 
@@ -49,8 +51,24 @@ class FullScaleLatticeSimulation:
         return self.u
 
     def set_result_diplacement_on_lattice_object(self):
-        """full_scale_lattice_simulation.py:77-107."""
+        """full_scale_lattice_simulation.py:77-107: displacements of every lattice node; the penalisation points
+        (node_mod, FE vertices in the reference) are interior points of the condensed struts here and are recovered in
+        closed form on the device (pl_node_mod) the first time one of them is looked at."""
         self.lattice.displacement_vector[:] = self.u
+        if self.lattice.is_penalized:
+            dev, u = self.device, self._u_solver
+            self.lattice._node_mod_pending = lambda: dev.node_mod(u)
+
+    @property
+    def domain(self):
+        """Stand-in for the dolfinx mesh the reference's model carries (``simulationModel.domain``): vertex
+        coordinates (lattice nodes, then penalisation points) and the line cells (segments) between them."""
+        from types import SimpleNamespace
+        from .views import _tables
+        t = _tables(self.lattice)
+        return SimpleNamespace(geometry=SimpleNamespace(x=t.node_xyz, dim=3),
+                               topology=SimpleNamespace(dim=1, cells=t.beam_conn, radius=t.beam_radius,
+                                                        beam_mod=t.beam_mod))
 
     def set_reaction_force_on_lattice_with_FEM_results(self):
         """full_scale_lattice_simulation.py:111-120: R_i = v_i^T K u for the 6 dofs of every constrained node."""
@@ -71,6 +89,8 @@ class FullScaleLatticeSimulation:
         return list(self.device.reactions(self.u)[i])
 
 
+@timing.category("simulation")
+@timing.timeit
 def solve_FEM_FenicsX(lattice, rtol=DEFAULT_RTOL, max_iter=DEFAULT_MAX_ITER):
     """Solve the lattice's FEM problem on the GPU; returns (xsol, simulationModel)."""
     model = FullScaleLatticeSimulation(lattice, lattice.device_model())

@@ -154,6 +154,12 @@ def test_solve_matches_reference_faithful_direct_solve(golden_dir, name, kernel)
     free = ~L.fixed_DOF
     expect = np.concatenate([uall[n][free[n]] for n in L._boundary_visit_order])
     assert _rel(xsol, expect) < 1e-7
+    # penalisation points (node_mod): FE vertices in the reference, recovered here in closed form along every condensed
+    # strut (pl_node_mod) - same node numbering as the reference, same displacements and rotations
+    assert len(L.nodes) == n0
+    umod = np.array([p.displacement_vector for p in L.nodes[N:]])
+    assert umod.shape == (n0 - N, 6) and _rel(umod, uall[N:n0]) < 1e-7
+    assert np.allclose(model.domain.geometry.x, g["node_xyz"]) and len(model.domain.topology.cells) == keep.sum()
     # reactions: R = K u on constrained nodes, times the reference's per-cell accumulation
     Rref = (K @ uall.ravel()).reshape(-1, 6)[:N]
     nodes = L.fixed_DOF.any(axis=1)

@@ -18,9 +18,11 @@ def test_imports_and_preset_lookup():
     from pyLatticeDesign.plotting_lattice import LatticePlotting         # noqa: F401
     from pyLatticeOpti.lattice_opti import LatticeOpti                   # noqa: F401
     L = LatticeSim("simulation/simulation_beam_flexion")
-    assert (L.get_number_cells(), L.get_number_beams(), L.get_number_nodes()) == (54, 432, 166)
+    # 432 struts -> 1 288 penalised segments, as in the reference: len(lattice.beams) counts the
+    # segments once the joints are penalised, 166 design nodes + 856 penalisation points
+    assert (L.lattice.n_cells, L.lattice.n_beams, L.lattice.n_nodes) == (54, 432, 166)
+    assert (L.get_number_cells(), L.get_number_beams(), L.get_number_nodes()) == (54, 1288, 166 + 856)
     assert L.material_name == "VeroClear" and L.is_penalized
-    # 432 struts -> 1 288 penalised segments, as in the reference
     assert int((L.penalized.seg_len > 0).sum()) == 1288
     with pytest.raises(FileNotFoundError):
         LatticeSim("simulation/does_not_exist")

@@ -10,4 +10,4 @@ preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells":
                          "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}}
 t0 = time.time(); L = LatticeSim(preset); t1 = time.time()
 xsol, model = solve_FEM_FenicsX(L); t2 = time.time()
-print(f"{n}^3 Octet through the drop-in API: LatticeSim {t1-t0:.1f} s, solve_FEM_FenicsX {t2-t1:.2f} s ({model.stats['iterations']} PCG iterations, device solve {model.stats['ms_solve']:.1f} ms), {L.get_number_beams()} struts, len(xsol) {len(xsol)}")
+print(f"{n}^3 Octet through the drop-in API: LatticeSim {t1-t0:.1f} s, solve_FEM_FenicsX {t2-t1:.2f} s ({model.stats['iterations']} PCG iterations, device solve {model.stats['ms_solve']:.1f} ms), {L.lattice.n_beams} struts, len(xsol) {len(xsol)}")
