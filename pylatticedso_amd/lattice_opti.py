@@ -31,7 +31,10 @@ _DOF = {"X": 0, "Y": 1, "Z": 2, "RX": 3, "RY": 4, "RZ": 5}
 
 class LatticeOpti(LatticeSim):
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0, convergence_plotting: bool = False,
-                 data_roots=None):
+                 data_roots=None, reference_compat: bool = False):
+        """``reference_compat``: for the "linear" parameterisation return the gradient exactly as the reference computes
+        it (lattice_opti.py:787-841, 719-720) instead of the derivative of the objective (see calculate_gradient)."""
+        self.reference_compat = bool(reference_compat)
         info = open_lattice_parameters(name_file).get("optimization_informations", {})
         # lattice_opti.py:96-103: simulation_type "DDM" runs every equilibrium through solve_DDM with the cell Schur
         # complements (exact or surrogate) and contracts their derivatives dS/dr for the gradient
@@ -195,10 +198,9 @@ class LatticeOpti(LatticeSim):
         if self._ddm_mode:
             # reset_cell_with_new_radii (lattice_sim.py:1421-1497): new cell radii -> new Schur complements (+ dS/dr)
             lat.cell_radii = self.cell_radii * self._cell_gfac[:, None]
-            if self.type_schur_complement_computation == "exact":
-                raise NotImplementedError("DDM optimisation with exact Schur complements: use a surrogate type "
-                                          "(the reference finite-differences dolfinx solves here) or 'FEM'")
-            self._surrogate_schur_complement_cells()
+            # exact: one device condensation per distinct radius set (+ central differences for dS/dr when gradients
+            # are on, as lattice_sim.py:1020-1054 does with dolfinx solves); surrogates: one batched evaluation
+            self.calculate_schur_complement_cells()
             return
         dev = self.device_model()
         dev.update_radii(lat.beam_radius)
@@ -342,6 +344,25 @@ class LatticeOpti(LatticeSim):
             if self.optimization_parameters.get("hybrid", False):
                 return s_cell.sum(axis=0)
             return np.array([s_cell.sum()])
+        if t == "linear" and self.reference_compat:
+            # The reference's chain rule, verbatim in effect (lattice_opti.py:787-841): slopes are de-normalised like
+            # radii (clamped into [r_min, r_max]), the "unclamped radius" r = sum a_k c_k + d is formed with the ABSOLUTE
+            # cell-centre coordinates and only decides which cells count; d r / d a_k = c_k, d r / d d = 1.  This is not
+            # the derivative of the objective (whose field is r = d + span * sum theta_k (c_k - c0_k) / L_k, :467-560);
+            # kept behind this switch so that runs can be compared with the reference number for number.
+            dirs = self.optimization_parameters.get("direction", [])
+            theta = self.actual_optimization_parameters
+            a = [self.denormalize_optimization_parameters([float(theta[i])])[0] for i in range(len(dirs))]
+            d0 = self.denormalize_optimization_parameters([float(theta[-1])])[0]
+            cen = self._cell_center
+            r_un = d0 + sum(a[i] * cen[:, "xyz".index(k)] for i, k in enumerate(dirs))
+            active = (r_un > self.min_radius + 1e-12) & (r_un < self.max_radius - 1e-12)
+            sc = (s_cell / self._cell_gfac[:, None]).sum(axis=1) * active
+            grad = np.zeros(self.number_parameters)
+            for i, k in enumerate(dirs):
+                grad[i] = (sc * cen[:, "xyz".index(k)]).sum()
+            grad[-1] = sc.sum()
+            return grad
         if t == "linear":
             dirs = self.optimization_parameters.get("direction", [])
             theta = self.actual_optimization_parameters
@@ -367,7 +388,7 @@ class LatticeOpti(LatticeSim):
         g = -self.calculate_gradient()
         if self.objective_function == "max":
             g = -g        # objective() negates the (normalised) value for 'max'; keep the pair consistent
-        if self.optimization_parameters["type"] == "linear":
+        if self.optimization_parameters["type"] == "linear" and not self.reference_compat:
             # slopes act on the physical radius directly (span already applied); only the intercept is normalised
             scale = np.ones(self.number_parameters)
             if self.enable_normalization:

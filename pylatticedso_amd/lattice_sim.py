@@ -452,7 +452,7 @@ class LatticeSim(LatticeViews):
         cb = self.cell_boundary_nodes()
         par = self._cell_parameter_radii()       # the reference groups by Cell.radii, which ignores the preset gradient
         keys = [tuple(np.round(par[c], 8)) for c in range(lat.n_cells)]
-        groups, mats, idx = {}, [], np.zeros(lat.n_cells, np.int32)
+        groups, mats, grads, idx = {}, [], [], np.zeros(lat.n_cells, np.int32)
         for c, k in enumerate(keys):
             if k not in groups:
                 beams = lat.cell_beam_idx[lat.cell_beam_ptr[c]:lat.cell_beam_ptr[c + 1]]
@@ -464,8 +464,27 @@ class LatticeSim(LatticeViews):
                                 pen_coef=self.penalization_coefficient, reorder=0) as dev:
                     dev.assemble()
                     mats.append(dev.schur(remap[cb[c]], rtol=1e-13, max_iter=200000))
+                    if self.enable_gradient_computing:
+                        # _compute_schur_gradients (lattice_sim.py:1020-1054): central differences in every radius
+                        # parameter of the cell, h = max(1e-8, 1e-6 max(1, |r|)), radii changed at FIXED penalised
+                        # segment lengths (Cell.change_beam_radius, cell.py:896-917)
+                        gl = []
+                        for j, rj in enumerate(par[c]):
+                            h = max(1e-8, 1e-6 * max(1.0, abs(rj)))
+                            rp, rm = rj + h, max(1e-12, rj - h)
+                            S_pm = []
+                            for rv in (rp, rm):
+                                rad = lat.beam_radius[beams].copy()
+                                sel = lat.beam_type[beams] == j
+                                rad[sel] = rv * self._cell_gfac[c]
+                                dev.update_radii(rad)
+                                dev.assemble()
+                                S_pm.append(dev.schur(remap[cb[c]], rtol=1e-13, max_iter=200000))
+                            gl.append((S_pm[0] - S_pm[1]) / (rp - rm))
+                        grads.append(gl)
                 groups[k] = len(mats) - 1
             idx[c] = groups[k]
+        self.schur_gradients = grads if self.enable_gradient_computing else None
         self.set_schur_complements(np.stack(mats), idx)
 
     def _surrogate_schur_complement_cells(self):

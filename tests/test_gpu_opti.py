@@ -2,6 +2,8 @@
 differences of the objective itself, for every parameterisation, and a short SLSQP run."""
 import copy
 
+import json
+
 import numpy as np
 import pytest
 
@@ -183,3 +185,42 @@ def test_ddm_objective_and_gradient_match_the_reference(golden_dir, case):
         fd[i] = (L.objective(list(xp)) - L.objective(list(xm))) / (2 * h)
     assert np.linalg.norm(grad - fd) < 1e-3 * np.linalg.norm(fd)
     assert np.linalg.norm(grad_ref - fd) > 0.1 * np.linalg.norm(fd)
+    # reference_compat = True reproduces the reference's own vector number for number
+    Lc = LatticeOpti(json.loads(str(g[f"{case}_preset_json"])), data_roots=[golden_dir], reference_compat=True)
+    Lc._initialize_optimization_solver()
+    assert abs(Lc.objective(list(x)) - float(g[f"{case}_objective_norm"])) < 1e-8
+    grad_c = np.asarray(Lc.gradient(list(x)))
+    assert np.linalg.norm(grad_c - grad_ref) < 1e-7 * np.linalg.norm(grad_ref)
+
+
+def test_ddm_optimisation_with_exact_schur_complements():
+    """simulation_type "DDM" with schur_complement_computation "exact" (lattice_sim.py:1020-1054: dS/dr by central
+    differences of exact condensations, here pl_schur of one representative cell per radius set): objective and
+    gradient against central differences of the objective, and against the FEM-mode objective of the same lattice
+    (exact Schur complements ARE the condensed FEM model, so the two objectives agree to solver tolerance)."""
+    par = {"type": "unit_cell", "hybrid": False}
+    ddm = {"enable_preconditioner": False, "max_iterations": 5000, "schur_complement_computation": {"type": "exact"}}
+    p = _preset(optimization_parameters=par)
+    p["geometry"]["number_of_cells"] = {"x": 3, "y": 1, "z": 1}
+    pf = json.loads(json.dumps(p))
+    p["simulation_parameters"]["DDM"] = ddm
+    p["optimization_informations"]["simulation_type"] = "DDM"
+    L = LatticeOpti(p)
+    Lf = LatticeOpti(pf)
+    x = np.array([0.3, 0.55, 0.8])
+    obj = L.objective(list(x))
+    assert L.schur_gradients is not None and len(L.schur_gradients) == 3 and L.schur_complements.shape[0] == 3
+    objf = Lf.objective(list(x))
+    assert abs(L.denorm_objective - Lf.denorm_objective) < 1e-4 * abs(Lf.denorm_objective)
+    grad = np.asarray(L.gradient(list(x)))
+    gradf = np.asarray(Lf.gradient(list(x)))
+    fd = np.zeros(3)
+    h = 1e-4
+    for i in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        fd[i] = (L.objective(list(xp)) - L.objective(list(xm))) / (2 * h)
+    assert np.linalg.norm(grad - fd) < 2e-3 * np.linalg.norm(fd)
+    assert np.linalg.norm(grad - gradf) < 2e-3 * np.linalg.norm(gradf)
+    assert obj > 0 and objf > 0
