@@ -171,6 +171,7 @@ def main():
                     help="edge of the CPU-baseline sample (0 = skip); 36 = 1.1 M struts, ~10-15 s on one core")
     ap.add_argument("--splu-cells", type=int, default=5,
                     help="edge of the reference-faithful (sub-meshed + sparse LU) CPU sample (0 = skip); 5 = ~15 s")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the palette-off / graded-lattice K*p measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing through solve_FEM_FenicsX")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     ap.add_argument("--force-dist", action="store_true",
@@ -305,6 +306,49 @@ def main():
                            "note": "PMC counters cannot be read inside this run (rocprofv3 --pmc is a separate "
                                    "pass); this is the committed pass for this workload / kernel / palette setting"}
 
+    # The same kernel on lattices whose records do NOT repeat (graded / optimised radii: what every pl_update_radii loop
+    # runs): K*p then streams one 40-byte record per strut instead of 2-byte palette ids.  Measured on this lattice with
+    # the palette switched off, and on a graded copy (own radius per cell, > 10^5 distinct records) incl. a whole step.
+    streaming = None
+    if world == 1 and not args.no_streaming and args.kernel in (0, 3) and args.reorder:
+        streaming = {}
+        with _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
+                              reorder=args.reorder, precond=args.precond, palette=0, tile_nodes=args.tile_nodes,
+                              coarse_max_dofs=args.coarse_max_dofs) as d2:
+            d2.set_bc(fixed, None, f)
+            d2.assemble()
+            ms = d2.time_kernel(0, 50)
+            streaming["palette_off"] = {"ms": ms, "achieved": ab["spmv"] / (ms * 1e-3) / 1e9,
+                                        "frac": ab["spmv"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        i3 = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), axis=-1).reshape(-1, 3)
+        rad_cell = (args.radius * (0.8 + 0.4 * (0.5 + 0.5 * np.sin(0.113 * i3[:, 0] + 0.271 * i3[:, 1] + 0.419 * i3[:, 2]))))
+        glat = LA.generate((1, 1, 1), ncell, [args.geom], [args.radius], cell_radii_override=rad_cell.reshape(-1, 1))
+        gpen = LA.penalize(glat, _capi.lzone(glat.node_xyz, glat.beam_conn, glat.beam_radius))
+        with _capi.HipLattice(glat.node_xyz, glat.beam_conn, glat.beam_radius, gpen.seg_len, gpen.seg_nsub, E, NU,
+                              device=local_rank, spmv_kernel=args.kernel, reorder=args.reorder, precond=args.precond,
+                              palette=args.palette, tile_nodes=args.tile_nodes,
+                              coarse_max_dofs=args.coarse_max_dofs) as d3:
+            d3.set_bc(fixed, None, f)
+            d3.assemble()
+            gst = d3.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+            torch.cuda.synchronize()
+            t0g = time.perf_counter()
+            for _ in range(3):
+                d3.assemble()
+                gst = d3.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+            torch.cuda.synchronize()
+            dtg = (time.perf_counter() - t0g) / 3
+            ms = d3.time_kernel(0, 50)
+            streaming["graded"] = {"ms": ms, "achieved": ab["spmv"] / (ms * 1e-3) / 1e9,
+                                   "frac": ab["spmv"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "distinct_radii": int(len(np.unique(glat.beam_radius))),
+                                   "beams_per_s": glat.n_beams / dtg, "ms_per_step": dtg * 1e3,
+                                   "pcg_iterations": gst["iterations"],
+                                   "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
+        streaming.update({"bound": "hbm", "kernel": "K*p: k_spmv_tile<.., kRecCompact>", "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "algorithmic_bytes": ab["spmv"],
+                          "traffic_source": "profiles/r02_h_pmc_streaming.json (separate rocprofv3 --pmc passes)"})
+
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -332,6 +376,8 @@ def main():
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
     }
+    if streaming is not None:
+        out["roofline_streaming"] = streaming
     if ms_coll is not None:
         out["collectives_ms"] = ms_coll
     dev.close()

@@ -92,6 +92,10 @@ typedef struct {
                             reference's "direction norm" test (conjugate_gradient_solver.py:102-105; solve_DDM passes
                             1e-12), and report info = 2 when a step length fell below 1e-6 (:107-109).  These tests need
                             the host to see every iteration: use check_every = 1.  Jacobi / DDM paths */
+  int32_t compact_records; /* LDS-tile K*p without a palette (graded / optimised lattices): 0 or 1 = stream 40-byte records
+                              (the 5 stiffness scalars; the strut vector is recomputed from the node coordinates),
+                              -1 = stream the 64-byte records */
+  int32_t reserved2;
 } pl_opts_t;
 
 typedef struct {

@@ -86,6 +86,7 @@ struct pl_context {
   DevBuf<double> xyz, radius, seg_len;
   DevBuf<int32_t> conn, seg_nsub;
   DevBuf<pl::Record> rec;
+  DevBuf<double> rec5;   // compact 5-scalar copy of the records for the streaming K*p (tile kernel, no palette)
   // node -> strut incidence, sliced ELL
   DevBuf<int64_t> slice_ptr;
   DevBuf<int2> ent;
@@ -245,6 +246,9 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     if (c->pal_ready)
       pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
                            dot_dev, c->stream);
+    else if (c->rec5.p)
+      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr,
+                           masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream, c->xyz.p);
     else
       pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y, dot_dev,
                            c->stream);
@@ -268,6 +272,9 @@ int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double
   if (c->pal_ready)
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
                                 dot_dev, c->stream);
+  else if (c->rec5.p)
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr,
+                                masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream, c->xyz.p);
   else
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y,
                                 dot_dev, c->stream);
@@ -291,7 +298,7 @@ inline bool ref_cg(const pl_context *c) { return c->opt.mintol > 0.0 || c->opt.r
 
 int launch_records(pl_context *c) {
   hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
-                     c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mat, c->rec.p);
+                     c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mat, c->rec.p, c->rec5.p);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -1132,6 +1139,8 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(c->seg_len.alloc(B * 3));
   PL_HIPC(c->seg_nsub.alloc(B * 3));
   PL_HIPC(c->rec.alloc(B));
+  // opts.compact_records (default on): the tile K*p streams 40-byte records when no palette applies
+  if (o->compact_records >= 0 && (o->spmv_kernel == 0 || o->spmv_kernel == 3)) PL_HIPC(c->rec5.alloc((size_t)B * 5));
   PL_HIPC(hipMemcpy(c->xyz.p, xyz.data(), xyz.size() * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->conn.p, conn.data(), conn.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->radius.p, radius.data(), B * sizeof(double), hipMemcpyHostToDevice));

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_build_records(int64_t B, const doubl
                                                           const double *__restrict__ radius,
                                                           const double *__restrict__ seg_len,
                                                           const int32_t *__restrict__ seg_nsub, Material m,
-                                                          Record *__restrict__ rec) {
+                                                          Record *__restrict__ rec, double *__restrict__ rec5) {
   const int64_t b = (int64_t)xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (b >= B) return;
   const int ia = conn[2 * b], ib = conn[2 * b + 1];
@@ -106,7 +106,12 @@ __global__ __launch_bounds__(kBlock) void k_build_records(int64_t B, const doubl
   const double len[3] = {seg_len[3 * b], seg_len[3 * b + 1], seg_len[3 * b + 2]};
   const int ns[3] = {seg_nsub[3 * b], seg_nsub[3 * b + 1], seg_nsub[3 * b + 2]};
   const Flex f = strut_flexibility(radius[b], len, ns, m);
-  rec[b] = make_record(scalars_from_flex(f), d);
+  const Record r = make_record(scalars_from_flex(f), d);
+  rec[b] = r;
+  if (rec5) {   // compact copy for the streaming K*p (pl_tile.h, kRecCompact)
+    double *q = rec5 + 5 * b;
+    q[0] = r.a; q[1] = r.c; q[2] = r.e1; q[3] = r.e2; q[4] = r.e3;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

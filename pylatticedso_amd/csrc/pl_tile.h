@@ -204,13 +204,32 @@ __device__ __forceinline__ void lds_add6(double *dst, int stride, V3 f, V3 m) {
   unsafeAtomicAdd(dst + 5 * stride, m.z);
 }
 
-// PAL: the record comes from the palette table through a 2-byte id (pl_palette.h) instead of rec[b].
-template <bool PAL, typename VT>
+// Where a strut's record comes from (template parameter REC of the tile kernel):
+//   kRecAoS      rec[b], 64 B per strut;
+//   kRecPalette  the palette table through a 2-byte id (pl_palette.h): periodic lattices, the table stays in L2;
+//   kRecCompact  5 stiffness scalars per strut (40 B) and d = x_B - x_A recomputed from the node coordinates, which
+//                are gathered like the x rows and mostly hit L2: the streaming path (graded / optimised lattices) is
+//                bound by HBM bytes, and this takes a third off the record stream.
+enum { kRecAoS = 0, kRecPalette = 1, kRecCompact = 2 };
+struct __attribute__((aligned(8))) Rec5 {
+  double a, c, e1, e2, e3;
+};
+
+template <int REC, typename VT>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
-                                           const VT *__restrict__ x, double *ys, int stride) {
+                                           const double *__restrict__ xyz, const VT *__restrict__ x, double *ys,
+                                           int stride) {
   const int2 c = conn2[b];
-  const Record r = PAL ? load_record(rec, pal[b]) : load_record(rec, b);
+  Record r;
+  if (REC == kRecCompact) {
+    const Rec5 q = reinterpret_cast<const Rec5 *>(rec)[b];
+    const double *pa = xyz + 3 * (int64_t)c.x, *pb = xyz + 3 * (int64_t)c.y;
+    r.a = q.a; r.c = q.c; r.e1 = q.e1; r.e2 = q.e2; r.e3 = q.e3;
+    r.dx = pb[0] - pa[0]; r.dy = pb[1] - pa[1]; r.dz = pb[2] - pa[2];
+  } else {
+    r = (REC == kRecPalette) ? load_record(rec, pal[b]) : load_record(rec, b);
+  }
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
@@ -229,13 +248,14 @@ constexpr int kTileBlock = 512;
 // VT = storage type of x and y (double, or float for the fp32 solver modes: the strut forces are still evaluated
 // and accumulated in fp64 - the forces on a node nearly cancel for the smooth fields a solve is made of, so rounding
 // them to fp32 before the sum would cost cond(K) * 6e-8, rounding the stored result costs 6e-8).
-template <bool MASK, bool DOT, bool PAL, typename VT>
+template <bool MASK, bool DOT, int REC, typename VT>
 __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ home_ptr,
                                                       const int64_t *__restrict__ foreign_ptr,
                                                       const int32_t *__restrict__ foreign_idx,
                                                       const int2 *__restrict__ conn2, const Record *__restrict__ rec,
                                                       const uint16_t *__restrict__ pal,
+                                                      const double *__restrict__ xyz,
                                                       const uint8_t *__restrict__ fixedbits,
                                                       const VT *__restrict__ x, VT *__restrict__ y,
                                                       double *__restrict__ dot_out, int stride) {
@@ -249,11 +269,11 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 4
   for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock)
-    tile_strut<PAL, VT>(b, n0, n1, conn2, rec, pal, x, ys, stride);
+    tile_strut<REC, VT>(b, n0, n1, conn2, rec, pal, xyz, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 4
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
-    tile_strut<PAL, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, x, ys, stride);
+    tile_strut<REC, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, xyz, x, ys, stride);
   __syncthreads();
   double acc = 0.0;
   const int64_t pair0 = 3 * (int64_t)n0;
@@ -282,28 +302,30 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   }
 }
 
-// pal != nullptr: `rec` is the palette table and pal[b] the strut's entry.
+// pal != nullptr: `rec` is the palette table and pal[b] the strut's entry; xyz != nullptr: `rec` is the compact
+// 5-scalar table (Rec5) and the strut vectors come from the node coordinates.
 template <typename VT>
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
-                             const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s) {
+                             const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s,
+                             const double *xyz = nullptr) {
   const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
 #define PL_T(M, D, P)                                                                                          \
   hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
-                     plan.foreign_idx.p, conn2, rec, pal, fixedbits, x, y, dot_dev, stride)
-  if (pal) {
-    if (fixedbits && dot_dev) PL_T(true, true, true);
-    else if (fixedbits) PL_T(true, false, true);
-    else if (dot_dev) PL_T(false, true, true);
-    else PL_T(false, false, true);
-  } else {
-    if (fixedbits && dot_dev) PL_T(true, true, false);
-    else if (fixedbits) PL_T(true, false, false);
-    else if (dot_dev) PL_T(false, true, false);
-    else PL_T(false, false, false);
-  }
+                     plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride)
+#define PL_TT(P)                                           \
+  do {                                                     \
+    if (fixedbits && dot_dev) PL_T(true, true, P);         \
+    else if (fixedbits) PL_T(true, false, P);              \
+    else if (dot_dev) PL_T(false, true, P);                \
+    else PL_T(false, false, P);                            \
+  } while (0)
+  if (pal) PL_TT(kRecPalette);
+  else if (xyz) PL_TT(kRecCompact);
+  else PL_TT(kRecAoS);
+#undef PL_TT
 #undef PL_T
 }
 
