@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--no-streaming", action="store_true", help="skip the palette-off / graded-lattice K*p measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing through solve_FEM_FenicsX")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
+    ap.add_argument("--interface-allreduce", action="store_true",
+                    help="multi-GPU: sum the interface rows with one all-reduce over all planes instead of the "
+                         "neighbour exchange")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (slab build, RCCL communicator) even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -242,7 +245,10 @@ def main():
         ok, gid, nsg = PT.global_interface_ids(keys, rank)
         uid = [_capi.HipLattice.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        dev.dist_init(rank, world, uid[0], slab.iface_local[ok], gid, nsg)
+        # interface rows: neighbour exchange (grouped ncclSend/ncclRecv with the two adjacent slabs) unless the
+        # all-planes all-reduce is asked for; a single-rank rehearsal has no neighbours
+        peers = None if (args.interface_allreduce or world == 1) else slab.iface_peer[ok]
+        dev.dist_init(rank, world, uid[0], slab.iface_local[ok], gid, nsg, shared_peer=peers)
         # global number of loaded nodes / struts (shared nodes counted once: they belong to the lower slab)
         lower_plane = np.zeros(len(xyz), bool)
         if rank > 0:
@@ -358,7 +364,10 @@ def main():
         "config": {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {args.geom} r={args.radius} cantilever "
                                f"(BASELINE.json configs[1] per GPU)",
                    "struts": n_beams_total, "struts_per_gpu": len(conn), "nodes_per_gpu": len(xyz),
-                   "partition": "single GPU" if world == 1 else f"{world} y-slabs, RCCL interface all-reduce",
+                   "partition": "single GPU" if world == 1 else
+                   f"{world} y-slabs, RCCL " + ("interface all-reduce" if args.interface_allreduce else
+                                                "neighbour exchange of interface rows (ncclSend/ncclRecv)") +
+                   " + fused scalar all-reduces",
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"], "precision": args.precision,
                    "inner_solves": st.get("restarts", 0.0),

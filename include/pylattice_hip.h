@@ -249,6 +249,14 @@ int pl_dist_unique_id(void *id_out);
 int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const int32_t *shared_local,
                  const int32_t *shared_global, int32_t n_shared, int32_t n_shared_global);
 
+/* Neighbour halo exchange ("sum of interface-node partial forces with the two neighbouring
+ * slabs"): shared_peer[i] = the rank that holds the other copy of shared entry i of pl_dist_init (a node shared with
+ * several ranks is listed once per peer there).  After this call the interface rows of every K*x travel by grouped
+ * ncclSend / ncclRecv between neighbours - each rank moves its own planes only, concurrently - instead of the all-reduce
+ * over all planes; the dot-product slots take a small all-reduce of their own.  Both ranks of a pair order their
+ * common nodes by global interface id, so no further handshake is needed.  Collective: every rank must call it. */
+int pl_dist_set_peers(pl_handle h, const int32_t *shared_peer /*[n_shared]*/);
+
 #ifdef __cplusplus
 }
 #endif

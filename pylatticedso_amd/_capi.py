@@ -22,7 +22,7 @@ EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_lzone", "pl_cre
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
-           "pl_dist_unique_id", "pl_dist_init"]
+           "pl_dist_unique_id", "pl_dist_init", "pl_dist_set_peers"]
 
 
 class PlMesh(C.Structure):
@@ -82,7 +82,7 @@ def load_library(path: str | None = None):
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V], "pl_node_mod": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
            "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
-           "pl_dist_init": [V, I32, I32, V, V, V, I32, I32]}
+           "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
     _lib = lib
@@ -342,12 +342,19 @@ class HipLattice:
         _check(lib, lib.pl_dist_unique_id(buf))
         return buf.raw
 
-    def dist_init(self, rank, world, unique_id: bytes, shared_local, shared_global, n_shared_global):
+    def dist_init(self, rank, world, unique_id: bytes, shared_local, shared_global, n_shared_global, shared_peer=None):
+        """Attach the handle to the RCCL communicator; ``shared_peer`` (rank on the other side of every shared entry)
+        switches the interface rows from the all-planes all-reduce to the neighbour exchange (pl_dist_set_peers)."""
         sl = np.ascontiguousarray(shared_local, dtype=np.int32)
         sg = np.ascontiguousarray(shared_global, dtype=np.int32)
         buf = C.create_string_buffer(unique_id, len(unique_id))
         _check(self._lib, self._lib.pl_dist_init(self._h, int(rank), int(world), buf, _ptr(sl), _ptr(sg),
                                                  int(len(sl)), int(n_shared_global)))
+        if shared_peer is not None:
+            sp = np.ascontiguousarray(shared_peer, dtype=np.int32)
+            if sp.shape != sl.shape:
+                raise ValueError("one peer rank per shared entry expected")
+            _check(self._lib, self._lib.pl_dist_set_peers(self._h, _ptr(sp)))
 
 
 # the reference wraps every hot-path method in @timing.category(..) @timing.timeit (SURVEY.md section 5); here the

@@ -1940,4 +1940,14 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   return PL_OK;
 }
 
+int pl_dist_set_peers(pl_handle h, const int32_t *shared_peer) {
+  if (!valid(h) || !shared_peer) return fail(PL_ERR_ARG, "pl_dist_set_peers: null argument");
+  if (!h->dist.active) return fail(PL_ERR_STATE, "pl_dist_set_peers: call pl_dist_init first");
+  PL_HIP(hipSetDevice(h->opt.device));
+  int rc = pl::dist_set_peers(h->dist, shared_peer);
+  if (rc) return fail(rc == 2 ? PL_ERR_ARG : PL_ERR_HIP, "pl_dist_set_peers: setup failed (" + std::to_string(rc) + ")");
+  h->assembled = false;
+  return PL_OK;
+}
+
 }  // extern "C"

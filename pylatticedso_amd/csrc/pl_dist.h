@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "pl_kernels.h"
@@ -26,10 +28,26 @@ struct DBuf {
   }
 };
 
+// One neighbouring rank of a slab partition: the nodes shared with it (both sides list them in the order of their
+// global interface ids) and the staging buffers of the point-to-point exchange.
+struct Peer {
+  int rank = -1;
+  int32_t n = 0;
+  DBuf<int32_t> loc;
+  DBuf<double> send, recv;
+};
+
 struct Dist {
   bool active = false;
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
+  // interface rows by grouped ncclSend / ncclRecv with the (at most two) neighbouring slabs instead of an all-reduce
+  // over ALL interface planes (pl_dist_set_peers): at N ranks the all-reduce carries N - 1 planes to everyone, each
+  // rank needs two
+  bool p2p = false;
+  std::vector<Peer *> peers;
+  std::vector<int32_t> h_loc, h_glob;
+  ~Dist() { for (Peer *q : peers) delete q; }
   int32_t n_shared = 0, n_shared_global = 0;
   DBuf<int32_t> local_idx, global_idx;   // [n_shared]
   DBuf<int32_t> slot2loc;                // [n_shared_global] local node of a global interface slot, -1 if not here
@@ -82,6 +100,44 @@ inline int dist_unique_id(void *out) {
   return 0;
 }
 
+template <typename VT>
+__global__ void k_pack_rows(int32_t n, const int32_t *__restrict__ loc, const VT *__restrict__ y,
+                            double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)n * 6) out[i] = (double)y[6 * (int64_t)loc[i / 6] + i % 6];
+}
+template <typename VT>
+__global__ void k_add_rows(int32_t n, const int32_t *__restrict__ loc, const double *__restrict__ in,
+                           VT *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)n * 6) {
+    VT *q = y + 6 * (int64_t)loc[i / 6] + i % 6;
+    *q = (VT)((double)*q + in[i]);       // mine + theirs on both sides: the same bits on both ranks
+  }
+}
+
+// Neighbour exchange: every rank sends its partial rows of each shared plane to the rank on the other side and adds
+// what it receives.  All sends and receives of one call form ONE RCCL group (they progress concurrently).
+template <typename VT>
+inline int dist_exchange_p2p(Dist &d, VT *y, hipStream_t s) {
+  for (Peer *q : d.peers)
+    if (q->n > 0)
+      hipLaunchKernelGGL(k_pack_rows<VT>, dim3((unsigned)((q->n * 6 + 255) / 256)), dim3(256), 0, s, q->n, q->loc.p, y,
+                         q->send.p);
+  if (ncclGroupStart() != ncclSuccess) return 2;
+  for (Peer *q : d.peers)
+    if (q->n > 0) {
+      if (ncclSend(q->send.p, (size_t)q->n * 6, ncclDouble, q->rank, d.comm, s) != ncclSuccess) return 2;
+      if (ncclRecv(q->recv.p, (size_t)q->n * 6, ncclDouble, q->rank, d.comm, s) != ncclSuccess) return 2;
+    }
+  if (ncclGroupEnd() != ncclSuccess) return 2;
+  for (Peer *q : d.peers)
+    if (q->n > 0)
+      hipLaunchKernelGGL(k_add_rows<VT>, dim3((unsigned)((q->n * 6 + 255) / 256)), dim3(256), 0, s, q->n, q->loc.p,
+                         (const double *)q->recv.p, y);
+  return 0;
+}
+
 // y[shared] <- sum over ranks of y[shared]; optionally `nscal` device scalars (e.g. the 32 slots of a LOCAL partial
 // dot product) ride in the tail of the same message and are summed over ranks too: ONE collective, one kernel
 // before it and one after.
@@ -89,6 +145,12 @@ inline int dist_unique_id(void *out) {
 template <typename VT>
 inline int dist_sum_shared(Dist &d, VT *y, hipStream_t s, double *scal = nullptr, int nscal = 0) {
   if (!d.active) return 0;
+  if (d.p2p) {   // rows with the neighbours; the scalar tail needs a (tiny) all-reduce of its own
+    if (dist_exchange_p2p<VT>(d, y, s)) return 2;
+    if (scal && nscal > 0 && ncclAllReduce(scal, scal, (size_t)nscal, ncclDouble, ncclSum, d.comm, s) != ncclSuccess)
+      return 2;
+    return 0;
+  }
   const int64_t nrow = (int64_t)d.n_shared_global * 6;
   if (!scal) nscal = 0;
   const int64_t n = nrow + nscal;
@@ -131,6 +193,8 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
     if (d.slot2loc.alloc(s2l.size()) != hipSuccess) return 2;
     if (hipMemcpy(d.slot2loc.p, s2l.data(), s2l.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return 3;
   }
+  d.h_loc.assign(loc, loc + n_shared);
+  d.h_glob.assign(glob, glob + n_shared);
   d.active = true;
   // multiplicity = all-reduce of ones on the shared nodes; weight = 1/multiplicity
   const int64_t n6 = N * 6;
@@ -138,6 +202,38 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
   if (dist_sum_shared(d, d.weight.p, s)) return 4;
   hipLaunchKernelGGL(k_recip, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, s, n6, d.weight.p);
   if (hipStreamSynchronize(s) != hipSuccess) return 5;
+  return 0;
+}
+
+// peer[i] = rank on the other side of shared entry i (as passed to dist_init).  Both ranks of a pair order the common
+// nodes by global interface id, so send and receive buffers line up without any further exchange.
+inline int dist_set_peers(Dist &d, const int32_t *peer) {
+  if (!d.active) return 1;
+  for (Peer *q : d.peers) delete q;
+  d.peers.clear();
+  std::vector<int32_t> ranks(peer, peer + d.n_shared);
+  std::sort(ranks.begin(), ranks.end());
+  ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
+  for (int32_t pr : ranks) {
+    if (pr < 0 || pr >= d.world) return 2;
+    std::vector<std::pair<int32_t, int32_t>> rows;   // (global id, local node)
+    for (int32_t i = 0; i < d.n_shared; ++i)
+      if (peer[i] == pr) rows.push_back({d.h_glob[i], d.h_loc[i]});
+    std::sort(rows.begin(), rows.end());
+    std::vector<int32_t> loc(rows.size());
+    for (size_t k = 0; k < rows.size(); ++k) loc[k] = rows[k].second;
+    Peer *q = new Peer();
+    q->rank = pr;
+    q->n = (int32_t)rows.size();
+    d.peers.push_back(q);
+    if (q->loc.alloc(std::max<size_t>(1, loc.size())) != hipSuccess) return 3;
+    if (q->send.alloc(std::max<size_t>(1, loc.size() * 6)) != hipSuccess) return 3;
+    if (q->recv.alloc(std::max<size_t>(1, loc.size() * 6)) != hipSuccess) return 3;
+    if (!loc.empty() &&
+        hipMemcpy(q->loc.p, loc.data(), loc.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+      return 3;
+  }
+  d.p2p = true;
   return 0;
 }
 

@@ -37,6 +37,7 @@ class Slab:
     seg_nsub: np.ndarray          # (b,3)
     iface_local: np.ndarray       # local ids of nodes lying on an interface plane of this slab
     iface_key: np.ndarray         # (m,4) int64 key (plane, qa, qb, 0) identifying the node across ranks
+    iface_peer: np.ndarray = None  # (m,) rank of the slab on the other side of the node's plane (neighbour exchange)
     n_owned_beams_global: int = 0
 
 
@@ -69,22 +70,24 @@ def build_slab(cell_size, num_cells, geom_types, radii, rank, world, axis=1, gra
     planes = []
     cpos, ccoord, csize = lat.cell_pos[:, axis], lat.cell_coord[:, axis], lat.cell_size[:, axis]
     if rank > 0:
-        planes.append((lo, float(ccoord[cpos == lo][0])))
+        planes.append((lo, float(ccoord[cpos == lo][0]), rank - 1))
     if rank < world - 1:
         c = np.flatnonzero(cpos == hi - 1)[0]
-        planes.append((hi, float(ccoord[c] + csize[c])))
+        planes.append((hi, float(ccoord[c] + csize[c]), rank + 1))
     others = [a for a in range(3) if a != axis]
-    loc, keys = [], []
-    for pid, coord in planes:
+    loc, keys, peers = [], [], []
+    for pid, coord, peer in planes:
         sel = np.flatnonzero(np.abs(xyz[:, axis] - coord) <= 1e-9)
         q = np.round(xyz[sel][:, others] * 1e6).astype(np.int64)
         loc.append(sel)
         keys.append(np.c_[np.full(len(sel), pid, np.int64), q, np.zeros(len(sel), np.int64)])
+        peers.append(np.full(len(sel), peer, np.int32))
     iface_local = np.concatenate(loc) if loc else np.zeros(0, np.int64)
     iface_key = np.concatenate(keys) if keys else np.zeros((0, 4), np.int64)
+    iface_peer = np.concatenate(peers) if peers else np.zeros(0, np.int32)
     return Slab(rank=rank, world=world, axis=axis, layers=(lo, hi), node_xyz=xyz, beam_conn=sub.beam_conn,
                 beam_radius=sub.beam_radius, seg_len=pen.seg_len, seg_nsub=pen.seg_nsub,
-                iface_local=iface_local, iface_key=iface_key)
+                iface_local=iface_local, iface_key=iface_key, iface_peer=iface_peer)
 
 
 def global_interface_ids(all_keys: list[np.ndarray], rank: int):

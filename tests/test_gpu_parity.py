@@ -296,6 +296,34 @@ def test_ddm_golden_cross_check(golden_dir):
     assert _rel(xsol, g["xsol"]) < 5e-3
 
 
+def test_neighbour_exchange_plumbing_with_a_self_peer(golden_dir):
+    """pl_dist_set_peers on the one GPU of the test box: a single-rank communicator whose only "neighbour" is the rank
+    itself, so every grouped ncclSend / ncclRecv pair delivers the rank's own packed rows and the shared rows of K*x
+    come back doubled - which pins the pack -> send/recv -> add chain (order by global interface id, fp64 and fp32
+    row types) without a second GPU.  The two-rank arithmetic itself is covered on CPU by tests/test_partition_gloo.py."""
+    _, L = _sim(golden_dir, "bcc_4x4x4")
+    lat = L.lattice
+    x = np.random.default_rng(1).standard_normal(6 * lat.n_nodes)
+    shared = np.flatnonzero(lat.node_xyz[:, 1] == 2.0)
+    rng = np.random.default_rng(5)
+    gid = rng.permutation(len(shared))                           # global ids in an order unrelated to the local one
+    with _device(L) as ref:
+        ref.assemble()
+        y0 = ref.spmv(x)
+    with _device(L) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, gid, len(shared),
+                      shared_peer=np.zeros(len(shared), np.int32))
+        dev.assemble()
+        y1 = dev.spmv(x)
+    expect = y0.copy()
+    expect[shared] *= 2.0
+    assert _rel(y1, expect) < 1e-14
+    with _device(L) as dev:
+        with pytest.raises(_capi.PlError):
+            dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, gid, len(shared),
+                          shared_peer=np.full(len(shared), 3, np.int32))          # peer outside the communicator
+
+
 def test_rccl_path_with_single_rank_communicator(golden_dir):
     """The multi-GPU code path (RCCL communicator, interface pack / all-reduce / unpack, weighted dot products)
     driven with world = 1 on the one GPU of the test box: results must equal the plain path."""

@@ -55,6 +55,30 @@ def _worker(rank, world, port, case, out):
     w = sum_shared(np.ones((n, 6)))
     w = 1.0 / w
 
+    # the neighbour exchange of libpylattice_hip (pl_dist_set_peers): per peer the common nodes in the order of their
+    # global interface ids, partial rows sent to the rank on the other side, received rows added - must give exactly
+    # what the all-reduce over all planes gives
+    peer = slab.iface_peer[ok]
+
+    def sum_shared_p2p(y):
+        y = y.copy()
+        reqs, recv = [], {}
+        for pr in np.unique(peer):
+            sel = np.flatnonzero(peer == pr)
+            rows = loc[sel][np.argsort(gid[sel], kind="stable")]
+            recv[int(pr)] = (rows, torch.zeros(len(rows), 6, dtype=torch.float64))
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(y[rows])), dst=int(pr)))
+            reqs.append(dist.irecv(recv[int(pr)][1], src=int(pr)))
+        for q in reqs:
+            q.wait()
+        for rows, buf in recv.values():
+            y[rows] += buf.numpy()
+        return y
+
+    probe = np.random.default_rng(rank).standard_normal((n, 6))
+    assert np.array_equal(sum_shared_p2p(probe), sum_shared(probe.copy()))
+    assert set(np.unique(peer)) <= {rank - 1, rank + 1} and len(peer) == len(loc)
+
     def wdot(a, b):
         t = torch.tensor([float((w * a * b).sum())], dtype=torch.float64)
         dist.all_reduce(t)
