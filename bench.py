@@ -389,6 +389,10 @@ def main():
         out["roofline_streaming"] = streaming
     if ms_coll is not None:
         out["collectives_ms"] = ms_coll
+        # one RCCL per process: torch's bundled librccl.so and /opt/rocm's share the soname, the loader maps the first
+        with open("/proc/self/maps") as fh:
+            out["rccl_libraries_mapped"] = sorted({ln.split()[-1] for ln in fh if "librccl" in ln})
+        out["process_group_backend"] = "gloo (host bootstrap only); data path: RCCL communicator inside libpylattice_hip"
     dev.close()
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol, args.splu_cells)
