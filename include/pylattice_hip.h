@@ -249,6 +249,37 @@ int pl_dist_unique_id(void *id_out);
 int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const int32_t *shared_local,
                  const int32_t *shared_global, int32_t n_shared, int32_t n_shared_global);
 
+/* ---- host-side lattice generation (no GPU involved) -------------------------------------------------------- */
+/* Lattice.generate_lattice + Cell.generate_beams + define_beam_node_index (lattice.py:421-483,665-698,
+ * cell.py:293-382) on flat arrays, multi-threaded: for every cell c and template strut s the two end points
+ * tmpl[6s + 3e + k] * cell_size[3c + k] + cell_coord[3c + k]; nodes and struts de-duplicated through coordinates
+ * rounded to 9 decimals (first creator wins); nodes numbered in (x, y, z) order, struts in (lower end, upper end) order.
+ * cell_radii[c * n_geom + g] is the radius the struts of geometry g get in cell c (gradient already applied),
+ * tmpl_type[s] the geometry of template strut s.  The result lives in a library-owned object: read the sizes from
+ * *info, fetch into caller arrays of those sizes (any pointer may be NULL), free.  created_nodes[2 (c n_tmpl + s) + e] /
+ * created_beam[c n_tmpl + s] give node and strut of every CREATED strut end (the hybrid-collision pass needs them).
+ * Returns PL_ERR_STATE when the lattice is too irregular for the direct-address node table (caller falls back). */
+typedef struct pl_lattice pl_lattice;
+typedef struct {
+  int64_t n_nodes, n_beams, n_cell_beam, n_cell_node, n_created;
+} pl_lattice_info_t;
+int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double *cell_size, const double *cell_radii,
+                        int32_t n_geom, int32_t n_tmpl, const double *tmpl, const int32_t *tmpl_type,
+                        pl_lattice **out, pl_lattice_info_t *info);
+int pl_lattice_fetch(const pl_lattice *L, double *node_xyz, int32_t *beam_conn, double *beam_radius, int32_t *beam_type,
+                     int32_t *beam_cell0, int64_t *cell_beam_ptr /*[n_cells+1]*/, int64_t *cell_beam_idx,
+                     int64_t *cell_node_ptr /*[n_cells+1]*/, int64_t *cell_node_idx, int32_t *created_nodes,
+                     int32_t *created_beam);
+void pl_lattice_free(pl_lattice *L);
+
+/* LatticeSim.set_penalized_beams (lattice_sim.py:245-308) on arrays: every strut becomes [pen(L_zone at point1) | middle
+ * | pen(L_zone at point2)]; new points at end + (other - end) / round(length, 4) * L_zone (beam.py:135,300-312).  Outputs
+ * per strut: the three geometric segment lengths (0 = absent), gmsh's element count int(len / mesh_size + 0.99) per
+ * segment (lattice_generation.py:50-64) and the two penalisation points (NaN where absent).  lzone = NULL: no
+ * penalisation (one segment per strut).  Host code, multi-threaded. */
+int pl_penalize(int64_t n_beams, const double *node_xyz, const int32_t *beam_conn, const double *lzone /*[2B] or NULL*/,
+                double mesh_size, double *seg_len /*[3B]*/, int32_t *seg_nsub /*[3B]*/, double *pen_xyz /*[6B]*/);
+
 /* Neighbour halo exchange ("sum of interface-node partial forces with the two neighbouring
  * slabs"): shared_peer[i] = the rank that holds the other copy of shared entry i of pl_dist_init (a node shared with
  * several ranks is listed once per peer there).  After this call the interface rows of every K*x travel by grouped

@@ -22,7 +22,8 @@ EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_lzone", "pl_cre
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
-           "pl_dist_unique_id", "pl_dist_init", "pl_dist_set_peers"]
+           "pl_dist_unique_id", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
+           "pl_lattice_free", "pl_penalize"]
 
 
 class PlMesh(C.Structure):
@@ -73,6 +74,7 @@ def load_library(path: str | None = None):
     lib.pl_version.restype = C.c_char_p
     lib.pl_destroy.restype = None
     lib.pl_default_opts.restype = None
+    lib.pl_lattice_free.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {"pl_default_opts": [V], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
            "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
@@ -82,7 +84,9 @@ def load_library(path: str | None = None):
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V], "pl_node_mod": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
            "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V],
-           "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V]}
+           "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V],
+           "pl_generate_lattice": [I64, V, V, V, I32, I32, V, V, V, V], "pl_lattice_fetch": [V] * 12,
+           "pl_lattice_free": [V], "pl_penalize": [I64, V, V, V, D, V, V, V]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
     _lib = lib
@@ -127,6 +131,58 @@ def debug_spd_solve(A, b, device=0, fp32_factor=False):
     q = C.c_double()
     _check(lib, lib.pl_debug_spd_solve(device, len(b), _ptr(A), _ptr(b), _ptr(x), C.byref(q), int(bool(fp32_factor))))
     return x, q.value
+
+
+class PlLatticeInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_beams", C.c_int64), ("n_cell_beam", C.c_int64), ("n_cell_node", C.c_int64),
+                ("n_created", C.c_int64)]
+
+
+def generate_lattice(cell_coord, cell_size, cell_radii, tmpl, tmpl_type, want_created=False):
+    """pl_generate_lattice: the multi-threaded host generator.  Returns a dict of arrays, or None when the library
+    declines (lattice too irregular for its node table) and the numpy path has to be taken."""
+    lib = load_library()
+    cc, cs = _f64(cell_coord).reshape(-1, 3), _f64(cell_size).reshape(-1, 3)
+    cr = _f64(cell_radii).reshape(len(cc), -1)
+    tm = _f64(tmpl).reshape(-1, 6)
+    tt = np.ascontiguousarray(tmpl_type, dtype=np.int32)
+    h = C.c_void_p()
+    info = PlLatticeInfo()
+    rc = lib.pl_generate_lattice(len(cc), _ptr(cc), _ptr(cs), _ptr(cr), cr.shape[1], len(tm), _ptr(tm), _ptr(tt),
+                                 C.byref(h), C.byref(info))
+    if rc == PL_ERR_STATE:
+        return None
+    if rc != PL_OK:
+        raise PlError(rc, "pl_generate_lattice: bad argument")
+    try:
+        Cn = len(cc)
+        out = {"node_xyz": np.empty((info.n_nodes, 3)), "beam_conn": np.empty((info.n_beams, 2), np.int32),
+               "beam_radius": np.empty(info.n_beams), "beam_type": np.empty(info.n_beams, np.int32),
+               "beam_cell0": np.empty(info.n_beams, np.int32), "cell_beam_ptr": np.empty(Cn + 1, np.int64),
+               "cell_beam_idx": np.empty(info.n_cell_beam, np.int64), "cell_node_ptr": np.empty(Cn + 1, np.int64),
+               "cell_node_idx": np.empty(info.n_cell_node, np.int64)}
+        if want_created:
+            out["pid"] = np.empty((Cn, len(tm), 2), np.int32)
+            out["bid"] = np.empty(Cn * len(tm), np.int32)
+        order = ["node_xyz", "beam_conn", "beam_radius", "beam_type", "beam_cell0", "cell_beam_ptr", "cell_beam_idx",
+                 "cell_node_ptr", "cell_node_idx", "pid", "bid"]
+        lib.pl_lattice_fetch(h, *[_ptr(out.get(k)) for k in order])
+    finally:
+        lib.pl_lattice_free(h)
+    return out
+
+
+def penalize_arrays(node_xyz, beam_conn, lzone, mesh_size):
+    """pl_penalize: (seg_len (B,3), seg_nsub (B,3) i32, pen_xyz (B,2,3))."""
+    lib = load_library()
+    xyz = _f64(node_xyz).reshape(-1, 3)
+    conn = np.ascontiguousarray(beam_conn, dtype=np.int32).reshape(-1, 2)
+    lz = None if lzone is None else _f64(lzone, 2 * len(conn))
+    B = len(conn)
+    seg_len, seg_nsub, pen = np.empty((B, 3)), np.empty((B, 3), np.int32), np.empty((B, 2, 3))
+    _check(lib, lib.pl_penalize(B, _ptr(xyz), _ptr(conn), _ptr(lz), float(mesh_size), _ptr(seg_len), _ptr(seg_nsub),
+                                _ptr(pen)))
+    return seg_len, seg_nsub, pen
 
 
 class HipLattice:

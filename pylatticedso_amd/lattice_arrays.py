@@ -98,12 +98,16 @@ def _csr_from_pairs(rows, cols, nrows):
 
 
 def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim=None, erased_blocks=None,
-             cell_radii_override=None, cell_range=None) -> LatticeArrays:
-    """Vectorised Lattice.generate_lattice: cells in i,j,k order, struts of every geometry, nodes and struts
+             cell_radii_override=None, cell_range=None, backend="auto") -> LatticeArrays:
+    """Lattice.generate_lattice on arrays: cells in i,j,k order, struts of every geometry, nodes and struts
     de-duplicated through coordinates rounded to 9 decimals (first creator wins, cell.py:312-368).
 
     ``cell_range`` = ((i0,i1),(j0,j1),(k0,k1)) restricts generation to a box of cells of the SAME global lattice
-    (coordinates, gradients and creation order are those of the full lattice) - used by the slab partition."""
+    (coordinates, gradients and creation order are those of the full lattice) - used by the slab partition.
+
+    ``backend``: "native" = the multi-threaded generator of libpylattice_hip (pl_generate_lattice, host code),
+    "numpy" = the vectorised restatement below, "auto" = native when the library is there and accepts the lattice.
+    Both give the same arrays bit for bit (tests/test_host_lattice.py)."""
     nx, ny, nz = num_cells
     csx, csy, csz = cell_size
     if grad_dim is None:
@@ -148,6 +152,39 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     tmpl = np.concatenate(tmpl)
     ttype = np.concatenate(ttype)
     nb = len(tmpl)
+
+    native = None
+    if backend in ("auto", "native"):
+        try:
+            from ._capi import generate_lattice
+            native = generate_lattice(coord, size, cell_radii, tmpl, ttype, want_created=len(geom_types) > 1)
+        except (OSError, FileNotFoundError, AttributeError):
+            native = None
+        if native is None and backend == "native":
+            raise RuntimeError("libpylattice_hip's host generator is not available for this lattice")
+    if native is not None:
+        node_xyz, beam_conn = native["node_xyz"], native["beam_conn"]
+        beam_radius, beam_type, beam_cell0 = native["beam_radius"], native["beam_type"], native["beam_cell0"]
+        cb_ptr, cb_idx = native["cell_beam_ptr"], native["cell_beam_idx"]
+        cn_ptr, cn_idx = native["cell_node_ptr"], native["cell_node_idx"]
+        if len(geom_types) > 1:                                  # lattice.py:482-483
+            cell_of = np.repeat(np.arange(C), nb)
+            split = _hybrid_collision_split(node_xyz, tmpl, native["pid"].astype(np.int64), native["bid"].astype(np.int64),
+                                            beam_conn, beam_radius, beam_type, beam_cell0)
+            if split is not None:
+                beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx = split
+                pair_beam = native["bid"].astype(np.int64)
+                cnt = np.diff(new_of_old_ptr)[pair_beam]
+                start = new_of_old_ptr[pair_beam]
+                pair_cell = np.repeat(cell_of, cnt)
+                within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+                cb_ptr, cb_idx = _csr_from_pairs(pair_cell, new_of_old_idx[np.repeat(start, cnt) + within], C)
+        bbox = np.array([node_xyz[:, 0].min(), node_xyz[:, 0].max(), node_xyz[:, 1].min(), node_xyz[:, 1].max(),
+                         node_xyz[:, 2].min(), node_xyz[:, 2].max()])
+        return LatticeArrays(node_xyz=node_xyz, beam_conn=beam_conn, beam_radius=beam_radius, beam_type=beam_type,
+                             beam_cell0=beam_cell0, cell_pos=pos, cell_coord=coord, cell_size=size,
+                             cell_radii=cell_radii, cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr,
+                             cell_node_idx=cn_idx, bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)))
 
     # end points of every (cell, template strut): frac*size + coordinate  (cell.py:300-305)
     P1 = tmpl[None, :, 0:3] * size[:, None, :] + coord[:, None, :]
@@ -465,12 +502,23 @@ def gmsh_subdivisions(length, h):
     return np.where(np.asarray(length) > 0, np.maximum(n, 1), 0).astype(np.int32)
 
 
-def penalize(lat: LatticeArrays, lzone: np.ndarray | None, mesh_size: float | None = None) -> PenalizedBeams:
+def penalize(lat: LatticeArrays, lzone: np.ndarray | None, mesh_size: float | None = None,
+             backend="auto") -> PenalizedBeams:
     """Split every strut into pen(L1) + middle + pen(L2) exactly where the reference puts the new points
-    (start + (end-start)/round(length,4) * L, beam.py:300-312) and count gmsh sub-elements per segment."""
+    (start + (end-start)/round(length,4) * L, beam.py:300-312) and count gmsh sub-elements per segment.
+    ``backend`` as in ``generate`` (pl_penalize / numpy; same bits)."""
     xyz, conn = lat.node_xyz, lat.beam_conn
     B = len(conn)
     h = (MESH_ELEMENT_LENGTH * lat.cell_size_nominal[0]) if mesh_size is None else mesh_size
+    if backend in ("auto", "native"):
+        try:
+            from ._capi import penalize_arrays
+            seg_len, seg_nsub, pen_xyz = penalize_arrays(xyz, conn, lzone, h)
+            return PenalizedBeams(seg_len=seg_len, seg_nsub=seg_nsub, pen_xyz=pen_xyz,
+                                  lzone=np.zeros((B, 2)) if lzone is None else np.asarray(lzone, float))
+        except (OSError, FileNotFoundError, AttributeError):
+            if backend == "native":
+                raise
     pa, pb = xyz[conn[:, 0]], xyz[conn[:, 1]]
     d = pb - pa
     true_len = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2 + d[:, 2] ** 2)
