@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--coarse-max-dofs", type=int, default=0,
                     help="upper bound on the dofs of the dense coarse level (0 = library default, 3072)")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
+    ap.add_argument("--condense", type=int, default=0,
+                    help="1 = exact elimination of an independent node set inside the PCG (opt-in, see pylattice_hip.h)")
     ap.add_argument("--precision", type=int, default=0,
                     help="0 = fp64 (headline), 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only")
     ap.add_argument("--cpu-cells", type=int, default=36,
@@ -237,7 +239,8 @@ def main():
         grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
-                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision)
+                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision,
+                           condense=args.condense)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world
@@ -370,7 +373,7 @@ def main():
                    " + fused scalar all-reduces",
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"], "precision": args.precision,
-                   "inner_solves": st.get("restarts", 0.0),
+                   "inner_solves": st.get("restarts", 0.0), "condensed_nodes": int(st.get("condensed_nodes", 0)),
                    "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
                                       3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)",
                                       4: "multi-level (Jacobi + tile blocks + rank-local dense level + all-reduced "

@@ -95,7 +95,11 @@ typedef struct {
   int32_t compact_records; /* LDS-tile K*p without a palette (graded / optimised lattices): 0 or 1 = stream 40-byte records
                               (the 5 stiffness scalars; the strut vector is recomputed from the node coordinates),
                               -1 = stream the 64-byte records */
-  int32_t reserved2;
+  int32_t condense;      /* 1: multi-level PCG (precond >= 2, fp64, one GPU) with exact elimination of an independent set of
+                            nodes (no two share a strut, none carries a Dirichlet dof) inside the solver: CG runs on the
+                            Schur complement of the other nodes, x still receives every node.  Costs a second K*p per
+                            iteration and saves a third of the iterations on bipartite node graphs (BCC: 793 -> 503 at
+                            100^3) - a wash in time with full-length vectors, hence opt-in.  0 = off */
 } pl_opts_t;
 
 typedef struct {
@@ -113,7 +117,8 @@ typedef struct {
   double info;             /* the reference CG's return code (conjugate_gradient_solver.py:75,99-109): 0 converged,
                               1 not converged, 2 not converged and a step length fell below 1e-6 */
   double stop_reason;      /* which test ended a converged solve: 0 ||r|| <= rtol ||b||, 1 direction norm (mintol) */
-  double reserved[3];
+  double condensed_nodes;  /* nodes eliminated exactly inside the solve (opts.condense) */
+  double reserved[2];
 } pl_stats_t;
 
 void pl_default_opts(pl_opts_t *o);

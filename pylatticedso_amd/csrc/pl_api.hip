@@ -138,6 +138,16 @@ struct pl_context {
   // while the all-reduced global level coarsens
   pl::Coarse coarseL;
   DevBuf<uint8_t> sharedbits, maskL;
+  // exact elimination of an independent node set inside the PCG (opts.condense, pl_coarse.h)
+  std::vector<int32_t> h_conn;        // struts in device numbering (host copy: the independent set depends on the mask)
+  std::vector<int64_t> h_adj_ptr;     // node -> neighbour nodes (CSR), built once when condensation is enabled
+  std::vector<int32_t> h_adj;
+  std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
+  DevBuf<int32_t> cnodes;
+  DevBuf<double> kcc_inv;
+  DevBuf<uint8_t> maskC, cflag;       // Dirichlet bits | 0x3f on condensed nodes; 1 on condensed nodes
+  int64_t n_cond = 0;
+  bool cond_ready = false;
   // multi-GPU
   pl::Dist dist;
 
@@ -222,8 +232,20 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 }
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
-int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
+                const uint8_t *maskbits = nullptr) {
   const int kind = choose_kernel(c);
+  if (maskbits && kind == 3 && c->tile.ready && c->opkind == 0) {   // tile kernel with a caller-chosen row mask
+    if (c->pal_ready)
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream);
+    else if (c->rec5.p)
+      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
+                           dot_dev, c->stream, c->xyz.p);
+    else
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
   const int64_t n6 = c->N * 6;
   if (c->opkind == 1) {
     PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
@@ -486,6 +508,55 @@ int build_coarse(pl_context *c) {
   return build_coarse_level(c, c->coarseL, c->maskL.p, false);
 }
 
+// Greedy maximal independent set of the node graph over the nodes that may be condensed (no Dirichlet dof, not shared
+// with another rank, at least three struts): no two of them share a strut, so K_cc is block diagonal.
+int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
+  c->cond_ready = false;
+  c->n_cond = 0;
+  // (single-GPU handles only for now: the two passes of the condensed operator would each need the interface exchange)
+  const bool wanted = c->opt.condense > 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision == 0 &&
+                      !c->h_adj_ptr.empty() && !c->dist.active;
+  if (!wanted) return PL_OK;
+  const int64_t N = c->N;
+  std::vector<uint8_t> state((size_t)N, 0);
+  std::vector<int32_t> picked;
+  for (int64_t i = 0; i < N; ++i) {
+    if (state[i] || bits[i] || (!c->h_shared.empty() && c->h_shared[i])) continue;
+    if (c->h_adj_ptr[i + 1] - c->h_adj_ptr[i] < 3) continue;
+    state[i] = 1;
+    picked.push_back((int32_t)i);
+    for (int64_t q = c->h_adj_ptr[i]; q < c->h_adj_ptr[i + 1]; ++q)
+      if (!state[c->h_adj[q]]) state[c->h_adj[q]] = 2;
+  }
+  if (picked.empty()) return PL_OK;
+  std::vector<uint8_t> flag((size_t)N, 0), mask(bits);
+  for (int32_t i : picked) {
+    flag[i] = 1;
+    mask[i] = 0x3f;
+  }
+  PL_HIP(c->cnodes.alloc(picked.size()));
+  PL_HIP(c->kcc_inv.alloc(picked.size() * 36));
+  if (!c->maskC.p) {
+    PL_HIP(c->maskC.alloc(N));
+    PL_HIP(c->cflag.alloc(N));
+  }
+  PL_HIP(hipMemcpy(c->cnodes.p, picked.data(), picked.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(c->maskC.p, mask.data(), N, hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(c->cflag.p, flag.data(), N, hipMemcpyHostToDevice));
+  c->n_cond = (int64_t)picked.size();
+  return PL_OK;
+}
+// K_cc^-1 of the condensed nodes from the current records (after launch_records, same stream)
+int launch_condensed_blocks(pl_context *c, hipStream_t st) {
+  c->cond_ready = false;
+  if (c->n_cond <= 0 || !c->have_bc) return PL_OK;
+  hipLaunchKernelGGL(pl::k_node_block_inverse, dim3(grid_for(c->n_cond)), dim3(pl::kBlock), 0, st, c->n_cond,
+                     c->cnodes.p, pl::kWave / c->lpn, c->slice_ptr.p, c->ent.p, c->rec.p, c->kcc_inv.p);
+  PL_HIP(hipGetLastError());
+  c->cond_ready = true;
+  return PL_OK;
+}
+
 int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
   const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
@@ -528,7 +599,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cl.ncp);
+                     cl.ncp, c->cond_ready ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -542,6 +613,17 @@ int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
   const int set = pl::S_COUNT * pl::kSlots;
   double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
+  if (c->cond_ready && c->coarse.ready) {
+    // S p: the condensed nodes take their equilibrium position under p (first pass, their rows of p are 0 on entry),
+    // then the ordinary product with their rows masked like Dirichlet rows (second pass, with p.Ap)
+    int rc = launch_spmv(c, c->p.p, c->Ap.p, false, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->Ap.p, c->p.p, -1.0);
+    rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p);
+    if (rc) return rc;
+    return pcg_tail_coarse(c, cur, nxt, k);
+  }
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
   if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
@@ -616,6 +698,17 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
                     c->scal.p + pl::S_RZ_OLD * pl::kSlots, (const double *)nullptr, c->stream);
     PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (c->cond_ready && c->coarse.ready) {
+    // start from the iterate whose condensed nodes are in equilibrium: x_c = K_cc^-1 r_c, r <- r - K x (rows of the
+    // condensed nodes become exactly 0 and stay 0: every later step keeps them in equilibrium)
+    hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, c->x.p, 1.0);
+    rc = launch_spmv(c, c->x.p, c->z.p, false, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pl::k_condense_residual, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->maskC.p,
+                       (const double *)c->z.p, c->r.p);
+    PL_HIP(hipGetLastError());
   }
   if (c->coarse.ready) {
     // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
@@ -1147,6 +1240,18 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipMemcpy(c->seg_len.p, seg_len.data(), 3 * B * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->seg_nsub.p, seg_nsub.data(), 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_TRY(build_incidence(c, conn));
+  if (o->condense > 0 && o->precond >= 2 && o->precision == 0 && o->reorder == 1) {
+    c->h_conn = conn;
+    c->h_adj_ptr.assign((size_t)N + 1, 0);
+    for (int64_t k = 0; k < 2 * B; ++k) c->h_adj_ptr[conn[k] + 1]++;
+    for (int64_t i = 0; i < N; ++i) c->h_adj_ptr[i + 1] += c->h_adj_ptr[i];
+    c->h_adj.resize((size_t)2 * B);
+    std::vector<int64_t> fill(c->h_adj_ptr.begin(), c->h_adj_ptr.end() - 1);
+    for (int64_t b = 0; b < B; ++b) {
+      c->h_adj[fill[conn[2 * b]]++] = conn[2 * b + 1];
+      c->h_adj[fill[conn[2 * b + 1]]++] = conn[2 * b];
+    }
+  }
   {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
@@ -1385,6 +1490,10 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   h->have_bc = true;
   h->coarse.n_fix = -1;
   h->coarseL.n_fix = -1;
+  {
+    int rcs = select_condensed(h, bits);
+    if (rcs) return rcs;
+  }
   if (h->assembled && h->opkind == 1) {
     if (h->opt.precond == 2) {
       // the factorised G was built for the old Dirichlet mask (and dinv must stay 0 next to it): build it again
@@ -1406,6 +1515,8 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     rc = build_coarse(h);
     if (rc) return rc;
     rc = launch_dinv32(h);
+    if (rc) return rc;
+    rc = launch_condensed_blocks(h, h->stream);
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
     if (h->bsr_with_bc) h->have_bsr = false;   // an explicit matrix built with the old mask is stale
@@ -1496,6 +1607,8 @@ int pl_assemble(pl_handle h) {
   rc = finish_diag_dist(h);
   if (rc) return rc;
   rc = launch_tile_blocks(h, h->side);
+  if (rc) return rc;
+  rc = launch_condensed_blocks(h, h->side);
   if (rc) return rc;
   const bool refresh_bsr = h->want_bsr && (!h->bsr_with_bc || h->have_bc);
   if (refresh_bsr) {
@@ -1648,6 +1761,7 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;
   st.precision_used = mp ? (double)h->opt.precision : 0.0;
+  st.condensed_nodes = (h->cond_ready && h->coarse.ready && !mp) ? (double)h->n_cond : 0.0;
   if (st.converged) st.info = 0.0;
   else if (st.info != 2.0) st.info = 1.0;     // precision mode the solve ran in
   hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,
@@ -1933,6 +2047,9 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   if (h->coarse.enabled) {   // the tile level and the rank-local dense level leave shared nodes out
     std::vector<uint8_t> sh((size_t)h->N, 0);
     for (int i = 0; i < n_shared; ++i) sh[loc[i]] = 1;
+    h->h_shared = sh;
+    h->cond_ready = false;   // (re-selected at the next pl_set_bc; until then nothing is condensed)
+    h->n_cond = 0;
     PL_HIP(hipMemcpy(h->sharedbits.p, sh.data(), sh.size(), hipMemcpyHostToDevice));
     h->coarseL.n_fix = -1;
   }

@@ -713,6 +713,68 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Exact elimination of an independent set of nodes inside the PCG (opts.condense).  No two condensed nodes share a strut
+// and none carries a Dirichlet dof, so K_cc is block diagonal (6 x 6 per node) and
+//     S p = (K [p_v ; -K_cc^-1 K_cv p_v])_v
+// is two passes of the ordinary K*x with a per-node 6 x 6 product in between: CG then runs on the Schur complement
+// of the remaining nodes while x accumulates the condensed nodes' exact (equilibrium) displacements.  For lattices
+// whose node graph is bipartite (BCC: cell centres vs corners) this removes half of the unknowns - the half the
+// diagonal smoother handles worst.
+// ---------------------------------------------------------------------------------------------------------------
+// K_cc^-1 of every condensed node from the sliced-ELL incidence (one thread per node; SN = nodes per ELL slice).
+__global__ __launch_bounds__(kBlock) void k_node_block_inverse(int64_t nc, const int32_t *__restrict__ cnodes, int SN,
+                                                               const int64_t *__restrict__ slice_ptr,
+                                                               const int2 *__restrict__ ent,
+                                                               const Record *__restrict__ rec,
+                                                               double *__restrict__ inv) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nc) return;
+  const int64_t i = cnodes[q], s = i / SN, lane = i % SN;
+  const int64_t p0 = slice_ptr[s], width = (slice_ptr[s + 1] - p0) / SN;
+  double A[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) A[e] = 0.0;
+  for (int64_t j = 0; j < width; ++j) {
+    const int2 e = ent[p0 + j * SN + lane];
+    if (e.x < 0) continue;
+    Record r = load_record(rec, e.y & 0x7fffffff);
+    if (e.y < 0) r = reversed(r);
+    double Kss[36], Kso[36];
+    tip_blocks(r, Kss, Kso);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] += Kss[k];
+  }
+  spd6_inverse(A);
+#pragma unroll
+  for (int k = 0; k < 36; ++k) inv[36 * q + k] = A[k];
+}
+// v[node] = sign * K_cc^-1 y[node] for every condensed node (sign -1: the equilibrium position under the forces y the
+// other nodes exert; +1: the response to a load y)
+template <typename VT>
+__global__ __launch_bounds__(kBlock) void k_condense_solve(int64_t nc, const int32_t *__restrict__ cnodes,
+                                                           const double *__restrict__ inv, const VT *__restrict__ y,
+                                                           VT *__restrict__ v, double sign) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t q = t / 6;
+  const int k = (int)(t - 6 * q);
+  if (q >= nc) return;
+  const int64_t i = cnodes[q];
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc += inv[36 * q + 6 * k + j] * (double)y[6 * i + j];
+  v[6 * i + k] = (VT)(sign * acc);
+}
+// r <- mask .* (r - y): the residual after the condensed nodes took their equilibrium position (their rows become 0)
+__global__ __launch_bounds__(kBlock) void k_condense_residual(int64_t N, const uint8_t *__restrict__ maskbits,
+                                                              const double *__restrict__ y, double *__restrict__ r) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 6 * N) return;
+  const int64_t i = t / 6;
+  const int k = (int)(t - 6 * i);
+  r[t] = ((maskbits[i] >> k) & 1u) ? 0.0 : r[t] - y[t];
+}
+
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
 // One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
 template <typename PT, typename RT>
@@ -734,7 +796,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ cenL,
                                                                  const double *__restrict__ ycL,
                                                                  const uint8_t *__restrict__ shared /* may be null */,
-                                                                 double *__restrict__ rcL, int ncpL) {
+                                                                 double *__restrict__ rcL, int ncpL,
+                                                                 const uint8_t *__restrict__ zero_rows /* may be null */) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   const double pap = scalar_read(scal, S_PAP);
@@ -803,6 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       zc[5] += L[5];
     }
     const unsigned fb = fixedbits[i];
+    const bool zr = zero_rows && zero_rows[i];       // condensed node: x takes the last step, the new direction is 0 there
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -815,8 +879,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       store_pair(x, 3 * i + q, xx);
       const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
       const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);
-      pp.x = z0 + beta * pp.x;
-      pp.y = z1 + beta * pp.y;
+      pp.x = zr ? 0.0 : z0 + beta * pp.x;
+      pp.y = zr ? 0.0 : z1 + beta * pp.y;
       store_pair(p, 3 * i + q, pp);
     }
   }

@@ -539,6 +539,36 @@ def test_tile_level_reduces_iterations_octet16():
     assert res[4][1]["iterations"] < res[3][1]["iterations"]
 
 
+@pytest.mark.parametrize("name", ["bcc_4x4x4", "bcc_6x3x3_flexion", "bccoctet_2x2x2", "bcchybrid1hybrid4_3x2x1_size"])
+def test_condensed_pcg_matches_oracle(golden_dir, name):
+    """opts.condense = 1: an independent set of nodes is eliminated exactly inside the PCG (CG on the Schur complement
+    of the others, two K*p passes per iteration); the solution - including the eliminated nodes - must be the oracle's,
+    prescribed displacements and loads on eliminated nodes included."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    f[lat.n_nodes // 2, :3] += [1e-3, -2e-3, 5e-4]                 # a load on an interior node (condensed or not)
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    its = {}
+    for cond in (0, 1):
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=cond) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st["converged"] == 1 and _rel(u, uref) < 1e-8
+            assert (st["condensed_nodes"] > 0) == bool(cond)
+            its[cond] = st["iterations"]
+            if cond:                                                  # a second right-hand side on the same handle
+                dev.set_bc(L.fixed_DOF, None, 2.0 * f)
+                u2, _ = dev.solve(rtol=1e-11, max_iter=20000)
+                uref2 = O.solve_dirichlet(K, L.fixed_DOF, 0 * ubar, np.where(L.fixed_DOF, 0.0, 2.0 * f)).reshape(-1, 6)
+                assert _rel(u2, uref2) < 1e-8
+    assert its[1] <= its[0]
+
+
 @pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "bcchybrid1hybrid4_3x2x1_size"])
 def test_fp32_solver_modes_match_oracle(golden_dir, name, precision):
