@@ -91,8 +91,11 @@ class FullScaleLatticeSimulation:
 
 @timing.category("simulation")
 @timing.timeit
-def solve_FEM_FenicsX(lattice, rtol=DEFAULT_RTOL, max_iter=DEFAULT_MAX_ITER):
-    """Solve the lattice's FEM problem on the GPU; returns (xsol, simulationModel)."""
+def solve_FEM_FenicsX(lattice, rtol=None, max_iter=DEFAULT_MAX_ITER):
+    """Solve the lattice's FEM problem on the GPU; returns (xsol, simulationModel).  ``rtol`` (on ||r|| / ||b|| of the
+    PCG; the reference solves directly) defaults to ``lattice.fem_rtol`` if set, else DEFAULT_RTOL."""
+    if rtol is None:
+        rtol = getattr(lattice, "fem_rtol", None) or DEFAULT_RTOL
     model = FullScaleLatticeSimulation(lattice, lattice.device_model())
     model.apply_displacement_all_nodes_with_lattice_data()
     model.apply_force_on_all_nodes_with_lattice_data()
