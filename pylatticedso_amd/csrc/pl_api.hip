@@ -114,6 +114,9 @@ struct pl_context {
   int ddm_nb = 0;
   DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
   DevBuf<double> ddm_St;
+  DevBuf<int64_t> ddm_node_ptr;       // node -> (cell * nb + slot) entries: the atomic-free scatter of k_ddm_node_gather
+  DevBuf<int32_t> ddm_node_ent;
+  DevBuf<double> ddm_stage;           // [cells][6 nb] local products
   // assembled-Schur preconditioner of the DDM operator (opt.precond = 2): optional palette of its own + dense factor
   DevBuf<int32_t> ddm_cell_P;
   DevBuf<double> ddm_Pt;
@@ -248,9 +251,11 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
   }
   const int64_t n6 = c->N * 6;
   if (c->opkind == 1) {
-    PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
-    hipLaunchKernelGGL(pl::k_ddm_apply, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock), 0,
-                       c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, y);
+    hipLaunchKernelGGL(pl::k_ddm_cell_product, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock),
+                       0, c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x,
+                       c->ddm_stage.p);
+    hipLaunchKernelGGL(pl::k_ddm_node_gather, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y);
     if (masked || dot_dev)
       hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
@@ -1372,6 +1377,20 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(hipMemcpy(c->ddm_cell_nodes.p, cell_nodes, (size_t)n_cells * nb * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->ddm_cell_S.p, cell_S, n_cells * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->ddm_St.p, St.data(), St.size() * sizeof(double), hipMemcpyHostToDevice));
+  {
+    if (n_cells * nb >= (1LL << 31)) return bail(fail(PL_ERR_ARG, "pl_create_ddm: more than 2^31 cell-node entries"));
+    std::vector<int64_t> nptr((size_t)n_nodes + 1, 0);
+    for (int64_t k = 0; k < n_cells * nb; ++k) nptr[cell_nodes[k] + 1]++;
+    for (int64_t i = 0; i < n_nodes; ++i) nptr[i + 1] += nptr[i];
+    std::vector<int32_t> nent((size_t)n_cells * nb);
+    std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
+    for (int64_t k = 0; k < n_cells * nb; ++k) nent[fill[cell_nodes[k]]++] = (int32_t)k;   // cell-major: fixed sum order
+    PL_HIPC(c->ddm_node_ptr.alloc(nptr.size()));
+    PL_HIPC(c->ddm_node_ent.alloc(nent.size()));
+    PL_HIPC(c->ddm_stage.alloc((size_t)n_cells * m));
+    PL_HIPC(hipMemcpy(c->ddm_node_ptr.p, nptr.data(), nptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    PL_HIPC(hipMemcpy(c->ddm_node_ent.p, nent.data(), nent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   const size_t n6 = (size_t)n_nodes * 6;
   PL_HIPC(c->fixed.alloc(n6));
   PL_HIPC(c->fixedbits.alloc(n_nodes));

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""rocprofv3 driver for the domain-decomposition operator: n^3 BCC cantilever, RBF Schur surrogate of the reference
+(tests/golden/reduced_basis_BCC_tol_1e-6.npz), one solve_DDM + timed applications of sum_c B^T S_c B.
+    rocprofv3 --kernel-trace --stats -d OUT -o ddm --output-format csv -- python3 tools/profile_ddm.py 32"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pylatticedso_amd.lattice_sim import LatticeSim  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": n, "y": n, "z": n},
+                       "radii": [0.05], "geom_types": ["BCC"]},
+          "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False,
+                                    "DDM": {"enable_preconditioner": True, "preconditioner_type": "exact",
+                                            "max_iterations": 20000,
+                                            "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}},
+          "boundary_conditions": {
+              "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"],
+                                         "Value": [0, 0, 0, 0, 0, 0]}},
+              "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}}
+t0 = time.perf_counter()
+L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[os.path.join(ROOT, "tests", "golden")])
+t1 = time.perf_counter()
+xsol, info, idx, b = L.solve_DDM()
+t2 = time.perf_counter()
+dev = L.ddm_model()
+out = {"cells": L.lattice.n_cells, "boundary_nodes": int(L.max_index_boundary + 1), "free_dofs": len(xsol),
+       "setup_s": t1 - t0, "solve_ddm_s": t2 - t1, "cg_iterations": L.iteration, "info": info,
+       "operator_ms": dev.time_kernel(0, 50), "cg_iteration_ms": dev.time_kernel(3, 50),
+       "preconditioner": {0: "none", 1: "Jacobi (above the dense limit)", 2: "assembled Schur, dense Cholesky"}[L._ddm_precond]}
+m = 48
+out["operator_algorithmic_MB"] = (L.lattice.n_cells * (8 * 4 + 4) + 2 * 6 * 8 * out["boundary_nodes"]) / 1e6
+out["operator_staging_MB"] = 2 * L.lattice.n_cells * m * 8 / 1e6
+print(json.dumps(out))
