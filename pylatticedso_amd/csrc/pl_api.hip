@@ -117,6 +117,7 @@ struct pl_context {
   DevBuf<int64_t> ddm_node_ptr;       // node -> (cell * nb + slot) entries: the atomic-free scatter of k_ddm_node_gather
   DevBuf<int32_t> ddm_node_ent;
   DevBuf<double> ddm_stage;           // [cells][6 nb] local products
+  DevBuf<int32_t> ddm_order;          // cells sorted by matrix id (k_ddm_cell_product_lds)
   // assembled-Schur preconditioner of the DDM operator (opt.precond = 2): optional palette of its own + dense factor
   DevBuf<int32_t> ddm_cell_P;
   DevBuf<double> ddm_Pt;
@@ -251,9 +252,23 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
   }
   const int64_t n6 = c->N * 6;
   if (c->opkind == 1) {
-    hipLaunchKernelGGL(pl::k_ddm_cell_product, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock),
-                       0, c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x,
-                       c->ddm_stage.p);
+    const int m = 6 * c->ddm_nb;
+    const size_t lds = ((size_t)m * m + (size_t)(pl::kBlock / pl::kWave) * m) * sizeof(double);
+    const unsigned gw = grid_for((c->ddm_cells + pl::kDdmWaveChunk - 1) / pl::kDdmWaveChunk, pl::kBlock / pl::kWave);
+    if (m <= 48)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<48>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
+                         c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);
+    else if (m <= 64)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<64>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
+                         c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);
+    else if (lds <= 64 * 1024)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_lds, dim3(grid_for(c->ddm_cells, pl::kDdmChunk)), dim3(pl::kBlock), lds,
+                         c->stream, c->ddm_cells, c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p,
+                         c->ddm_St.p, x, c->ddm_stage.p);
+    else
+      hipLaunchKernelGGL(pl::k_ddm_cell_product, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock),
+                         0, c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x,
+                         c->ddm_stage.p);
     hipLaunchKernelGGL(pl::k_ddm_node_gather, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
                        c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y);
     if (masked || dot_dev)
@@ -1390,6 +1405,11 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
     PL_HIPC(c->ddm_stage.alloc((size_t)n_cells * m));
     PL_HIPC(hipMemcpy(c->ddm_node_ptr.p, nptr.data(), nptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     PL_HIPC(hipMemcpy(c->ddm_node_ent.p, nent.data(), nent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> order((size_t)n_cells);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t l, int32_t r) { return cell_S[l] < cell_S[r]; });
+    PL_HIPC(c->ddm_order.alloc(order.size()));
+    PL_HIPC(hipMemcpy(c->ddm_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   const size_t n6 = (size_t)n_nodes * 6;
   PL_HIPC(c->fixed.alloc(n6));

@@ -76,6 +76,125 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product(int64_t C, int nb, 
     stage[c * m + i] = acc;
   }
 }
+// Same product with the cell matrix staged in LDS: cells are visited in the order of their matrix id (`order`, sorted
+// on the host), a workgroup takes kDdmChunk consecutive ones and (re)loads S^T into LDS only when the id changes - on a
+// lattice with few distinct cells that is once per workgroup instead of once per cell from L2 (18 KB per BCC cell:
+// the L2 read of S, not the arithmetic, bounded k_ddm_cell_product).  Needs 8 m^2 bytes of LDS (m <= 84).
+constexpr int kDdmChunk = 32;
+__global__ __launch_bounds__(kBlock) void k_ddm_cell_product_lds(int64_t C, int nb, const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ cell_nodes,
+                                                                 const int32_t *__restrict__ cell_S,
+                                                                 const double *__restrict__ St,
+                                                                 const double *__restrict__ x,
+                                                                 double *__restrict__ stage) {
+  extern __shared__ double lds[];                 // [m*m] S^T, then [waves][m] cell vectors
+  const int m = 6 * nb;
+  double *Ss = lds, *ucell = lds + m * m;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t q0 = (int64_t)blockIdx.x * kDdmChunk;
+  int loaded = -1;
+  for (int round = 0; round < kDdmChunk / (kBlock / kWave); ++round) {
+    const int64_t q = q0 + round * (kBlock / kWave) + wv;
+    const int64_t c = q < C ? order[q] : -1;
+    // all waves of the round must agree on the matrix in LDS: take the first cell's id, cells with another id in the
+    // same round wait for a reload (they are contiguous in `order`, so this happens at most once per id boundary)
+    const int64_t qf = q0 + round * (kBlock / kWave);
+    if (qf >= C) break;
+    const int want = cell_S[order[qf]];
+    if (want != loaded) {
+      __syncthreads();
+      const double *S = St + (size_t)want * m * m;
+      for (int e = threadIdx.x; e < m * m; e += kBlock) Ss[e] = S[e];
+      loaded = want;
+      __syncthreads();
+    }
+    if (c < 0) continue;
+    const int32_t *nodes = cell_nodes + c * nb;
+    double *u = ucell + wv * m;
+    double part = 0.0;
+    for (int i = lane; i < m; i += 64) {
+      const double v = x[6 * (int64_t)nodes[i / 6] + i % 6];
+      u[i] = v;
+      part += v;
+    }
+    double tot = part;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const bool skip = tot == 0.0;
+    const bool own = cell_S[c] == loaded;          // (else: the rare cell whose matrix is not the staged one)
+    const double *Sg = St + (size_t)cell_S[c] * m * m;
+    for (int i = lane; i < m; i += 64) {
+      double acc = 0.0;
+      if (!skip) {
+        if (own)
+          for (int j = 0; j < m; ++j) acc += Ss[j * m + i] * u[j];
+        else
+          for (int j = 0; j < m; ++j) acc += Sg[(size_t)j * m + i] * u[j];
+      }
+      stage[c * m + i] = acc;
+    }
+  }
+}
+
+// Register-resident form for m <= 64 (BCC: 48, Hybrid4: 36): lane i keeps row i of S (column i of S^T) in registers,
+// the cell's vector lives one value per lane and is broadcast with v_readlane (scalar operand of the FMA): no LDS and
+// no L2 traffic per cell at all.  A wave walks kDdmWaveChunk consecutive cells of the id-sorted order and reloads its
+// row only when the matrix id changes.
+constexpr int kDdmWaveChunk = 8;
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int MT>
+__global__ __launch_bounds__(kBlock) void k_ddm_cell_product_reg(int64_t C, int nb, const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ cell_nodes,
+                                                                 const int32_t *__restrict__ cell_S,
+                                                                 const double *__restrict__ St,
+                                                                 const double *__restrict__ x,
+                                                                 double *__restrict__ stage) {
+  const int m = 6 * nb;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t q0 = w * kDdmWaveChunk;
+  if (q0 >= C) return;
+  double Srow[MT];
+  int loaded = -1;
+  const int il = lane < m ? lane : 0;
+  // all gathers of the chunk first (independent loads in flight together), then the products
+  int64_t cell[kDdmWaveChunk];
+  double uu[kDdmWaveChunk];
+#pragma unroll
+  for (int k = 0; k < kDdmWaveChunk; ++k) {
+    const int64_t q = q0 + k;
+    cell[k] = q < C ? (int64_t)order[q] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kDdmWaveChunk; ++k)
+    uu[k] = (cell[k] >= 0 && lane < m) ? x[6 * (int64_t)cell_nodes[cell[k] * nb + lane / 6] + lane % 6] : 0.0;
+#pragma unroll
+  for (int k = 0; k < kDdmWaveChunk; ++k) {
+    const int64_t c = cell[k];
+    if (c < 0) break;
+    const int id = cell_S[c];
+    if (id != loaded) {
+      const double *S = St + (size_t)id * m * m;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) Srow[j] = j < m ? S[(size_t)j * m + il] : 0.0;      // St[j][i] = S[i][j]
+      loaded = id;
+    }
+    const double u = uu[k];
+    double tot = u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    double acc = 0.0;
+    if (tot != 0.0) {                       // lattice_sim.py:1239
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc += Srow[j] * readlane_f64(u, j);
+    }
+    if (lane < m) stage[c * m + lane] = acc;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_ddm_node_gather(int64_t N, const int64_t *__restrict__ node_ptr,
                                                             const int32_t *__restrict__ node_ent,
                                                             const double *__restrict__ stage,
