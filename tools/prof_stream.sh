@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_f
+O=$R/gpurun_out/${1:-r02_l}
 mkdir -p $O
 cd $R
 for cfg in "p0:--palette 0" "gr:--graded 1"; do
