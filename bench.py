@@ -166,7 +166,8 @@ def main():
                     help="upper bound on the dofs of the dense coarse level (0 = library default, 3072)")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--condense", type=int, default=0,
-                    help="1 = exact elimination of an independent node set inside the PCG (opt-in, see pylattice_hip.h)")
+                    help="exact elimination of an independent node set inside the PCG: 0 = automatic (bipartite node "
+                         "graphs such as BCC), 1 = whenever possible, -1 = never (see pylattice_hip.h)")
     ap.add_argument("--precision", type=int, default=0,
                     help="0 = fp64 (headline), 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only")
     ap.add_argument("--cpu-cells", type=int, default=36,

@@ -95,11 +95,12 @@ typedef struct {
   int32_t compact_records; /* LDS-tile K*p without a palette (graded / optimised lattices): 0 or 1 = stream 40-byte records
                               (the 5 stiffness scalars; the strut vector is recomputed from the node coordinates),
                               -1 = stream the 64-byte records */
-  int32_t condense;      /* 1: multi-level PCG (precond >= 2, fp64, one GPU) with exact elimination of an independent set of
-                            nodes (no two share a strut, none carries a Dirichlet dof) inside the solver: CG runs on the
-                            Schur complement of the other nodes, x still receives every node.  Costs a second K*p per
-                            iteration and saves a third of the iterations on bipartite node graphs (BCC: 793 -> 503 at
-                            100^3) - a wash in time with full-length vectors, hence opt-in.  0 = off */
+  int32_t condense;      /* multi-level PCG (precond >= 2, fp64, one GPU): exact elimination of an independent set of nodes (no
+                            two share a strut, none carries a Dirichlet dof; chosen at pl_create, interior nodes first)
+                            inside the solver - CG runs on the Schur complement of the other nodes, the vector kernels skip
+                            the eliminated rows, every iteration pays a second K*p, x still receives every node.
+                            0 = automatic: when >= 45 % of the nodes can go (bipartite node graphs such as BCC: 793 -> 503
+                            iterations and 275 -> 228 ms at 100^3), 1 = whenever candidates exist, -1 = never */
 } pl_opts_t;
 
 typedef struct {

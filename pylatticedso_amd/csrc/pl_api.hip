@@ -143,9 +143,7 @@ struct pl_context {
   pl::Coarse coarseL;
   DevBuf<uint8_t> sharedbits, maskL;
   // exact elimination of an independent node set inside the PCG (opts.condense, pl_coarse.h)
-  std::vector<int32_t> h_conn;        // struts in device numbering (host copy: the independent set depends on the mask)
-  std::vector<int64_t> h_adj_ptr;     // node -> neighbour nodes (CSR), built once when condensation is enabled
-  std::vector<int32_t> h_adj;
+  std::vector<uint8_t> h_cand;        // candidates (an independent set of the node graph, chosen at pl_create; device numbering)
   std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
   DevBuf<int32_t> cnodes;
   DevBuf<double> kcc_inv;
@@ -237,16 +235,20 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
-                const uint8_t *maskbits = nullptr) {
+                const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
   const int kind = choose_kernel(c);
-  if (maskbits && kind == 3 && c->tile.ready && c->opkind == 0) {   // tile kernel with a caller-chosen row mask
+  if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0) {
+    // tile kernel with a caller-chosen row mask and / or only one kind of strut ends (node elimination)
+    const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
     if (c->pal_ready)
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream);
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,
+                           (const double *)nullptr, ends, cf);
     else if (c->rec5.p)
       pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
-                           dot_dev, c->stream, c->xyz.p);
+                           dot_dev, c->stream, c->xyz.p, ends, cf);
     else
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream);
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
+                           (const double *)nullptr, ends, cf);
     PL_HIP(hipGetLastError());
     return PL_OK;
   }
@@ -528,26 +530,19 @@ int build_coarse(pl_context *c) {
   return build_coarse_level(c, c->coarseL, c->maskL.p, false);
 }
 
-// Greedy maximal independent set of the node graph over the nodes that may be condensed (no Dirichlet dof, not shared
-// with another rank, at least three struts): no two of them share a strut, so K_cc is block diagonal.
+// The nodes eliminated in this solve: the candidates of pl_create (an independent set of the node graph, so K_cc is block
+// diagonal) that carry no Dirichlet dof and are not shared with another rank.
 int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   c->cond_ready = false;
   c->n_cond = 0;
   // (single-GPU handles only for now: the two passes of the condensed operator would each need the interface exchange)
-  const bool wanted = c->opt.condense > 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision == 0 &&
-                      !c->h_adj_ptr.empty() && !c->dist.active;
+  const bool wanted = c->opt.condense >= 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision == 0 &&
+                      !c->h_cand.empty() && !c->dist.active;
   if (!wanted) return PL_OK;
   const int64_t N = c->N;
-  std::vector<uint8_t> state((size_t)N, 0);
   std::vector<int32_t> picked;
-  for (int64_t i = 0; i < N; ++i) {
-    if (state[i] || bits[i] || (!c->h_shared.empty() && c->h_shared[i])) continue;
-    if (c->h_adj_ptr[i + 1] - c->h_adj_ptr[i] < 3) continue;
-    state[i] = 1;
-    picked.push_back((int32_t)i);
-    for (int64_t q = c->h_adj_ptr[i]; q < c->h_adj_ptr[i + 1]; ++q)
-      if (!state[c->h_adj[q]]) state[c->h_adj[q]] = 2;
-  }
+  for (int64_t i = 0; i < N; ++i)
+    if (c->h_cand[i] && !bits[i] && (c->h_shared.empty() || !c->h_shared[i])) picked.push_back((int32_t)i);
   if (picked.empty()) return PL_OK;
   std::vector<uint8_t> flag((size_t)N, 0), mask(bits);
   for (int32_t i : picked) {
@@ -601,7 +596,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cs.ncp);
+                     cs.ncp, c->cond_ready ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
     pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
@@ -636,11 +631,11 @@ int pcg_iteration(pl_context *c, int k) {
   if (c->cond_ready && c->coarse.ready) {
     // S p: the condensed nodes take their equilibrium position under p (first pass, their rows of p are 0 on entry),
     // then the ordinary product with their rows masked like Dirichlet rows (second pass, with p.Ap)
-    int rc = launch_spmv(c, c->p.p, c->Ap.p, false, nullptr);
+    int rc = launch_spmv(c, c->p.p, c->Ap.p, false, nullptr, nullptr, pl::kEndsCondensed);
     if (rc) return rc;
     hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
                        c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->Ap.p, c->p.p, -1.0);
-    rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p);
+    rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
     if (rc) return rc;
     return pcg_tail_coarse(c, cur, nxt, k);
   }
@@ -722,12 +717,15 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   if (c->cond_ready && c->coarse.ready) {
     // start from the iterate whose condensed nodes are in equilibrium: x_c = K_cc^-1 r_c, r <- r - K x (rows of the
     // condensed nodes become exactly 0 and stay 0: every later step keeps them in equilibrium)
+    // t_c = K_cc^-1 b_c (rows of z, zero elsewhere), r_v -= (K t)_v: the load the eliminated nodes pass on.  Their own
+    // rows of r keep b_c, their rows of x stay 0 until the back-substitution after the loop.
+    PL_HIP(hipMemsetAsync(c->z.p, 0, n6 * sizeof(double), c->stream));
     hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, c->x.p, 1.0);
-    rc = launch_spmv(c, c->x.p, c->z.p, false, nullptr);
+                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, c->z.p, 1.0);
+    rc = launch_spmv(c, c->z.p, c->tmp2.p, true, nullptr, c->maskC.p, pl::kEndsOthers);
     if (rc) return rc;
-    hipLaunchKernelGGL(pl::k_condense_residual, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->maskC.p,
-                       (const double *)c->z.p, c->r.p);
+    hipLaunchKernelGGL(pl::k_condense_subtract, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->cflag.p,
+                       (const double *)c->tmp2.p, c->r.p);
     PL_HIP(hipGetLastError());
   }
   if (c->coarse.ready) {
@@ -817,6 +815,13 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     }
   }
   if (!st->converged) st->iterations = k;
+  if (c->cond_ready && c->coarse.ready) {   // eliminated nodes: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
+    rc = launch_spmv(c, c->x.p, c->tmp2.p, false, nullptr, nullptr, pl::kEndsCondensed);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pl::k_condense_backsubst, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
+    PL_HIP(hipGetLastError());
+  }
   return PL_OK;
 }
 
@@ -1222,6 +1227,65 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   }
   c->iperm.resize(N);
   for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
+  if (o->condense >= 0 && o->precond >= 2 && o->precision == 0 && o->reorder == 1 && o->grid_nodes == 0) {
+    // Candidates for exact elimination inside the PCG (opts.condense): a greedy maximal independent set of the node
+    // graph (no two share a strut; at least three struts each).  Inside every tile they are numbered LAST, so that the
+    // vector kernels, which skip them, skip one contiguous run of rows per tile.
+    std::vector<int64_t> aptr((size_t)N + 1, 0);
+    for (int64_t k = 0; k < 2 * B; ++k) aptr[c->iperm[m->beam_conn[k]] + 1]++;
+    for (int64_t i = 0; i < N; ++i) aptr[i + 1] += aptr[i];
+    std::vector<int32_t> adj((size_t)2 * B);
+    {
+      std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+      for (int64_t b = 0; b < B; ++b) {
+        const int32_t u = c->iperm[m->beam_conn[2 * b]], v = c->iperm[m->beam_conn[2 * b + 1]];
+        adj[fill[u]++] = v;
+        adj[fill[v]++] = u;
+      }
+    }
+    // two greedy passes: nodes strictly inside the bounding box first, then the ones on it.  Boundary conditions sit
+    // on the faces (a node with a Dirichlet dof cannot be eliminated) and face nodes have fewer struts; on BCC this
+    // picks the cell centres rather than the corners (measured: 702 -> 468 iterations at 50^3 against 575 the other way)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(lo[k], m->node_xyz[3 * i + k]);
+        hi[k] = std::max(hi[k], m->node_xyz[3 * i + k]);
+      }
+    std::vector<uint8_t> state((size_t)N, 0);
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t i = 0; i < N; ++i) {
+        if (state[i] || aptr[i + 1] - aptr[i] < 3) continue;
+        const double *q3 = m->node_xyz + 3 * (size_t)c->perm[i];
+        const bool on_box = q3[0] <= lo[0] || q3[0] >= hi[0] || q3[1] <= lo[1] || q3[1] >= hi[1] || q3[2] <= lo[2] ||
+                            q3[2] >= hi[2];
+        if (on_box != (pass == 1)) continue;
+        state[i] = 1;
+        for (int64_t q = aptr[i]; q < aptr[i + 1]; ++q)
+          if (!state[adj[q]]) state[adj[q]] = 2;
+      }
+    int64_t n_cand = 0;
+    for (int64_t i = 0; i < N; ++i) n_cand += state[i] == 1;
+    // automatic mode: only when close to half of the unknowns can go (bipartite node graphs such as BCC: measured
+    // 1.1-1.2 x faster solves; Octet, a quarter of the nodes: 1.2 x slower - every iteration pays a second K*p)
+    const bool use = o->condense > 0 || (double)n_cand >= 0.45 * (double)N;
+    const int64_t T = use ? (int64_t)tile_start.size() - 1 : 0;
+    std::vector<int32_t> np(c->perm.size());
+    if (use) c->h_cand.assign((size_t)N, 0);
+    for (int64_t t = 0; t < T; ++t) {
+      int64_t w = tile_start[t];
+      for (int pass = 0; pass < 2; ++pass)
+        for (int64_t i = tile_start[t]; i < tile_start[t + 1]; ++i)
+          if ((state[i] == 1) == (pass == 1)) {
+            c->h_cand[w] = (uint8_t)pass;
+            np[w++] = c->perm[i];
+          }
+    }
+    if (use) {
+      c->perm.swap(np);
+      for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
+    }
+  }
 
   std::vector<double> xyz((size_t)N * 3);
   for (int64_t i = 0; i < N; ++i) std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
@@ -1260,18 +1324,6 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipMemcpy(c->seg_len.p, seg_len.data(), 3 * B * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->seg_nsub.p, seg_nsub.data(), 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
   PL_TRY(build_incidence(c, conn));
-  if (o->condense > 0 && o->precond >= 2 && o->precision == 0 && o->reorder == 1) {
-    c->h_conn = conn;
-    c->h_adj_ptr.assign((size_t)N + 1, 0);
-    for (int64_t k = 0; k < 2 * B; ++k) c->h_adj_ptr[conn[k] + 1]++;
-    for (int64_t i = 0; i < N; ++i) c->h_adj_ptr[i + 1] += c->h_adj_ptr[i];
-    c->h_adj.resize((size_t)2 * B);
-    std::vector<int64_t> fill(c->h_adj_ptr.begin(), c->h_adj_ptr.end() - 1);
-    for (int64_t b = 0; b < B; ++b) {
-      c->h_adj[fill[conn[2 * b]]++] = conn[2 * b + 1];
-      c->h_adj[fill[conn[2 * b + 1]]++] = conn[2 * b];
-    }
-  }
   {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));

@@ -568,7 +568,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const int32_t *__restrict__ aggL_of_tile /* may be null */,
                                                             const double *__restrict__ cenL,
                                                             const uint8_t *__restrict__ shared /* may be null */,
-                                                            double *__restrict__ rcL, int ncp) {
+                                                            double *__restrict__ rcL, int ncp,
+                                                            const uint8_t *__restrict__ skip_rows /* may be null */) {
   __shared__ double red[20][kBlock / kWave];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   double accT[6] = {0, 0, 0, 0, 0, 0};      // tile level on several GPUs: the tile's restriction without shared nodes
   const bool own_t = Bt_inv && shared;
   for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
+    if (skip_rows && skip_rows[i]) continue;    // eliminated node (opts.condense): not an unknown of this CG
     // (x += alpha p is done by k_pcg_direction_coarse, which reads p anyway: one vector pass less per iteration)
     double av[6], dv[6], rv[6];
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
@@ -765,14 +767,28 @@ __global__ __launch_bounds__(kBlock) void k_condense_solve(int64_t nc, const int
   for (int j = 0; j < 6; ++j) acc += inv[36 * q + 6 * k + j] * (double)y[6 * i + j];
   v[6 * i + k] = (VT)(sign * acc);
 }
-// r <- mask .* (r - y): the residual after the condensed nodes took their equilibrium position (their rows become 0)
-__global__ __launch_bounds__(kBlock) void k_condense_residual(int64_t N, const uint8_t *__restrict__ maskbits,
+// r_v <- r_v - y_v on the rows of the nodes that stay (the load the eliminated nodes pass on to them); the rows of the
+// eliminated nodes keep their own right-hand side b_c for the back-substitution at the end
+__global__ __launch_bounds__(kBlock) void k_condense_subtract(int64_t N, const uint8_t *__restrict__ cflag,
                                                               const double *__restrict__ y, double *__restrict__ r) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= 6 * N) return;
-  const int64_t i = t / 6;
-  const int k = (int)(t - 6 * i);
-  r[t] = ((maskbits[i] >> k) & 1u) ? 0.0 : r[t] - y[t];
+  if (!cflag[t / 6]) r[t] -= y[t];
+}
+// x_c = K_cc^-1 (b_c - y_c): the eliminated nodes' displacements once the others are known (y = K [x_v ; 0])
+__global__ __launch_bounds__(kBlock) void k_condense_backsubst(int64_t nc, const int32_t *__restrict__ cnodes,
+                                                               const double *__restrict__ inv,
+                                                               const double *__restrict__ b,
+                                                               const double *__restrict__ y, double *__restrict__ x) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t q = t / 6;
+  const int k = (int)(t - 6 * q);
+  if (q >= nc) return;
+  const int64_t i = cnodes[q];
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc += inv[36 * q + 6 * k + j] * (b[6 * i + j] - y[6 * i + j]);
+  x[6 * i + k] = acc;
 }
 
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
@@ -846,6 +862,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     l2 = cenL[3 * aL + 2];
   }
   for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
+    if (zero_rows && zero_rows[i]) {   // eliminated node: only clear its row of p (the next first pass wants zeros there)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) store_pair(p, 3 * i + q, double2{0.0, 0.0});
+      continue;
+    }
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     if (own_t && !shared[i]) {
@@ -866,7 +887,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       zc[5] += L[5];
     }
     const unsigned fb = fixedbits[i];
-    const bool zr = zero_rows && zero_rows[i];       // condensed node: x takes the last step, the new direction is 0 there
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * i);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -879,8 +899,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       store_pair(x, 3 * i + q, xx);
       const double z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : zc[2 * q]);
       const double z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : zc[2 * q + 1]);
-      pp.x = zr ? 0.0 : z0 + beta * pp.x;
-      pp.y = zr ? 0.0 : z1 + beta * pp.y;
+      pp.x = z0 + beta * pp.x;
+      pp.y = z1 + beta * pp.y;
       store_pair(p, 3 * i + q, pp);
     }
   }

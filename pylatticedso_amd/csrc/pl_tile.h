@@ -215,11 +215,14 @@ struct __attribute__((aligned(8))) Rec5 {
   double a, c, e1, e2, e3;
 };
 
-template <int REC, typename VT>
+// ENDS: which strut ends are accumulated - kEndsAll, or (node elimination, pl_coarse.h) only the ends at condensed nodes
+// / only the others, told apart by the byte flag cflag[node].
+enum { kEndsAll = 0, kEndsCondensed = 1, kEndsOthers = 2 };
+template <int REC, int ENDS, typename VT>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
-                                           const double *__restrict__ xyz, const VT *__restrict__ x, double *ys,
-                                           int stride) {
+                                           const double *__restrict__ xyz, const uint8_t *__restrict__ cflag,
+                                           const VT *__restrict__ x, double *ys, int stride) {
   const int2 c = conn2[b];
   Record r;
   if (REC == kRecCompact) {
@@ -234,8 +237,13 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
   tip_force(r, uA, tA, uB, tB, F, M);
-  if (c.y >= n0 && c.y < n1) lds_add6(ys + (c.y - n0), stride, F, M);
-  if (c.x >= n0 && c.x < n1) {
+  bool takeB = c.y >= n0 && c.y < n1, takeA = c.x >= n0 && c.x < n1;
+  if (ENDS != kEndsAll) {
+    if (takeB) takeB = (cflag[c.y] != 0) == (ENDS == kEndsCondensed);
+    if (takeA) takeA = (cflag[c.x] != 0) == (ENDS == kEndsCondensed);
+  }
+  if (takeB) lds_add6(ys + (c.y - n0), stride, F, M);
+  if (takeA) {
     const V3 d = {r.dx, r.dy, r.dz};
     lds_add6(ys + (c.x - n0), stride, (-1.0) * F, (-1.0) * M - cross(d, F));
   }
@@ -248,7 +256,7 @@ constexpr int kTileBlock = 512;
 // VT = storage type of x and y (double, or float for the fp32 solver modes: the strut forces are still evaluated
 // and accumulated in fp64 - the forces on a node nearly cancel for the smooth fields a solve is made of, so rounding
 // them to fp32 before the sum would cost cond(K) * 6e-8, rounding the stored result costs 6e-8).
-template <bool MASK, bool DOT, int REC, typename VT>
+template <bool MASK, bool DOT, int REC, typename VT, int ENDS = kEndsAll>
 __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restrict__ tile_start,
                                                       const int64_t *__restrict__ home_ptr,
                                                       const int64_t *__restrict__ foreign_ptr,
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
                                                       const double *__restrict__ xyz,
                                                       const uint8_t *__restrict__ fixedbits,
                                                       const VT *__restrict__ x, VT *__restrict__ y,
-                                                      double *__restrict__ dot_out, int stride) {
+                                                      double *__restrict__ dot_out, int stride,
+                                                      const uint8_t *__restrict__ cflag = nullptr) {
   extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
   __shared__ double red[kTileBlock / kWave];
   const unsigned t = xcd_block(blockIdx.x, gridDim.x);
@@ -269,16 +278,17 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 4
   for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock)
-    tile_strut<REC, VT>(b, n0, n1, conn2, rec, pal, xyz, x, ys, stride);
+    tile_strut<REC, ENDS, VT>(b, n0, n1, conn2, rec, pal, xyz, cflag, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
 #pragma unroll 4
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
-    tile_strut<REC, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, xyz, x, ys, stride);
+    tile_strut<REC, ENDS, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, xyz, cflag, x, ys, stride);
   __syncthreads();
   double acc = 0.0;
   const int64_t pair0 = 3 * (int64_t)n0;
   for (int i = threadIdx.x; i < nn * 3; i += kTileBlock) {
     const int node = i / 3, part = i - 3 * node;
+    if (ENDS != kEndsAll && ((cflag[n0 + node] != 0) != (ENDS == kEndsCondensed))) continue;   // rows of the other kind
     double2 v = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
     if (MASK) {
       const unsigned fb = fixedbits[n0 + node] >> (2 * part);
@@ -303,28 +313,35 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
 }
 
 // pal != nullptr: `rec` is the palette table and pal[b] the strut's entry; xyz != nullptr: `rec` is the compact
-// 5-scalar table (Rec5) and the strut vectors come from the node coordinates.
+// 5-scalar table (Rec5) and the strut vectors come from the node coordinates.  ends / cflag: see tile_strut.
 template <typename VT>
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
                              const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s,
-                             const double *xyz = nullptr) {
+                             const double *xyz = nullptr, int ends = kEndsAll, const uint8_t *cflag = nullptr) {
   const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
-#define PL_T(M, D, P)                                                                                          \
-  hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p, plan.foreign_ptr.p, \
-                     plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride)
-#define PL_TT(P)                                           \
-  do {                                                     \
-    if (fixedbits && dot_dev) PL_T(true, true, P);         \
-    else if (fixedbits) PL_T(true, false, P);              \
-    else if (dot_dev) PL_T(false, true, P);                \
-    else PL_T(false, false, P);                            \
+#define PL_T(M, D, P, E)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT, E>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p,           \
+                     plan.foreign_ptr.p, plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride, cflag)
+#define PL_TT(P, E)                                           \
+  do {                                                        \
+    if (fixedbits && dot_dev) PL_T(true, true, P, E);         \
+    else if (fixedbits) PL_T(true, false, P, E);              \
+    else if (dot_dev) PL_T(false, true, P, E);                \
+    else PL_T(false, false, P, E);                            \
   } while (0)
-  if (pal) PL_TT(kRecPalette);
-  else if (xyz) PL_TT(kRecCompact);
-  else PL_TT(kRecAoS);
+#define PL_TE(P)                                   \
+  do {                                             \
+    if (ends == kEndsCondensed) PL_TT(P, kEndsCondensed); \
+    else if (ends == kEndsOthers) PL_TT(P, kEndsOthers);  \
+    else PL_TT(P, kEndsAll);                       \
+  } while (0)
+  if (pal) PL_TE(kRecPalette);
+  else if (xyz) PL_TE(kRecCompact);
+  else PL_TE(kRecAoS);
+#undef PL_TE
 #undef PL_TT
 #undef PL_T
 }

@@ -444,7 +444,9 @@ def test_full_size_properties_config3():
         dev.set_bc(fixed, None, f)
         dev.assemble()                       # the coarse levels need the Dirichlet set
         u, st = dev.solve(rtol=1e-8, max_iter=50000)
-        assert st["converged"] == 1 and int(st["precond_used"]) == 3 and st["iterations"] < 1000
+        # BCC is bipartite: the automatic node elimination takes the 10^6 cell centres out (793 -> 503 iterations)
+        assert st["converged"] == 1 and int(st["precond_used"]) == 3 and st["iterations"] < 560
+        assert int(st["condensed_nodes"]) == 1_000_000
         res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
         assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8
         assert abs((f * u).sum() - 2.0 * dev.energy(u)) < 1e-7 * abs((f * u).sum())
@@ -553,20 +555,20 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
     ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
     uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
     its = {}
-    for cond in (0, 1):
+    for cond in (-1, 1):
         with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=cond) as dev:
             dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
             dev.assemble()
             u, st = dev.solve(rtol=1e-11, max_iter=20000)
             assert st["converged"] == 1 and _rel(u, uref) < 1e-8
-            assert (st["condensed_nodes"] > 0) == bool(cond)
+            assert (st["condensed_nodes"] > 0) == (cond > 0)
             its[cond] = st["iterations"]
-            if cond:                                                  # a second right-hand side on the same handle
+            if cond > 0:                                                  # a second right-hand side on the same handle
                 dev.set_bc(L.fixed_DOF, None, 2.0 * f)
                 u2, _ = dev.solve(rtol=1e-11, max_iter=20000)
                 uref2 = O.solve_dirichlet(K, L.fixed_DOF, 0 * ubar, np.where(L.fixed_DOF, 0.0, 2.0 * f)).reshape(-1, 6)
                 assert _rel(u2, uref2) < 1e-8
-    assert its[1] <= its[0]
+    assert its[1] <= its[-1]
 
 
 @pytest.mark.parametrize("precision", [1, 2])

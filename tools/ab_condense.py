@@ -19,16 +19,17 @@ for geom, n, r in cases:
     f = np.zeros((lat.n_nodes, 6))
     f[tgt, 2] = -0.1 / tgt.sum()
     out = {}
-    for cond in (-1, 1):
+    for cond in (-1, 0 if os.environ.get('AUTO') else 1):
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
-                              precond=3, palette=1, condense=cond) as dev:
+                              precond=3, palette=1, condense=cond,
+                              tile_nodes=int(os.environ.get('TILE', '0'))) as dev:
             dev.set_bc(fixed, None, f)
             dev.assemble()
             u, st = dev.solve(rtol=1e-8, max_iter=50000)
             u, st = dev.solve(rtol=1e-8, max_iter=50000)
             res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
             out[cond] = (u, st, np.linalg.norm(res) / np.linalg.norm(f), dev.time_kernel(3, 20))
-    (u0, s0, r0, t0), (u1, s1, r1, t1) = out[-1], out[1]
+    (u0, s0, r0, t0), (u1, s1, r1, t1) = out[-1], out[0 if os.environ.get('AUTO') else 1]
     print(f"{geom} {n}^3: plain {s0['iterations']} its {s0['ms_solve']:.1f} ms ({t0 * 1e3:.0f} us/it, true res {r0:.1e}) | "
           f"condensed ({int(s1['condensed_nodes'])} of {lat.n_nodes} nodes) {s1['iterations']} its {s1['ms_solve']:.1f} ms "
           f"({t1 * 1e3:.0f} us/it, true res {r1:.1e}) | rel diff {np.linalg.norm(u1 - u0) / np.linalg.norm(u0):.1e}",
