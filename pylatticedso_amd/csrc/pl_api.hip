@@ -148,8 +148,16 @@ struct pl_context {
   DevBuf<int32_t> cnodes;
   DevBuf<double> kcc_inv;
   DevBuf<uint8_t> maskC, cflag;       // Dirichlet bits | 0x3f on condensed nodes; 1 on condensed nodes
+  // classes of eliminated nodes with the same K_cc^-1 (pl_coarse.h k_cls_*): only with a record palette
+  DevBuf<unsigned long long> cls_key, cls_keys;
+  DevBuf<int> cls_owner, cls_flags;
+  DevBuf<uint16_t> cls_id;
+  DevBuf<double> cls_table;
+  int *cls_host_flag = nullptr;       // pinned
+  bool cls_ready = false;
   int64_t n_cond = 0;
-  bool cond_ready = false;
+  bool cond_ready = false;   // K_cc^-1 valid for the current records and mask
+  bool cond_use = false;     // the running solve eliminates them (fp64 PCG and precision = 1)
   // multi-GPU
   pl::Dist dist;
 
@@ -312,16 +320,19 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
 }
 
 // K*p of the fp32 solver modes: tile kernel only, fp32-stored x / y, fp64 arithmetic (pl_tile.h)
-int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double *dot_dev) {
+int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double *dot_dev,
+                    const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
+  const uint8_t *mk = maskbits ? maskbits : (masked ? (const uint8_t *)c->fixedbits.p : (const uint8_t *)nullptr);
+  const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
   if (c->pal_ready)
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
-                                dot_dev, c->stream);
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, mk, x, y, dot_dev, c->stream,
+                                (const double *)nullptr, ends, cf);
   else if (c->rec5.p)
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr,
-                                masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream, c->xyz.p);
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, mk, x, y,
+                                dot_dev, c->stream, c->xyz.p, ends, cf);
   else
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y,
-                                dot_dev, c->stream);
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, mk, x, y, dot_dev, c->stream,
+                                (const double *)nullptr, ends, cf);
   if (c->dist.active) {
     int rc = pl::dist_sum_shared<float>(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
     if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
@@ -530,13 +541,16 @@ int build_coarse(pl_context *c) {
   return build_coarse_level(c, c->coarseL, c->maskL.p, false);
 }
 
+inline const double *cinv(const pl_context *c) { return c->cls_ready ? c->cls_table.p : c->kcc_inv.p; }
+inline const uint16_t *ccls(const pl_context *c) { return c->cls_ready ? c->cls_id.p : (const uint16_t *)nullptr; }
+
 // The nodes eliminated in this solve: the candidates of pl_create (an independent set of the node graph, so K_cc is block
 // diagonal) that carry no Dirichlet dof and are not shared with another rank.
 int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   c->cond_ready = false;
   c->n_cond = 0;
   // (single-GPU handles only for now: the two passes of the condensed operator would each need the interface exchange)
-  const bool wanted = c->opt.condense >= 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision == 0 &&
+  const bool wanted = c->opt.condense >= 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision != 2 &&
                       !c->h_cand.empty() && !c->dist.active;
   if (!wanted) return PL_OK;
   const int64_t N = c->N;
@@ -569,7 +583,45 @@ int launch_condensed_blocks(pl_context *c, hipStream_t st) {
                      c->cnodes.p, pl::kWave / c->lpn, c->slice_ptr.p, c->ent.p, c->rec.p, c->kcc_inv.p);
   PL_HIP(hipGetLastError());
   c->cond_ready = true;
+  c->cls_ready = false;
+  if (c->opt.palette && c->pal_id.p) {
+    // Classes by the record-palette ids of the incident struts (queued behind launch_palette on the same stream; if the
+    // record palette turns out not to hold, finish_condensed_classes drops the classes as well)
+    if (!c->cls_table.p) {
+      PL_HIP(c->cls_keys.alloc(65536));
+      PL_HIP(c->cls_owner.alloc(65536));
+      PL_HIP(c->cls_flags.alloc(1));
+      PL_HIP(c->cls_table.alloc((size_t)65536 * 36));
+      void *pinned = nullptr;
+      PL_HIP(hipHostMalloc(&pinned, sizeof(int), hipHostMallocDefault));
+      c->cls_host_flag = static_cast<int *>(pinned);
+    }
+    if (c->cls_key.n < (size_t)c->n_cond) {
+      PL_HIP(c->cls_key.alloc((size_t)c->n_cond));
+      PL_HIP(c->cls_id.alloc((size_t)c->n_cond));
+    }
+    *c->cls_host_flag = 1;
+    PL_HIP(hipMemsetAsync(c->cls_keys.p, 0xFF, 65536 * sizeof(unsigned long long), st));
+    PL_HIP(hipMemsetAsync(c->cls_owner.p, 0x7F, 65536 * sizeof(int), st));
+    PL_HIP(hipMemsetAsync(c->cls_flags.p, 0, sizeof(int), st));
+    const dim3 g(grid_for(c->n_cond)), blk(pl::kBlock);
+    hipLaunchKernelGGL(pl::k_cls_hash, g, blk, 0, st, c->n_cond, c->cnodes.p, pl::kWave / c->lpn, c->slice_ptr.p,
+                       c->ent.p, c->pal_id.p, c->cls_key.p);
+    hipLaunchKernelGGL(pl::k_cls_insert, g, blk, 0, st, c->n_cond, c->cls_key.p, c->cls_keys.p, c->cls_owner.p,
+                       c->cls_id.p, c->cls_flags.p);
+    hipLaunchKernelGGL(pl::k_cls_publish, dim3(grid_for(c->n_cond * 36)), blk, 0, st, c->n_cond, c->kcc_inv.p,
+                       c->cls_owner.p, c->cls_id.p, c->cls_table.p);
+    hipLaunchKernelGGL(pl::k_cls_verify, g, blk, 0, st, c->n_cond, c->kcc_inv.p, c->cls_id.p, c->cls_table.p,
+                       c->cls_flags.p);
+    PL_HIP(hipGetLastError());
+    PL_HIP(hipMemcpyAsync(c->cls_host_flag, c->cls_flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   return PL_OK;
+}
+// after the stream has drained and finish_palette() has run
+void finish_condensed_classes(pl_context *c) {
+  c->cls_ready = c->cond_ready && c->cls_host_flag && *c->cls_host_flag == 0 && c->pal_ready && c->opt.palette;
+  if (c->cls_host_flag) *c->cls_host_flag = 1;
 }
 
 int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
@@ -596,7 +648,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cs.ncp, c->cond_ready ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
+                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
     pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
@@ -614,7 +666,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      c->hist.p, hist_slot, cs.rc, cs.ncp,
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cl.ncp, c->cond_ready ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
+                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -628,13 +680,13 @@ int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
   const int set = pl::S_COUNT * pl::kSlots;
   double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
-  if (c->cond_ready && c->coarse.ready) {
+  if (c->cond_use) {
     // S p: the condensed nodes take their equilibrium position under p (first pass, their rows of p are 0 on entry),
     // then the ordinary product with their rows masked like Dirichlet rows (second pass, with p.Ap)
     int rc = launch_spmv(c, c->p.p, c->Ap.p, false, nullptr, nullptr, pl::kEndsCondensed);
     if (rc) return rc;
     hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->Ap.p, c->p.p, -1.0);
+                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->Ap.p, c->p.p, -1.0);
     rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
     if (rc) return rc;
     return pcg_tail_coarse(c, cur, nxt, k);
@@ -721,10 +773,10 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     // rows of r keep b_c, their rows of x stay 0 until the back-substitution after the loop.
     PL_HIP(hipMemsetAsync(c->z.p, 0, n6 * sizeof(double), c->stream));
     hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, c->z.p, 1.0);
+                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, c->z.p, 1.0);
     rc = launch_spmv(c, c->z.p, c->tmp2.p, true, nullptr, c->maskC.p, pl::kEndsOthers);
     if (rc) return rc;
-    hipLaunchKernelGGL(pl::k_condense_subtract, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->cflag.p,
+    hipLaunchKernelGGL(pl::k_condense_subtract<double>, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->cflag.p,
                        (const double *)c->tmp2.p, c->r.p);
     PL_HIP(hipGetLastError());
   }
@@ -815,11 +867,11 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     }
   }
   if (!st->converged) st->iterations = k;
-  if (c->cond_ready && c->coarse.ready) {   // eliminated nodes: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
+  if (c->cond_use) {   // eliminated nodes: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
     rc = launch_spmv(c, c->x.p, c->tmp2.p, false, nullptr, nullptr, pl::kEndsCondensed);
     if (rc) return rc;
-    hipLaunchKernelGGL(pl::k_condense_backsubst, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                       c->n_cond, c->cnodes.p, c->kcc_inv.p, (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
+    hipLaunchKernelGGL(pl::k_condense_backsubst<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
     PL_HIP(hipGetLastError());
   }
   return PL_OK;
@@ -918,6 +970,17 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
       hipLaunchKernelGGL(k_mp_restart, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, c->r.p,
                          reinterpret_cast<float *>(ri), reinterpret_cast<float *>(xi));
     PL_HIP(hipMemsetAsync(p32, 0, n6 * sizeof(float), c->stream));
+    if (kAll32 && c->cond_use) {
+      // node elimination inside the inner solve (as in pcg_solve): t_c = K_cc^-1 b_c in the rows of p32, r_v -= (K t)_v
+      float *r32 = reinterpret_cast<float *>(ri);
+      hipLaunchKernelGGL(pl::k_condense_solve<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                         c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)r32, p32, 1.0);
+      rc = launch_spmv_f32(c, p32, Ap32, true, nullptr, c->maskC.p, pl::kEndsOthers);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pl::k_condense_subtract<float>, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->cflag.p, (const float *)Ap32, r32);
+      PL_HIP(hipMemsetAsync(p32, 0, n6 * sizeof(float), c->stream));
+    }
     PL_HIP(hipMemsetAsync(Ap32, 0, n6 * sizeof(float), c->stream));
     rc = pcg_tail_coarse_t<float, RT>(c, c->scal.p + set, c->scal.p, max_iter + 1, p32, (const float *)Ap32, xi, ri);
     if (rc) return rc;
@@ -930,7 +993,15 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
       const int todo = std::min(next, max_iter - k);
       for (int q = 0; q < todo; ++q) {
         double *cur = c->scal.p + ((j + q) & 1) * set, *nxt = c->scal.p + ((j + q + 1) & 1) * set;
-        rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        if (kAll32 && c->cond_use) {
+          rc = launch_spmv_f32(c, p32, Ap32, false, nullptr, nullptr, pl::kEndsCondensed);
+          if (rc) return rc;
+          hipLaunchKernelGGL(pl::k_condense_solve<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                             c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)Ap32, p32, -1.0);
+          rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
+        } else {
+          rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        }
         if (rc) return rc;
         rc = pcg_tail_coarse_t<float, RT>(c, cur, nxt, k + q, p32, (const float *)Ap32, xi, ri);
         if (rc) return rc;
@@ -960,6 +1031,13 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
       }
     }
     // ---- true residual of the accumulated solution
+    if (kAll32 && c->cond_use) {   // the eliminated nodes of this inner solve: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
+      float *x32 = reinterpret_cast<float *>(xi), *r32 = reinterpret_cast<float *>(ri);
+      rc = launch_spmv_f32(c, x32, Ap32, false, nullptr, nullptr, pl::kEndsCondensed);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pl::k_condense_backsubst<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                         c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)r32, (const float *)Ap32, x32);
+    }
     if (kAll32)
       hipLaunchKernelGGL(k_mp_accumulate, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          reinterpret_cast<const float *>(xi), c->x.p);
@@ -1227,7 +1305,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   }
   c->iperm.resize(N);
   for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
-  if (o->condense >= 0 && o->precond >= 2 && o->precision == 0 && o->reorder == 1 && o->grid_nodes == 0) {
+  if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1 && o->grid_nodes == 0) {
     // Candidates for exact elimination inside the PCG (opts.condense): a greedy maximal independent set of the node
     // graph (no two share a strut; at least three struts each).  Inside every tile they are numbered LAST, so that the
     // vector kernels, which skip them, skip one contiguous run of rows per tile.
@@ -1552,6 +1630,7 @@ void pl_destroy(pl_handle h) {
   (void)hipStreamSynchronize(h->stream);
   pl::dist_destroy(h->dist);
   if (h->pal_host_flags != h->pal_fallback_flags) (void)hipHostFree(h->pal_host_flags);
+  if (h->cls_host_flag) (void)hipHostFree(h->cls_host_flag);
   delete h;
 }
 
@@ -1610,6 +1689,11 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     rc = launch_condensed_blocks(h, h->stream);
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
+    {
+      const bool keep = h->pal_ready;        // (the record palette is untouched by a new mask)
+      finish_condensed_classes(h);
+      (void)keep;
+    }
     if (h->bsr_with_bc) h->have_bsr = false;   // an explicit matrix built with the old mask is stale
   }
   return PL_OK;
@@ -1715,6 +1799,7 @@ int pl_assemble(pl_handle h) {
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
   finish_palette(h);
+  finish_condensed_classes(h);
   // the factorisation has consumed A_c: zero it now, behind the caller's back, instead of at the head of the next
   // assembly's critical chain (34 MB; it would sit in front of the coarse assembly there)
   for (pl::Coarse *cs : {&h->coarse, &h->coarseL})
@@ -1847,12 +1932,14 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   if (rc) return rc;
   // fp32 solver modes need the multi-level preconditioner on the tile kernel; anything else runs the fp64 PCG
   const bool mp = h->opt.precision != 0 && h->opkind == 0 && h->coarse.ready && choose_kernel(h) == 3 && h->tile.ready;
+  h->cond_use = h->cond_ready && h->coarse.ready && h->opkind == 0 && choose_kernel(h) == 3 && h->tile.ready &&
+                (!mp || h->opt.precision == 1);
   if (mp && h->opt.precision == 1) rc = pcg_solve_mp_t<float>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   else if (mp) rc = pcg_solve_mp_t<double>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;
   st.precision_used = mp ? (double)h->opt.precision : 0.0;
-  st.condensed_nodes = (h->cond_ready && h->coarse.ready && !mp) ? (double)h->n_cond : 0.0;
+  st.condensed_nodes = h->cond_use ? (double)h->n_cond : 0.0;
   if (st.converged) st.info = 0.0;
   else if (st.info != 2.0) st.info = 1.0;     // precision mode the solve ran in
   hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,

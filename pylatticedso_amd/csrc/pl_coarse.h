@@ -753,42 +753,116 @@ __global__ __launch_bounds__(kBlock) void k_node_block_inverse(int64_t nc, const
 }
 // v[node] = sign * K_cc^-1 y[node] for every condensed node (sign -1: the equilibrium position under the forces y the
 // other nodes exert; +1: the response to a load y)
+// (cls != null: inv is the class table of k_cls_* below, cls[q] the node's entry - a lattice with a record palette has a
+// few dozen distinct K_cc, and 288 bytes per eliminated node and iteration were the largest stream of the elimination)
 template <typename VT>
 __global__ __launch_bounds__(kBlock) void k_condense_solve(int64_t nc, const int32_t *__restrict__ cnodes,
-                                                           const double *__restrict__ inv, const VT *__restrict__ y,
+                                                           const double *__restrict__ inv,
+                                                           const uint16_t *__restrict__ cls, const VT *__restrict__ y,
                                                            VT *__restrict__ v, double sign) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t q = t / 6;
   const int k = (int)(t - 6 * q);
   if (q >= nc) return;
   const int64_t i = cnodes[q];
+  const double *A = inv + 36 * (cls ? (int64_t)cls[q] : q);
   double acc = 0.0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) acc += inv[36 * q + 6 * k + j] * (double)y[6 * i + j];
+  for (int j = 0; j < 6; ++j) acc += A[6 * k + j] * (double)y[6 * i + j];
   v[6 * i + k] = (VT)(sign * acc);
+}
+// ---- classes of eliminated nodes with the same K_cc: nodes whose incident struts carry the same multiset of (record
+// palette id, end) have the same block up to the order of the sum.  Same scheme as pl_palette.h: hash -> claim a slot ->
+// the owner publishes its inverse -> every node verifies (1e-10: a hash collision would pair DIFFERENT blocks).
+__global__ __launch_bounds__(kBlock) void k_cls_hash(int64_t nc, const int32_t *__restrict__ cnodes, int SN,
+                                                     const int64_t *__restrict__ slice_ptr,
+                                                     const int2 *__restrict__ ent, const uint16_t *__restrict__ pal,
+                                                     unsigned long long *__restrict__ key) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nc) return;
+  const int64_t i = cnodes[q], s = i / SN, lane = i % SN;
+  const int64_t p0 = slice_ptr[s], width = (slice_ptr[s + 1] - p0) / SN;
+  unsigned long long h = 0;
+  for (int64_t j = 0; j < width; ++j) {
+    const int2 e = ent[p0 + j * SN + lane];
+    if (e.x < 0) continue;
+    unsigned long long v = ((unsigned long long)pal[e.y & 0x7fffffff] << 1) | (e.y < 0 ? 1ull : 0ull);
+    v = (v + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    v ^= v >> 29;
+    v *= 0x94D049BB133111EBull;
+    v ^= v >> 32;
+    h += v;                                   // commutative: the order of the incident struts does not matter
+  }
+  key[q] = h == ~0ull ? 0 : h;
+}
+__global__ __launch_bounds__(kBlock) void k_cls_insert(int64_t nc, const unsigned long long *__restrict__ key,
+                                                       unsigned long long *__restrict__ keys, int *__restrict__ owner,
+                                                       uint16_t *__restrict__ cls, int *__restrict__ flags) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nc) return;
+  const unsigned long long h = key[q];
+  unsigned slot = (unsigned)(h >> 48);
+  for (int probe = 0; probe < 32; ++probe) {
+    unsigned long long cur = keys[slot];
+    if (cur == ~0ull) cur = atomicCAS(keys + slot, ~0ull, h);
+    if (cur == ~0ull || cur == h) {
+      if ((int)q < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(owner + slot, (int)q);
+      cls[q] = (uint16_t)slot;
+      return;
+    }
+    slot = (slot + 1) & 65535u;
+  }
+  flags[0] = 1;
+}
+__global__ __launch_bounds__(kBlock) void k_cls_publish(int64_t nc, const double *__restrict__ inv,
+                                                        const int *__restrict__ owner, const uint16_t *__restrict__ cls,
+                                                        double *__restrict__ table) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t q = t / 36;
+  if (q >= nc) return;
+  if (owner[cls[q]] == (int)q) table[36 * (int64_t)cls[q] + (t - 36 * q)] = inv[t];
+}
+__global__ __launch_bounds__(kBlock) void k_cls_verify(int64_t nc, const double *__restrict__ inv,
+                                                       const uint16_t *__restrict__ cls,
+                                                       const double *__restrict__ table, int *__restrict__ flags) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nc) return;
+  const double *a = inv + 36 * q, *b = table + 36 * (int64_t)cls[q];
+  double scale = 0.0, diff = 0.0;
+#pragma unroll
+  for (int e = 0; e < 36; ++e) {
+    scale = fmax(scale, fabs(a[e]));
+    diff = fmax(diff, fabs(a[e] - b[e]));
+  }
+  if (!(diff <= 1e-10 * scale)) flags[0] = 1;
 }
 // r_v <- r_v - y_v on the rows of the nodes that stay (the load the eliminated nodes pass on to them); the rows of the
 // eliminated nodes keep their own right-hand side b_c for the back-substitution at the end
+template <typename VT>
 __global__ __launch_bounds__(kBlock) void k_condense_subtract(int64_t N, const uint8_t *__restrict__ cflag,
-                                                              const double *__restrict__ y, double *__restrict__ r) {
+                                                              const VT *__restrict__ y, VT *__restrict__ r) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= 6 * N) return;
-  if (!cflag[t / 6]) r[t] -= y[t];
+  if (!cflag[t / 6]) r[t] = (VT)((double)r[t] - (double)y[t]);
 }
 // x_c = K_cc^-1 (b_c - y_c): the eliminated nodes' displacements once the others are known (y = K [x_v ; 0])
+template <typename VT>
 __global__ __launch_bounds__(kBlock) void k_condense_backsubst(int64_t nc, const int32_t *__restrict__ cnodes,
                                                                const double *__restrict__ inv,
-                                                               const double *__restrict__ b,
-                                                               const double *__restrict__ y, double *__restrict__ x) {
+                                                               const uint16_t *__restrict__ cls,
+                                                               const VT *__restrict__ b,
+                                                               const VT *__restrict__ y, VT *__restrict__ x) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t q = t / 6;
   const int k = (int)(t - 6 * q);
   if (q >= nc) return;
   const int64_t i = cnodes[q];
+  const double *A = inv + 36 * (cls ? (int64_t)cls[q] : q);
   double acc = 0.0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) acc += inv[36 * q + 6 * k + j] * (b[6 * i + j] - y[6 * i + j]);
-  x[6 * i + k] = acc;
+  for (int j = 0; j < 6; ++j) acc += A[6 * k + j] * ((double)b[6 * i + j] - (double)y[6 * i + j]);
+  x[6 * i + k] = (VT)acc;
 }
 
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
