@@ -2,9 +2,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -69,7 +72,7 @@ struct pl_context {
   // pl_assemble overlaps the latency-bound dense factorisation chain (main stream) with the bandwidth-bound fills
   // (palette, Jacobi diagonal, tile blocks, explicit BSR) on a second stream
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr;
   bool assembled = false, have_bc = false, have_bsr = false;
   int pal_fallback_flags[2] = {1, 0};
   int *pal_host_flags = pal_fallback_flags;   // pinned once the palette is in use: a D2H copy into pageable memory blocks the host
@@ -169,6 +172,7 @@ struct pl_context {
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_chol) (void)hipEventDestroy(ev_chol);
     if (side) (void)hipStreamDestroy(side);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -462,9 +466,13 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
 }
 
 // A_c = Z^T P K P Z on the device, then its Cholesky factor and W = L^-1 (pl_dense.h).
-int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool reduce) {
+int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool reduce,
+                       const std::function<void()> &after_chol = nullptr) {
   cs.ready = false;
-  if (!cs.enabled || !c->have_bc) return PL_OK;
+  if (!cs.enabled || !c->have_bc) {
+    if (after_chol) after_chol();
+    return PL_OK;
+  }
   const int n = cs.ncp;
   if (!cs.ac_clean) PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
   cs.ac_clean = false;
@@ -524,7 +532,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     }
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream);
+  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream, after_chol);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
@@ -534,8 +542,8 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   return PL_OK;
 }
 
-int build_coarse(pl_context *c) {
-  int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true);
+int build_coarse(pl_context *c, const std::function<void()> &after_chol = nullptr) {
+  int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true, after_chol);
   if (rc || !c->coarseL.enabled) return rc;
   // (mask = Dirichlet | shared, launch_local_mask: its modes live on this rank's own nodes only)
   return build_coarse_level(c, c->coarseL, c->maskL.p, false);
@@ -625,10 +633,11 @@ void finish_condensed_classes(pl_context *c) {
 }
 
 int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
-  const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
+  const size_t lds = (size_t)(pl::kBsrBlock / pl::kWave) * 64 * pl::kBsrPitch * sizeof(double);   // 38 KB
+  const unsigned gb = grid_for(c->n_slices, pl::kBsrBlock / pl::kWave);
 #define PL_B(L)                                                                                                  \
-  hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(g), dim3(pl::kBlock), 0, st, c->N, c->slice_ptr.p, c->ent.p,  \
+  hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(gb), dim3(pl::kBsrBlock), lds, st, c->N, c->slice_ptr.p, c->ent.p,  \
                      c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p, fb, with_bc, c->bsr_vals.p)
   switch (c->lpn) { case 1: PL_B(1); break; case 2: PL_B(2); break; case 4: PL_B(4); break; case 8: PL_B(8); break;
                     default: PL_B(16); }
@@ -1146,6 +1155,20 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
 
 bool valid(pl_handle h) { return h != nullptr; }
 
+// PL_TIMING=1 in the environment: wall clock of the host-side stages of pl_create on stderr
+struct StageTimer {
+  const char *what;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(const char *w) : what(w), on(std::getenv("PL_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char *stage) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[%s] %-28s %8.1f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 }  // namespace
 
 // ==========================================================================================================
@@ -1229,6 +1252,7 @@ void pl_default_opts(pl_opts_t *o) {
 
 int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (!m || !o || !out) return fail(PL_ERR_ARG, "pl_create: null argument");
+  StageTimer stage("pl_create");
   if (m->n_nodes <= 0 || m->n_beams <= 0) return fail(PL_ERR_ARG, "pl_create: empty mesh");
   if (m->n_nodes >= (1LL << 31) - 64 || m->n_beams >= (1LL << 31) - 64)
     return fail(PL_ERR_ARG, "pl_create: more than 2^31 nodes/struts per handle");
@@ -1250,6 +1274,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
       if (m->seg_len[3 * b + k] < 0.0 || (m->seg_len[3 * b + k] > 0.0 && m->seg_nsub[3 * b + k] < 1))
         return fail(PL_ERR_ARG, "pl_create: bad segment data on strut " + std::to_string(b));
   }
+  stage.mark("validate");
   PL_HIP(hipSetDevice(o->device));
   pl_context *c = new pl_context();
   c->opt = *o;
@@ -1286,6 +1311,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreate(&c->ev1));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_chol, hipEventDisableTiming));
 
   // node ordering on the device
   const double global_grid[7] = {o->grid_lo[0], o->grid_lo[1], o->grid_lo[2], o->grid_hi[0], o->grid_hi[1],
@@ -1303,6 +1329,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   } else {
     pl::chunk_tiles(N, tile_start);
   }
+  stage.mark("spatial order");
   c->iperm.resize(N);
   for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
   if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1 && o->grid_nodes == 0) {
@@ -1365,6 +1392,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     }
   }
 
+  stage.mark("candidates");
   std::vector<double> xyz((size_t)N * 3);
   for (int64_t i = 0; i < N; ++i) std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
   std::vector<int32_t> conn((size_t)B * 2);
@@ -1377,6 +1405,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
       conn[2 * b + 1] = conn0[2 * (size_t)c->bperm[b] + 1];
     }
   }
+  stage.mark("strut order");
   std::vector<double> radius(B), seg_len((size_t)B * 3);
   std::vector<int32_t> seg_nsub((size_t)B * 3);
   for (int64_t b = 0; b < B; ++b) {
@@ -1401,11 +1430,14 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipMemcpy(c->radius.p, radius.data(), B * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->seg_len.p, seg_len.data(), 3 * B * sizeof(double), hipMemcpyHostToDevice));
   PL_HIPC(hipMemcpy(c->seg_nsub.p, seg_nsub.data(), 3 * B * sizeof(int32_t), hipMemcpyHostToDevice));
+  stage.mark("permute + upload");
   PL_TRY(build_incidence(c, conn));
+  stage.mark("incidence + BSR pattern");
   {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
+  stage.mark("tile plan");
   if (o->precond >= 2 && o->precond <= 4) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
     c->coarse.tile_level = (o->precond >= 3);
@@ -1432,6 +1464,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     }
   }
 
+  stage.mark("coarse setup");
   const size_t n6 = (size_t)N * 6;
   PL_HIPC(c->fixed.alloc(n6));
   PL_HIPC(c->fixedbits.alloc(N));
@@ -1447,6 +1480,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipDeviceSynchronize());
 #undef PL_TRY
 #undef PL_HIPC
+  stage.mark("vector buffers");
   *out = c;
   return PL_OK;
 }
@@ -1508,6 +1542,7 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(hipEventCreate(&c->ev1));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_chol, hipEventDisableTiming));
   c->perm.resize(n_nodes);
   std::iota(c->perm.begin(), c->perm.end(), 0);
   c->iperm = c->perm;
@@ -1786,13 +1821,26 @@ int pl_assemble(pl_handle h) {
   rc = launch_condensed_blocks(h, h->side);
   if (rc) return rc;
   const bool refresh_bsr = h->want_bsr && (!h->bsr_with_bc || h->have_bc);
-  if (refresh_bsr) {
-    rc = launch_bsr_fill(h, h->bsr_with_bc, h->side);
-    if (rc) return rc;
-  }
+  // The explicit K is the one bulk item of the assembly (2.5 GB of traffic): next to the Cholesky chain it slows every
+  // link of that latency-bound chain (44 -> 57 us), so it starts when the chain's last link is queued and runs beside
+  // the single-launch inverse factor instead.
+  int rc_fill = PL_OK;
+  bool fill_queued = false;
+  auto queue_fill = [&]() {
+    if (!refresh_bsr || fill_queued) return;
+    fill_queued = true;
+    if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_chol, 0) != hipSuccess) {
+      rc_fill = fail(PL_ERR_HIP, "pl_assemble: could not order the BSR fill behind the factorisation");
+      return;
+    }
+    rc_fill = launch_bsr_fill(h, h->bsr_with_bc, h->side);
+    if (hipEventRecord(h->ev_join, h->side) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
+  };
   PL_HIP(hipEventRecord(h->ev_join, h->side));
-  rc = build_coarse(h);
+  rc = build_coarse(h, h->coarse.enabled && h->have_bc ? std::function<void()>(queue_fill) : std::function<void()>());
   if (rc) return rc;
+  queue_fill();                                  // (no dense level: queue it now)
+  if (rc_fill) return rc_fill;
   PL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   rc = launch_dinv32(h);
   if (rc) return rc;

@@ -271,19 +271,42 @@ __global__ __launch_bounds__(kBlock) void k_diag_gather(int64_t N, const int64_t
 // block is the lane-group sum of the Kss blocks.  Row i holds [diag block] + one block per incident strut, columns
 // ascending (slots fixed at setup).  with_bc: dolfinx Dirichlet treatment (rows/cols zeroed, unit diagonal).
 // ---------------------------------------------------------------------------------------------------------
+// Stores: a lane's 6 x 6 block is 288 contiguous bytes, but the 64 lanes of a wave own 64 blocks scattered over the rows
+// of 16 nodes - written lane by lane that is 36 store instructions of 64 x 8 bytes with a 288-byte stride (2.4 TB/s).
+// Every block is therefore staged in LDS (one row of kBsrPitch doubles per lane) and the wave writes three whole blocks
+// per instruction: lanes 0-17 / 18-35 / 36-53 each store the 18 double2 of one block.
+constexpr int kBsrPitch = 38;          // doubles per staged block (36 + 2: rows stay 16-byte aligned)
+constexpr int kBsrBlock = 128;         // two waves per workgroup: 2 x 19 KB of staging, four workgroups per CU
+__device__ __forceinline__ void bsr_store_staged(double *stage /* this wave's [64][kBsrPitch] */, int lane,
+                                                 int64_t my_block /* -1: nothing staged by this lane */,
+                                                 double *__restrict__ vals) {
+  const int g = lane / 18, l = lane - 18 * g;        // g = 3: idle lanes 54..63
+#pragma unroll 2
+  for (int j = 0; j < 66; j += 3) {
+    const int src = j + g;
+    const int64_t blk = __shfl(my_block, src < 64 ? src : 0, 64);
+    if (g < 3 && src < 64 && blk >= 0) {
+      const double2 v = *reinterpret_cast<const double2 *>(stage + src * kBsrPitch + 2 * l);
+      *reinterpret_cast<double2 *>(vals + 36 * blk + 2 * l) = v;
+    }
+  }
+}
+
 template <int LPN>
-__global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *__restrict__ slice_ptr,
+__global__ __launch_bounds__(kBsrBlock) void k_bsr_fill(int64_t N, const int64_t *__restrict__ slice_ptr,
                                                      const int2 *__restrict__ ent, const Record *__restrict__ rec,
                                                      const int64_t *__restrict__ rowptr,
                                                      const int32_t *__restrict__ ent_slot,
                                                      const int32_t *__restrict__ diag_slot,
                                                      const uint8_t *__restrict__ fixedbits, int with_bc,
                                                      double *__restrict__ vals) {
+  extern __shared__ double bsr_lds[];                   // [kBsrBlock / kWave][64][kBsrPitch]
   constexpr int kSliceNodes = kWave / LPN;
-  const int lane = threadIdx.x & 63, sub = lane / kSliceNodes;
-  const int64_t slice = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, sub = lane / kSliceNodes, wv = threadIdx.x >> 6;
+  double *stage = bsr_lds + (size_t)wv * 64 * kBsrPitch;
+  const int64_t slice = (int64_t)blockIdx.x * (kBsrBlock / kWave) + wv;
   const int64_t i = slice * kSliceNodes + (lane & (kSliceNodes - 1));
-  if (slice * kSliceNodes >= N) return;
+  if (slice * kSliceNodes >= N) return;                 // wave-uniform
   const bool live = i < N;
   double Kd[36];
 #pragma unroll
@@ -291,29 +314,37 @@ __global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *_
   const unsigned fi = (live && with_bc && fixedbits) ? fixedbits[i] : 0u;
   const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
   const int64_t row0 = live ? rowptr[i] : 0;
-  for (int64_t p = p0 + lane; p < p1; p += 64) {
-    const int2 e = ent[p];
-    if (e.x >= 0) {
-      Record r = load_record(rec, e.y & 0x7fffffff);
-      if (e.y < 0) r = reversed(r);
-      double Kss[36], Kso[36];
-      tip_blocks(r, Kss, Kso);
-      const unsigned fo = (with_bc && fixedbits) ? fixedbits[e.x] : 0u;
-      double *dst = vals + 36 * (row0 + ent_slot[p]);
+  for (int64_t pb = p0; pb < p1; pb += 64) {            // whole wave takes every trip (the staged stores are collective)
+    const int64_t p = pb + lane;
+    int64_t my_block = -1;
+    if (p < p1) {
+      const int2 e = ent[p];
+      if (e.x >= 0) {
+        Record r = load_record(rec, e.y & 0x7fffffff);
+        if (e.y < 0) r = reversed(r);
+        double Kss[36], Kso[36];
+        tip_blocks(r, Kss, Kso);
+        const unsigned fo = (with_bc && fixedbits) ? fixedbits[e.x] : 0u;
+        my_block = row0 + ent_slot[p];
+        double *dst = stage + lane * kBsrPitch;
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+        for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          Kd[a * 6 + b] += Kss[a * 6 + b];
-          const bool z = ((fi >> a) & 1u) || ((fo >> b) & 1u);
-          dst[a * 6 + b] = z ? 0.0 : Kso[a * 6 + b];
-        }
+          for (int b = 0; b < 6; ++b) {
+            Kd[a * 6 + b] += Kss[a * 6 + b];
+            const bool z = ((fi >> a) & 1u) || ((fo >> b) & 1u);
+            dst[a * 6 + b] = z ? 0.0 : Kso[a * 6 + b];
+          }
+      }
     }
+    bsr_store_staged(stage, lane, my_block, vals);       // (LDS accesses of one wave are ordered: no barrier needed)
   }
 #pragma unroll
   for (int k = 0; k < 36; ++k) Kd[k] = lpn_sum<LPN>(Kd[k]);
+  int64_t my_block = -1;
   if (live && sub == 0) {
-    double *dd = vals + 36 * (row0 + diag_slot[i]);
+    my_block = row0 + diag_slot[i];
+    double *dd = stage + lane * kBsrPitch;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -322,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_bsr_fill(int64_t N, const int64_t *_
         dd[a * 6 + b] = (fa || fb) ? ((a == b) ? 1.0 : 0.0) : Kd[a * 6 + b];
       }
   }
+  bsr_store_staged(stage, lane, my_block, vals);
 }
 
 // y = A x for the assembled BSR matrix: one thread per block row (cross-check path).
