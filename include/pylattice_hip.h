@@ -101,6 +101,11 @@ typedef struct {
                             the eliminated rows, every iteration pays a second K*p, x still receives every node.
                             0 = automatic: when >= 45 % of the nodes can go (bipartite node graphs such as BCC: 793 -> 503
                             iterations and 275 -> 228 ms at 100^3), 1 = whenever candidates exist, -1 = never */
+  int32_t chol_persistent; /* 1: factor the dense coarse operator in ONE persistent launch with a grid barrier per block
+                              column instead of one launch per block column.  Measured slower (2.94 vs 2.86 ms per
+                              assembly at 50^3 Octet): the release / acquire fences of a barrier across the 8 XCDs cost
+                              what the kernel boundary costs - kept as an experiment switch */
+  int32_t reserved3;
 } pl_opts_t;
 
 typedef struct {

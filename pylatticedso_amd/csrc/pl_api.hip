@@ -532,7 +532,8 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     }
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream, after_chol);
+  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream, after_chol,
+                           c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr);
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));

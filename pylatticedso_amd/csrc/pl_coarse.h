@@ -44,6 +44,7 @@ struct Coarse {
   float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
   double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
+  unsigned *bar = nullptr;   // grid-barrier counter of the persistent Cholesky chain (pl_dense.h)
   bool ac_clean = false;   // Ac was zeroed after the previous factorisation (off the critical path of pl_assemble)
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
@@ -61,7 +62,7 @@ struct Coarse {
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32})
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)bar})
       if (q) (void)hipFree(q);
   }
 };
@@ -187,6 +188,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.yc, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.tv, (size_t)c.ncp * sizeof(double)) != hipSuccess) return 2;
   if (hipMalloc((void **)&c.info, 2 * sizeof(int)) != hipSuccess) return 2;
+  if (hipMalloc((void **)&c.bar, sizeof(unsigned)) != hipSuccess) return 2;
   {
     c.h_tile_start = tile_start;
     if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;

@@ -228,13 +228,10 @@ __global__ __launch_bounds__(kBlock) void k_chol_diag(double *__restrict__ A, in
 // A_ij -= L_ik L_jk^T, and - for (k+1, k+1) - goes straight on to factor and invert that diagonal block, so the
 // next link can start.  L_ik goes to the separate matrix Lf (written by workgroup (i, i)); column k of A stays
 // readable for everybody.
-__global__ __launch_bounds__(kBlock) void k_chol_step(double *__restrict__ A, double *__restrict__ Lf, int ld, int kb,
-                                                      double *__restrict__ Dinv, int *__restrict__ info) {
-  __shared__ double S[3 * kNB * kLdT];                       // 101 KB of the CU's 160 KB
+__device__ __forceinline__ void chol_step_body(double *__restrict__ A, double *__restrict__ Lf, int ld, int kb, int ib,
+                                               int jb, double *__restrict__ Dinv, int *__restrict__ info, double *S) {
   double *X = S, *Y = S + kNB * kLdT, *D = S + 2 * kNB * kLdT;
   static_assert(kDiagLds <= 2 * kNB * kLdT, "diagonal-block scratch must fit into X|Y");
-  const int ib = kb + 1 + blockIdx.x, jb = kb + 1 + blockIdx.y;
-  if (jb > ib) return;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   stage_rows_as_k_minor(Dinv + (size_t)kb * kNB * kNB, kNB, D);                          // D[m][col] = Dinv_k[col][m]
   stage_rows_as_k_minor(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, X);          // X[m][row] = A_jk[row][m]
@@ -291,6 +288,55 @@ __global__ __launch_bounds__(kBlock) void k_chol_step(double *__restrict__ A, do
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] = a[i][j];
+}
+
+__global__ __launch_bounds__(kBlock) void k_chol_step(double *__restrict__ A, double *__restrict__ Lf, int ld, int kb,
+                                                      double *__restrict__ Dinv, int *__restrict__ info) {
+  __shared__ double S[3 * kNB * kLdT];                       // 101 KB of the CU's 160 KB
+  const int ib = kb + 1 + blockIdx.x, jb = kb + 1 + blockIdx.y;
+  if (jb > ib) return;
+  chol_step_body(A, Lf, ld, kb, ib, jb, Dinv, info, S);
+}
+
+// The whole chain of block columns in ONE launch: the grid is the band (bw x bw workgroups, at most kChainMaxGrid so that
+// they are all resident - one per CU at 101 KB of LDS), every workgroup walks k = 0 .. nb - 2 and a grid barrier
+// (one atomic counter, release / acquire fences at agent scope) separates the steps.  What it saves is the ~13 us a
+// dependent kernel launch costs per link.  A barrier that does not complete within ~2 s sets info[0] = -7 and every
+// workgroup leaves (a hung kernel would take the GPU with it).
+constexpr int kChainMaxGrid = 196;
+__device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned target, int *info) {
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    __threadfence();                                             // release: this workgroup's blocks are visible
+    atomicAdd(bar, 1u);
+    int good = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 26) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -7) {
+        atomicExch(info, -7);
+        good = 0;
+        break;
+      }
+    }
+    __threadfence();                                             // acquire: drop stale lines of the vector L1
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+__global__ __launch_bounds__(kBlock) void k_chol_chain(double *__restrict__ A, double *__restrict__ Lf, int ld, int nb,
+                                                       int bw, double *__restrict__ Dinv, int *__restrict__ info,
+                                                       unsigned *__restrict__ bar) {
+  __shared__ double S[3 * kNB * kLdT];
+  const unsigned nwg = gridDim.x * gridDim.y;
+  for (int kb = 0; kb + 1 < nb; ++kb) {
+    const int rest = min(nb - kb - 1, bw);
+    const int ib = kb + 1 + (int)blockIdx.x, jb = kb + 1 + (int)blockIdx.y;
+    if ((int)blockIdx.x < rest && (int)blockIdx.y < rest && jb <= ib) chol_step_body(A, Lf, ld, kb, ib, jb, Dinv, info, S);
+    if (kb + 2 < nb && !chain_barrier(bar, (unsigned)(kb + 1) * nwg, info)) return;
+  }
 }
 
 // W = L^-1 column by column: block column k of W depends on nothing but L, so ONE launch computes all of W with
@@ -461,13 +507,20 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const WT *__re
 // bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
 template <typename WT>
 inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *Dinv, int n, int ld, int *info,
-                                 int bw, hipStream_t s, const std::function<void()> &after_chol = nullptr) {
+                                 int bw, hipStream_t s, const std::function<void()> &after_chol = nullptr,
+                                 unsigned *bar = nullptr) {
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
   hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, 0, Dinv, info);
-  for (int k = 0; k + 1 < nb; ++k) {
-    const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
-    hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
+  const int g = std::min(nb - 1, bw);
+  if (bar && nb > 2 && g * g <= kChainMaxGrid) {   // the band fits the chip: one persistent launch for the whole chain
+    (void)hipMemsetAsync(bar, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_chol_chain, dim3(g, g), dim3(kBlock), 0, s, A, Lf, ld, nb, bw, Dinv, info, bar);
+  } else {
+    for (int k = 0; k + 1 < nb; ++k) {
+      const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
+      hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
+    }
   }
   // after_chol: bulk work of the caller that should NOT run beside this latency-bound chain of dependent launches (every
   // link is slower next to a bandwidth-heavy kernel: measured 44 -> 57 us, also when released at 55 % of the chain) but
