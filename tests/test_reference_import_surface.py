@@ -40,4 +40,14 @@ def test_simulation_example_end_to_end(tmp_path):
     assert np.allclose(L.displacement_vector[L.fixed_DOF], np.where(L.fixed_DOF, model._ubar, 0)[L.fixed_DOF])
     ex = exportSimulationResults(model, "t", out_dir=str(tmp_path))
     ex.export_displacement_rotation()
-    assert os.path.getsize(ex.export_finalize()) > 1000
+    ex.export_reaction_force()
+    path = ex.export_finalize()
+    txt = open(path).read().split("\n")
+    # the file holds the whole penalised model: 166 lattice nodes + 856 penalisation points, 1 288 segments
+    assert "POINTS 1022 double" in txt and "LINES 1288 3864" in txt and "VECTORS displacement double" in txt
+    i0 = txt.index("VECTORS displacement double") + 1
+    disp = np.array([[float(v) for v in ln.split()] for ln in txt[i0:i0 + 1022]])
+    assert np.allclose(disp[:166], model.u[:, :3], rtol=1e-10, atol=1e-14)
+    assert np.abs(disp[166:]).max() > 0.1 * np.abs(disp[:166]).max()       # node_mod points carry real displacements
+    radius = np.array([float(v) for v in txt[txt.index("SCALARS radius double 1") + 2:][:1288]])
+    assert set(np.round(radius, 12)) == {0.1, 0.15}
