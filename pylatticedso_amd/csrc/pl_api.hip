@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 
 #include "../../include/pylattice_hip.h"
 #include "pl_kernels.h"
+#include "pl_parallel.h"
 #include "pl_tile.h"
 #include "pl_dist.h"
 #include "pl_coarse.h"
@@ -1079,10 +1081,9 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
 int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
   const int64_t N = c->N, B = c->B;
   std::vector<int32_t> deg(N, 0);
-  for (int64_t b = 0; b < B; ++b) {
-    deg[conn[2 * b]]++;
-    deg[conn[2 * b + 1]]++;
-  }
+  pl::parallel_for(2 * B, [&](int64_t k0, int64_t k1, unsigned) {
+    for (int64_t k = k0; k < k1; ++k) __atomic_fetch_add(&deg[conn[k]], 1, __ATOMIC_RELAXED);
+  }, 1 << 16);
   std::vector<int64_t> ptr(N + 1, 0);
   for (int64_t i = 0; i < N; ++i) ptr[i + 1] = ptr[i] + deg[i];
   struct E {
@@ -1090,14 +1091,19 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
   };
   std::vector<E> adj((size_t)ptr[N]);
   std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-  for (int64_t b = 0; b < B; ++b) {
-    const int32_t a = conn[2 * b], d = conn[2 * b + 1];
-    adj[fill[d]++] = {a, (int32_t)b};                               // node d is the strut's tip (point2)
-    adj[fill[a]++] = {d, (int32_t)((uint32_t)b | 0x80000000u)};     // node a is point1 -> reversed record
-  }
-  for (int64_t i = 0; i < N; ++i)
-    std::sort(adj.begin() + ptr[i], adj.begin() + ptr[i + 1],
-              [](const E &l, const E &r) { return l.other < r.other || (l.other == r.other && l.code < r.code); });
+  pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {       // any order inside a row: the rows are sorted next
+    for (int64_t b = b0; b < b1; ++b) {
+      const int32_t a = conn[2 * b], d = conn[2 * b + 1];
+      adj[__atomic_fetch_add(&fill[d], (int64_t)1, __ATOMIC_RELAXED)] = {a, (int32_t)b};   // d is the strut's tip (point2)
+      adj[__atomic_fetch_add(&fill[a], (int64_t)1, __ATOMIC_RELAXED)] =                    // a is point1 -> reversed record
+          {d, (int32_t)((uint32_t)b | 0x80000000u)};
+    }
+  }, 1 << 16);
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i)
+      std::sort(adj.begin() + ptr[i], adj.begin() + ptr[i + 1],
+                [](const E &l, const E &r) { return l.other < r.other || (l.other == r.other && l.code < r.code); });
+  });
 
   // sliced ELL: kSliceNodes (16) nodes per slice, width padded to a multiple of kLPN (4) so that one slice is a
   // whole number of 64-entry wave trips
@@ -1118,7 +1124,8 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
   c->nblk = c->h_rowptr[N];
   c->h_col.assign((size_t)c->nblk, 0);
   std::vector<int32_t> ent_slot((size_t)sp[S], 0), diag_slot(N, 0);
-  for (int64_t i = 0; i < N; ++i) {
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+  for (int64_t i = i0; i < i1; ++i) {
     const int64_t s = i / SN, lane = i % SN;
     int slot = 0;
     bool diag_done = false;
@@ -1139,6 +1146,7 @@ int build_incidence(pl_context *c, const std::vector<int32_t> &conn) {
       c->h_col[c->h_rowptr[i] + slot++] = (int32_t)i;
     }
   }
+  });
   c->n_slices = S;
   c->n_ent = sp[S];
   PL_HIP(c->slice_ptr.alloc(S + 1));
@@ -1264,16 +1272,24 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     return fail(PL_ERR_NODEVICE, "pl_create: no HIP device visible (libpylattice_hip has no CPU fallback)");
   if (o->device < 0 || o->device >= ndev) return fail(PL_ERR_ARG, "pl_create: bad device ordinal");
   const int64_t N = m->n_nodes, B = m->n_beams;
-  for (int64_t b = 0; b < B; ++b) {
-    const int32_t a = m->beam_conn[2 * b], d = m->beam_conn[2 * b + 1];
-    if (a < 0 || d < 0 || a >= N || d >= N || a == d)
-      return fail(PL_ERR_ARG, "pl_create: strut " + std::to_string(b) + " has invalid end nodes");
-    if (!(m->beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_create: non-positive radius");
-    const double L = m->seg_len[3 * b] + m->seg_len[3 * b + 1] + m->seg_len[3 * b + 2];
-    if (!(L > 0.0)) return fail(PL_ERR_ARG, "pl_create: strut with zero length");
-    for (int k = 0; k < 3; ++k)
-      if (m->seg_len[3 * b + k] < 0.0 || (m->seg_len[3 * b + k] > 0.0 && m->seg_nsub[3 * b + k] < 1))
-        return fail(PL_ERR_ARG, "pl_create: bad segment data on strut " + std::to_string(b));
+  {
+    std::atomic<int64_t> bad_ends{-1}, bad_radius{-1}, bad_len{-1}, bad_seg{-1};
+    pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+      for (int64_t b = b0; b < b1; ++b) {
+        const int32_t a = m->beam_conn[2 * b], d = m->beam_conn[2 * b + 1];
+        if (a < 0 || d < 0 || a >= N || d >= N || a == d) bad_ends = b;
+        if (!(m->beam_radius[b] > 0.0)) bad_radius = b;
+        const double L = m->seg_len[3 * b] + m->seg_len[3 * b + 1] + m->seg_len[3 * b + 2];
+        if (!(L > 0.0)) bad_len = b;
+        for (int k = 0; k < 3; ++k)
+          if (m->seg_len[3 * b + k] < 0.0 || (m->seg_len[3 * b + k] > 0.0 && m->seg_nsub[3 * b + k] < 1)) bad_seg = b;
+      }
+    });
+    if (bad_ends >= 0)
+      return fail(PL_ERR_ARG, "pl_create: strut " + std::to_string(bad_ends.load()) + " has invalid end nodes");
+    if (bad_radius >= 0) return fail(PL_ERR_ARG, "pl_create: non-positive radius");
+    if (bad_len >= 0) return fail(PL_ERR_ARG, "pl_create: strut with zero length");
+    if (bad_seg >= 0) return fail(PL_ERR_ARG, "pl_create: bad segment data on strut " + std::to_string(bad_seg.load()));
   }
   stage.mark("validate");
   PL_HIP(hipSetDevice(o->device));
@@ -1332,22 +1348,29 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   }
   stage.mark("spatial order");
   c->iperm.resize(N);
-  for (int64_t i = 0; i < N; ++i) c->iperm[c->perm[i]] = (int32_t)i;
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i) c->iperm[c->perm[i]] = (int32_t)i;
+  }, 1 << 16);
   if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1 && o->grid_nodes == 0) {
     // Candidates for exact elimination inside the PCG (opts.condense): a greedy maximal independent set of the node
     // graph (no two share a strut; at least three struts each).  Inside every tile they are numbered LAST, so that the
     // vector kernels, which skip them, skip one contiguous run of rows per tile.
     std::vector<int64_t> aptr((size_t)N + 1, 0);
-    for (int64_t k = 0; k < 2 * B; ++k) aptr[c->iperm[m->beam_conn[k]] + 1]++;
+    pl::parallel_for(2 * B, [&](int64_t k0, int64_t k1, unsigned) {
+      for (int64_t k = k0; k < k1; ++k)
+        __atomic_fetch_add(&aptr[c->iperm[m->beam_conn[k]] + 1], (int64_t)1, __ATOMIC_RELAXED);
+    }, 1 << 16);
     for (int64_t i = 0; i < N; ++i) aptr[i + 1] += aptr[i];
     std::vector<int32_t> adj((size_t)2 * B);
-    {
+    {   // neighbour lists in any order: the greedy passes below only ask whether a neighbour is taken
       std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
-      for (int64_t b = 0; b < B; ++b) {
-        const int32_t u = c->iperm[m->beam_conn[2 * b]], v = c->iperm[m->beam_conn[2 * b + 1]];
-        adj[fill[u]++] = v;
-        adj[fill[v]++] = u;
-      }
+      pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t b = b0; b < b1; ++b) {
+          const int32_t u = c->iperm[m->beam_conn[2 * b]], v = c->iperm[m->beam_conn[2 * b + 1]];
+          adj[__atomic_fetch_add(&fill[u], (int64_t)1, __ATOMIC_RELAXED)] = v;
+          adj[__atomic_fetch_add(&fill[v], (int64_t)1, __ATOMIC_RELAXED)] = u;
+        }
+      }, 1 << 16);
     }
     // two greedy passes: nodes strictly inside the bounding box first, then the ones on it.  Boundary conditions sit
     // on the faces (a node with a Dirichlet dof cannot be eliminated) and face nodes have fewer struts; on BCC this
@@ -1395,28 +1418,37 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
 
   stage.mark("candidates");
   std::vector<double> xyz((size_t)N * 3);
-  for (int64_t i = 0; i < N; ++i) std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i)
+      std::memcpy(&xyz[3 * i], m->node_xyz + 3 * (size_t)c->perm[i], 3 * sizeof(double));
+  });
   std::vector<int32_t> conn((size_t)B * 2);
   {
     std::vector<int32_t> conn0((size_t)B * 2);
-    for (int64_t k = 0; k < 2 * B; ++k) conn0[k] = c->iperm[m->beam_conn[k]];
+    pl::parallel_for(2 * B, [&](int64_t k0, int64_t k1, unsigned) {
+      for (int64_t k = k0; k < k1; ++k) conn0[k] = c->iperm[m->beam_conn[k]];
+    });
     pl::tile_strut_order(conn0, N, B, tile_start, tile_of, c->bperm);
-    for (int64_t b = 0; b < B; ++b) {
-      conn[2 * b] = conn0[2 * (size_t)c->bperm[b]];
-      conn[2 * b + 1] = conn0[2 * (size_t)c->bperm[b] + 1];
-    }
+    pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+      for (int64_t b = b0; b < b1; ++b) {
+        conn[2 * b] = conn0[2 * (size_t)c->bperm[b]];
+        conn[2 * b + 1] = conn0[2 * (size_t)c->bperm[b] + 1];
+      }
+    });
   }
   stage.mark("strut order");
   std::vector<double> radius(B), seg_len((size_t)B * 3);
   std::vector<int32_t> seg_nsub((size_t)B * 3);
-  for (int64_t b = 0; b < B; ++b) {
-    const size_t ob = (size_t)c->bperm[b];
-    radius[b] = m->beam_radius[ob];
-    for (int k = 0; k < 3; ++k) {
-      seg_len[3 * b + k] = m->seg_len[3 * ob + k];
-      seg_nsub[3 * b + k] = m->seg_nsub[3 * ob + k];
+  pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+    for (int64_t b = b0; b < b1; ++b) {
+      const size_t ob = (size_t)c->bperm[b];
+      radius[b] = m->beam_radius[ob];
+      for (int k = 0; k < 3; ++k) {
+        seg_len[3 * b + k] = m->seg_len[3 * ob + k];
+        seg_nsub[3 * b + k] = m->seg_nsub[3 * ob + k];
+      }
     }
-  }
+  });
 
   PL_HIPC(c->xyz.alloc(N * 3));
   PL_HIPC(c->conn.alloc(B * 2));

@@ -26,29 +26,12 @@
 #include <vector>
 
 #include "../../include/pylattice_hip.h"
+#include "pl_parallel.h"
 
 namespace {
 
-unsigned n_workers() {
-  unsigned n = std::thread::hardware_concurrency();
-  return std::max(1u, std::min(n ? n : 4u, 64u));
-}
-
-template <typename F>
-void parallel_for(int64_t n, F &&body, int64_t grain = 1024) {   // body(begin, end, worker)
-  const unsigned W = (unsigned)std::min<int64_t>(n_workers(), std::max<int64_t>(1, n / grain));
-  if (W <= 1) {
-    body((int64_t)0, n, 0u);
-    return;
-  }
-  std::vector<std::thread> th;
-  th.reserve(W);
-  for (unsigned w = 0; w < W; ++w) {
-    const int64_t b = n * w / W, e = n * (w + 1) / W;
-    th.emplace_back([&body, b, e, w]() { body(b, e, w); });
-  }
-  for (auto &t : th) t.join();
-}
+using pl::parallel_for;
+inline unsigned n_workers() { return pl::host_workers(); }
 
 inline int64_t key9(double v) { return (int64_t)std::rint(v * 1e9); }   // np.round(v, 9), as an integer
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "pl_kernels.h"
+#include "pl_parallel.h"
 
 namespace pl {
 
@@ -69,13 +70,25 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
   int64_t *nb = nbrick;
   for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / side));
   std::vector<int64_t> key(N);
-  for (int64_t i = 0; i < N; ++i) {
-    int64_t c[3];
-    for (int k = 0; k < 3; ++k)
-      c[k] = std::max<int64_t>(0, std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / side)));
-    key[i] = (c[0] * nb[1] + c[1]) * nb[2] + c[2];
+  parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i) {
+      int64_t c[3];
+      for (int k = 0; k < 3; ++k)
+        c[k] = std::max<int64_t>(0, std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / side)));
+      key[i] = (c[0] * nb[1] + c[1]) * nb[2] + c[2];
+    }
+  });
+  const int64_t n_keys = nb[0] * nb[1] * nb[2];
+  if (n_keys <= 4 * N + 1024) {   // stable counting sort by brick (the usual case: about N / nodes_per_brick bricks)
+    std::vector<int64_t> start((size_t)n_keys + 1, 0);
+    for (int64_t i = 0; i < N; ++i) start[key[i] + 1]++;
+    for (int64_t q = 0; q < n_keys; ++q) start[q + 1] += start[q];
+    std::vector<int32_t> sorted(N);
+    for (int64_t i = 0; i < N; ++i) sorted[start[key[perm[i]]]++] = perm[i];
+    perm.swap(sorted);
+  } else {
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
   }
-  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
   tile_start.clear();
   tile_brick.clear();
   int64_t run0 = 0;
@@ -144,12 +157,21 @@ inline void tile_strut_order(const std::vector<int32_t> &conn, int64_t N, int64_
     const int32_t pivot = tile_of[d] == home[b] ? d : a;   // an end that lies in the home tile
     occ[b] = cnt[pivot]++;
   }
+  // order by (home tile, occurrence, original index): counting sort into the home tiles, then every tile's short run
+  // sorted on its own - the same permutation as one stable sort of all struts, in O(B) and in parallel
+  std::vector<int64_t> hp(T + 1, 0);
+  for (int64_t b = 0; b < B; ++b) hp[home[b] + 1]++;
+  for (int64_t t = 0; t < T; ++t) hp[t + 1] += hp[t];
   bperm.resize(B);
-  std::iota(bperm.begin(), bperm.end(), 0);
-  std::stable_sort(bperm.begin(), bperm.end(), [&](int32_t l, int32_t r) {
-    if (home[l] != home[r]) return home[l] < home[r];
-    return occ[l] < occ[r];
-  });
+  {
+    std::vector<int64_t> fill(hp.begin(), hp.end() - 1);
+    for (int64_t b = 0; b < B; ++b) bperm[fill[home[b]]++] = (int32_t)b;      // ascending original index inside a tile
+  }
+  parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
+    for (int64_t t = t0; t < t1; ++t)
+      std::stable_sort(bperm.begin() + hp[t], bperm.begin() + hp[t + 1],
+                       [&](int32_t l, int32_t r) { return occ[l] < occ[r]; });
+  }, 16);
 }
 
 // conn must already be in the NEW strut numbering.

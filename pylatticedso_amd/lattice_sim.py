@@ -281,11 +281,17 @@ class LatticeSim(LatticeViews):
         on = ((xyz == lo) | (xyz == hi)).any(axis=1)
         on_box[idx[on]] = True
         # visit order: cell-major, then (round(x,9), round(y,9), round(z,9), index); node index already sorts by xyz
-        order = np.lexsort((idx, cell_of))
-        seq = idx[order]
-        seq = seq[on_box[seq]]
-        _, first = np.unique(seq, return_index=True)
-        visit = seq[np.sort(first)]
+        inside = np.ones(len(idx), bool)
+        inside[ptr[1:-1]] = False                           # first entry of every cell but the first
+        if len(idx) > 1 and not np.all((np.diff(idx) > 0) | ~inside[1:]):
+            idx = idx[np.lexsort((idx, cell_of))]           # rows not yet ascending inside their cell
+        seq = idx[on_box[idx]]
+        # first visit of every node, without sorting: of duplicate targets of a fancy assignment the last one written
+        # stays, so writing the positions in reverse leaves the first one
+        pos = np.arange(len(seq))
+        first = np.full(N, -1, np.int64)
+        first[seq[::-1]] = pos[::-1]
+        visit = seq[first[seq] == pos]
         self.index_boundary[visit] = np.arange(len(visit))
         self.max_index_boundary = len(visit) - 1
         self._boundary_visit_order = visit
