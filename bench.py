@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--condense", type=int, default=0,
                     help="exact elimination of an independent node set inside the PCG: 0 = automatic (bipartite node "
                          "graphs such as BCC), 1 = whenever possible, -1 = never (see pylattice_hip.h)")
+    ap.add_argument("--cg-form", type=int, default=0,
+                    help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
+                         "vectors); 0 = ordinary form")
     ap.add_argument("--precision", type=int, default=0,
                     help="0 = fp64 (headline), 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only")
     ap.add_argument("--cpu-cells", type=int, default=36,
@@ -241,7 +244,7 @@ def main():
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
                            tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision,
-                           condense=args.condense)
+                           condense=args.condense, cg_form=args.cg_form)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world
@@ -378,6 +381,7 @@ def main():
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"], "precision": args.precision,
                    "inner_solves": st.get("restarts", 0.0), "condensed_nodes": int(st.get("condensed_nodes", 0)),
+                   "cg_form": int(st.get("cg_form_used", 0)),
                    "preconditioner": {1: "Jacobi", 2: "two-level (Jacobi + rigid-body coarse space)",
                                       3: "multi-level (Jacobi + tile blocks + dense rigid-body coarse space)",
                                       4: "multi-level (Jacobi + tile blocks + rank-local dense level + all-reduced "

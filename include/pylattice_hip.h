@@ -105,7 +105,9 @@ typedef struct {
                               column instead of one launch per block column.  Measured slower (2.94 vs 2.86 ms per
                               assembly at 50^3 Octet): the release / acquire fences of a barrier across the 8 XCDs cost
                               what the kernel boundary costs - kept as an experiment switch */
-  int32_t reserved3;
+  int32_t cg_form;       /* multi-level PCG (precond 2 / 3, fp64, no node elimination): 1 = single-reduction form (Chronopoulos-
+                          * Gear recurrences, the dense level's residual carried by recurrence): ONE all-reduce per iteration on
+                          * several GPUs instead of three exchanges, for three more stored vectors.  0 = ordinary form. */
 } pl_opts_t;
 
 typedef struct {
@@ -124,7 +126,8 @@ typedef struct {
                               1 not converged, 2 not converged and a step length fell below 1e-6 */
   double stop_reason;      /* which test ended a converged solve: 0 ||r|| <= rtol ||b||, 1 direction norm (mintol) */
   double condensed_nodes;  /* nodes eliminated exactly inside the solve (opts.condense) */
-  double reserved[2];
+  double cg_form_used;     /* 1: the solve ran in the single-reduction form (opts.cg_form) */
+  double reserved[1];
 } pl_stats_t;
 
 void pl_default_opts(pl_opts_t *o);

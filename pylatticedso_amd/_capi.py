@@ -40,7 +40,7 @@ class PlOpts(C.Structure):
                 ("local_max_dofs", C.c_int32), ("precision", C.c_int32), ("restart_every", C.c_int32),
                 ("alpha_max", C.c_double), ("grid_lo", C.c_double * 3), ("grid_hi", C.c_double * 3),
                 ("grid_nodes", C.c_int64), ("mintol", C.c_double), ("compact_records", C.c_int32),
-                ("condense", C.c_int32), ("chol_persistent", C.c_int32), ("reserved3", C.c_int32)]
+                ("condense", C.c_int32), ("chol_persistent", C.c_int32), ("cg_form", C.c_int32)]
 
 
 class PlStats(C.Structure):
@@ -48,7 +48,8 @@ class PlStats(C.Structure):
                 ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
                 ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("restarts", C.c_double),
                 ("precision_used", C.c_double), ("info", C.c_double), ("stop_reason", C.c_double),
-                ("condensed_nodes", C.c_double), ("reserved", C.c_double * 2)]
+                ("condensed_nodes", C.c_double), ("cg_form_used", C.c_double),
+                ("reserved", C.c_double * 1)]
 
 
 class PlError(RuntimeError):
@@ -190,7 +191,8 @@ class HipLattice:
 
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
                  pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=0, lanes_per_node=0, tile_nodes=0, precond=1,
-                 coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0, precision=0, compact_records=0, condense=0, chol_persistent=0):
+                 coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0, precision=0, compact_records=0, condense=0, chol_persistent=0,
+                 cg_form=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -213,6 +215,7 @@ class HipLattice:
         opts.compact_records = compact_records
         opts.condense = condense
         opts.chol_persistent = chol_persistent
+        opts.cg_form = cg_form
         opts.precision = precision            # 0 fp64, 1 fp32 inner PCG + fp64 refinement, 2 fp32 p / K*p only
         if grid is not None:                       # (lo[3], hi[3], n_nodes) of the whole lattice (multi-GPU)
             lo, hi, nn = grid

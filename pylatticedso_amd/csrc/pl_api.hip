@@ -19,6 +19,7 @@
 #include "pl_tile.h"
 #include "pl_dist.h"
 #include "pl_coarse.h"
+#include "pl_cg1.h"
 #include "pl_palette.h"
 #include "pl_ddm.h"
 #include "pl_lzone.h"
@@ -110,6 +111,7 @@ struct pl_context {
   DevBuf<double> ubar, f;
   // solver state
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
+  DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
   int hist_cap = 0;
   // LDS-tile operator
   pl::TilePlan tile;
@@ -249,7 +251,7 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
-                const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
+                const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll, bool reduce_dot = true) {
   const int kind = choose_kernel(c);
   if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0) {
     // tile kernel with a caller-chosen row mask and / or only one kind of strut ends (node elimination)
@@ -318,7 +320,9 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     // Every rank now holds the product of ITS struts.  The Dirichlet mask commutes with the sum over ranks, and
     // x.(K x) = sum_r x_r.(K_r x_r) with the LOCAL partial products and NO multiplicity weights, so the kernels above
     // ran exactly as on one GPU; the interface rows and the 32 slots of the partial dot travel in one all-reduce.
-    int rc = pl::dist_sum_shared(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
+    // (reduce_dot = false: the caller sums the dot slots in a collective of its own - single-reduction PCG)
+    const bool with_dot = dot_dev && reduce_dot;
+    int rc = pl::dist_sum_shared(c->dist, y, c->stream, with_dot ? dot_dev : nullptr, with_dot ? pl::kSlots : 0);
     if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
   }
   PL_HIP(hipGetLastError());
@@ -886,6 +890,141 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
     PL_HIP(hipGetLastError());
   }
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Single-reduction PCG (opts.cg_form = 1; pl_cg1.h): u -> z, w -> Ap, s -> tmp2.
+// ----------------------------------------------------------------------------------------------------------
+inline bool cg1_applies(const pl_context *c) {
+  return c->opt.cg_form == 1 && c->coarse.ready && !c->coarseL.ready && !c->cond_use && c->opt.precision == 0 &&
+         c->opkind == 0 && c->tile.ready && choose_kernel(c) == 3;
+}
+
+int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+                  pl_stats_t *st) {
+  const int64_t n6 = c->N * 6;
+  pl::Coarse &cs = c->coarse;
+  const int ncp = cs.ncp, bs = pl::cg1_block_size(ncp);
+  int rc = ensure_hist(c, max_iter + 2);
+  if (rc) return rc;
+  const size_t need = 2 * (size_t)bs + 2 * pl::kSlots + 4 + (size_t)ncp;
+  if (!c->cg1.p || c->cg1.n < need) PL_HIP(c->cg1.alloc(need));
+  double *blk[2] = {c->cg1.p, c->cg1.p + bs};
+  double *gc[2] = {c->cg1.p + 2 * bs, c->cg1.p + 2 * bs + pl::kSlots};
+  double *stt[2] = {c->cg1.p + 2 * bs + 2 * pl::kSlots, c->cg1.p + 2 * bs + 2 * pl::kSlots + 2};
+  double *sc = c->cg1.p + 2 * bs + 2 * pl::kSlots + 4;
+  double *u = c->z.p, *w = c->Ap.p, *s = c->tmp2.p;
+  const double *wt = c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr;
+  const uint8_t *shared = c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr;
+  const double *Bt = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
+  const double *yt = cs.tile_level ? (const double *)cs.yt : (const double *)nullptr;
+  const dim3 gt((unsigned)cs.n_tiles), blkdim(pl::kBlock);
+
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->cg1.p, 0, need * sizeof(double), c->stream));
+  // r0 = P (f - K ubar), x = 0, ||b||^2 (the z / p the init kernel also writes are overwritten below)
+  if (c->dist.active)
+    pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
+                                 c->z.p, c->p.p, c->scal.p, c->stream);
+  else
+    hipLaunchKernelGGL(pl::k_pcg_init, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
+  PL_HIP(hipMemsetAsync(c->p.p, 0, n6 * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(s, 0, n6 * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(cs.rc, 0, (size_t)ncp * sizeof(double), c->stream));
+
+  // u = M^-1 r, w = K u and the reduction block of iteration k (k = -1: the pass that prepares iteration 0)
+  auto second_half = [&](int k) -> int {
+    const int cur = k & 1, nxt = (k + 1) & 1;
+    pl::dense_apply(cs.W, cs.Wt, ncp, ncp, cs.rc, cs.tv, cs.yc, gc[nxt], (const double *)nullptr, c->stream);
+    hipLaunchKernelGGL(pl::k_cg1_precond, gt, blkdim, 0, c->stream, c->tile.tile_start.p, (const double *)c->r.p,
+                       cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc, yt, c->fixedbits.p, shared, u,
+                       k >= 0 ? blk[cur] : (double *)nullptr, bs, k >= 0 ? gc[cur] : (double *)nullptr);
+    int r2 = launch_spmv(c, u, w, true, blk[nxt] + ncp, nullptr, pl::kEndsAll, false);
+    if (r2) return r2;
+    hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                       c->xyz.p, (const double *)w, wt, blk[nxt]);
+    if (c->dist.active && pl::dist_sum_scalars(c->dist, blk[nxt], bs, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the single-reduction PCG failed");
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  };
+  // Z^T r0 (summed over ranks once), tile level and partial sums of r0 into block 0, then u0, w0
+  hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                     c->xyz.p, (const double *)c->r.p, wt, cs.rc);
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, cs.rc, ncp, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of the initial coarse residual failed");
+  hipLaunchKernelGGL(pl::k_cg1_update<true>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                     c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p, c->r.p,
+                     (const double *)blk[1], (const double *)gc[1], (const double *)stt[1], stt[0], blk[0], Bt, cs.yt,
+                     shared, cs.rc, sc, ncp, c->hist.p, -1);
+  rc = second_half(-1);
+  if (rc) return rc;
+
+  double h_scal[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p + pl::S_BB * pl::kSlots, sizeof(h_scal), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  double bb = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) bb += h_scal[k];
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  st->info = 1.0;
+  if (!(bb > 0.0)) {
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  const bool adaptive = c->opt.check_every <= 0;
+  const int chunk = adaptive ? 32 : c->opt.check_every;
+  std::vector<double> h_hist(chunk);
+  int k = 0, next = chunk, k_prev = 0;
+  double rr_prev = bb;
+  // hist[k] = ||r_k||^2, the residual BEFORE update k (it is reduced together with that iteration's other sums)
+  while (k < max_iter + 1) {
+    const int todo = std::min(next, max_iter + 1 - k);
+    for (int j = 0; j < todo; ++j) {
+      const int it = k + j, cur = it & 1, nxt = (it + 1) & 1;
+      hipLaunchKernelGGL(pl::k_cg1_update<false>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p,
+                         cs.cen.p, c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p,
+                         c->r.p, (const double *)blk[cur], (const double *)gc[cur], (const double *)stt[cur], stt[nxt],
+                         blk[nxt], Bt, cs.yt, shared, cs.rc, sc, ncp, c->hist.p, it);
+      rc = second_half(it);
+      if (rc) return rc;
+    }
+    PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < todo; ++j) {
+      const double rr = h_hist[j];
+      if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+      if (!st->converged) st->rel_residual = std::sqrt(rr / bb);
+      if (rr <= thresh && !st->converged) {
+        st->converged = 1;
+        st->iterations = k + j;      // updates applied when this residual was reached (x has had a few more since)
+        st->info = 0.0;
+        st->stop_reason = 0.0;
+      }
+    }
+    k += todo;
+    if (st->converged) break;
+    if (adaptive) {
+      const double rr_end = h_hist[todo - 1];
+      next = chunk;
+      if (rr_end < rr_prev && rr_end > thresh) {
+        const double per_it = std::log(rr_end / rr_prev) / (double)(k - k_prev);
+        const double need_it = std::log(thresh / rr_end) / per_it;
+        if (need_it < 2.0 * chunk) next = std::max(2, std::min(chunk, (int)std::ceil(0.75 * need_it) + 1));
+      }
+      rr_prev = rr_end;
+      k_prev = k;
+    }
+  }
+  if (!st->converged) st->iterations = std::min(k, max_iter);
   return PL_OK;
 }
 
@@ -2014,8 +2153,11 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   // fp32 solver modes need the multi-level preconditioner on the tile kernel; anything else runs the fp64 PCG
   const bool mp = h->opt.precision != 0 && h->opkind == 0 && h->coarse.ready && choose_kernel(h) == 3 && h->tile.ready;
   h->cond_use = h->cond_ready && h->coarse.ready && h->opkind == 0 && choose_kernel(h) == 3 && h->tile.ready &&
-                (!mp || h->opt.precision == 1);
-  if (mp && h->opt.precision == 1) rc = pcg_solve_mp_t<float>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+                (!mp || h->opt.precision == 1) && h->opt.cg_form != 1;
+  const bool cg1 = !mp && cg1_applies(h);
+  st.cg_form_used = cg1 ? 1.0 : 0.0;
+  if (cg1) rc = pcg_solve_cg1(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
+  else if (mp && h->opt.precision == 1) rc = pcg_solve_mp_t<float>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   else if (mp) rc = pcg_solve_mp_t<double>(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;

@@ -360,6 +360,16 @@ def test_rccl_path_with_single_rank_communicator(golden_dir):
         dev.assemble()
         u3, st3 = dev.solve(rtol=1e-11)
     assert _rel(u3, u0) < 1e-8 and st3["converged"] == 1
+    # ... and in the single-reduction form (one all-reduce per iteration: opts.cg_form = 1), with the neighbour exchange
+    # as well (the rank is its own neighbour: shared rows come back doubled, so the weights are 1/2 and the assembled
+    # operator is the plain one only if every shared row is halved first - here only the all-reduce variant is compared)
+    with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, grid=grid, cg_form=1) as dev:
+        dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        u5, st5 = dev.solve(rtol=1e-11)
+    assert _rel(u5, u0) < 1e-8 and st5["converged"] == 1 and int(st5["cg_form_used"]) == 1
+    assert st5["iterations"] <= st3["iterations"] + 2
     # ... and with the rank-local dense level under a coarser global one (precond = 4, what bench.py uses for N > 1):
     # shared nodes are left out of the local level, nothing of it is communicated
     with _device(L, precond=4, tile_nodes=32, coarse_max_dofs=100, local_max_dofs=600, grid=grid) as dev:
@@ -569,6 +579,64 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
                 uref2 = O.solve_dirichlet(K, L.fixed_DOF, 0 * ubar, np.where(L.fixed_DOF, 0.0, 2.0 * f)).reshape(-1, 6)
                 assert _rel(u2, uref2) < 1e-8
     assert its[1] <= its[-1]
+
+
+@pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "octet_3x2x2_size",
+                                  "bcchybrid1hybrid4_3x2x1_size"])
+def test_single_reduction_pcg_matches_oracle(golden_dir, name):
+    """opts.cg_form = 1 (Chronopoulos-Gear recurrences, the dense level's residual carried by recurrence - one all-reduce
+    per iteration on several GPUs): same solution as the oracle's direct solve and as the ordinary form, prescribed
+    displacements included; the iteration count may differ by the one-iteration lag of the residual norm."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    res = {}
+    for form in (0, 1):
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=-1, cg_form=form) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st["converged"] == 1 and int(st["cg_form_used"]) == form
+            assert _rel(u, uref) < 1e-8
+            res[form] = (u, st["iterations"])
+            if form == 1:                                                # a second solve on the same handle
+                dev.set_bc(L.fixed_DOF, None, 2.0 * f)
+                u2, _ = dev.solve(rtol=1e-11, max_iter=20000)
+                uref2 = O.solve_dirichlet(K, L.fixed_DOF, 0 * ubar, np.where(L.fixed_DOF, 0.0, 2.0 * f)).reshape(-1, 6)
+                assert _rel(u2, uref2) < 1e-8
+    assert _rel(res[1][0], res[0][0]) < 1e-8
+    assert res[1][1] <= res[0][1] * 1.03 + 2
+
+
+def test_single_reduction_pcg_at_scale():
+    """24^3 Octet cantilever with the bench's solver settings: both CG forms reach the same displacements (1e-8) and
+    the single-reduction form needs at most 3 % + 1 more iterations."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 24
+    lat = LA.generate((1, 1, 1), (n, n, n), ["Octet"], [0.03])
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == float(n)
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    out = {}
+    for form in (0, 1):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, palette=1, cg_form=form) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=5000)
+            assert st["converged"] == 1 and int(st["cg_form_used"]) == form
+            r = np.where(fixed, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(f)
+            out[form] = (u, st["iterations"])
+    assert _rel(out[1][0], out[0][0]) < 1e-8
+    assert out[1][1] <= out[0][1] * 1.03 + 1
 
 
 @pytest.mark.parametrize("precision", [1, 2])
