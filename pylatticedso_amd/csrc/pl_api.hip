@@ -658,7 +658,7 @@ template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream,
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
@@ -675,7 +675,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cs.rc + cs.ncp + pl::kSlots, c->stream);
-  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, c->stream,
+  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream,
                      c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
                      cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur,
                      nxt,
@@ -919,7 +919,7 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
   const uint8_t *shared = c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr;
   const double *Bt = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
   const double *yt = cs.tile_level ? (const double *)cs.yt : (const double *)nullptr;
-  const dim3 gt((unsigned)cs.n_tiles), blkdim(pl::kBlock);
+  const dim3 gt((unsigned)cs.n_tiles), blkdim(cs.vblock);
 
   PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
   PL_HIP(hipMemsetAsync(c->cg1.p, 0, need * sizeof(double), c->stream));
@@ -1398,6 +1398,14 @@ void pl_default_opts(pl_opts_t *o) {
   o->check_every = 0;   // adaptive
 }
 
+namespace {
+// dofs the dense level may have (see the comment at its set-up in pl_create)
+inline int coarse_budget(const pl_opts_t *o, int64_t N) {
+  const bool multi_rank = o->grid_nodes > 0;
+  return o->coarse_max_dofs > 0 ? o->coarse_max_dofs : ((multi_rank || N >= 1000000) ? 3072 : 2100);
+}
+}  // namespace
+
 int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (!m || !o || !out) return fail(PL_ERR_ARG, "pl_create: null argument");
   StageTimer stage("pl_create");
@@ -1480,7 +1488,8 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (o->reorder == 1) {
     pl::spatial_order(m->node_xyz, N, c->perm, tile_start,
                       (double)(o->tile_nodes > 0 ? std::min(o->tile_nodes, pl::kTileMaxNodes) : 256), tile_brick,
-                      grid, o->grid_nodes > 0 ? global_grid : nullptr);
+                      grid, o->grid_nodes > 0 ? global_grid : nullptr,
+                      (o->precond >= 2 && o->precond <= 4) ? coarse_budget(o, N) : 0);
     c->reordered = true;
   } else {
     pl::chunk_tiles(N, tile_start);
@@ -1618,7 +1627,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     // 50^3 Octet: 7^3 aggregates 18.9 ms per step, 8^3 20.7 ms), beyond that and in multi-rank runs (collectives in
     // every iteration) the full 3 072
     const bool multi_rank = o->grid_nodes > 0;
-    const int max_dofs = o->coarse_max_dofs > 0 ? o->coarse_max_dofs : ((multi_rank || N >= 1000000) ? 3072 : 2100);
+    const int max_dofs = coarse_budget(o, N);
     int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn, false, multi_rank);
     if (rc == 4)
       return bail(fail(PL_ERR_ARG, "pl_create: a strut spans more than neighbouring aggregates; the band-packed "

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_restrict(const int32_t *__restri
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     double vv[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_restrict(const int32_t *__restri
     acc[4] += vv[4] + (rz * vv[0] - rx * vv[2]);
     acc[5] += vv[5] + (rx * vv[1] - ry * vv[0]);
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const double s = wave_sum(acc[k]);
@@ -70,8 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_restrict(const int32_t *__restri
   __syncthreads();
   if (threadIdx.x < 6) {
     double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
+    for (int q = 0; q < nw; ++q) s += red[threadIdx.x][q];
     unsafeAtomicAdd(out + 6 * a + threadIdx.x, s);
   }
 }
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
     }
     alpha = (den != 0.0) ? gamma / den : 0.0;
     if (t == 0) {   // dense level by recurrence (replicated on every rank), history, state of the next iteration
-      for (int e = threadIdx.x; e < ncp; e += kBlock) {
+      for (int e = threadIdx.x; e < ncp; e += blockDim.x) {
         const double sv = blk[e] + beta * sc[e];
         sc[e] = sv;
         rc[e] -= alpha * sv;
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
     for (int j = 0; j < 6; ++j) bi[j] = Bt_inv[(size_t)t * 36 + 6 * threadIdx.x + j];
   }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0-5 tile restriction (nodes of this rank alone), 6 r.r, 7 r.D^-1 r
-  for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     double rv[6], dv[6];
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
 #pragma unroll
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
       acc[5] += rv[5] + (rx * rv[1] - ry * rv[0]);
     }
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const double v = wave_sum(acc[q]);
@@ -189,8 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
   if (threadIdx.x < 8) {
     double *gam_slot = blk_nxt + ncp + kSlots + (blockIdx.x & (kSlots - 1)), *rr_slot = gam_slot + kSlots;
     double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < kBlock / kWave; ++q) v += red[threadIdx.x][q];
+    for (int q = 0; q < nw; ++q) v += red[threadIdx.x][q];
     if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, v);
     if (!Bt_inv) {
       if (threadIdx.x == 7) unsafeAtomicAdd(gam_slot, v);
@@ -224,8 +222,9 @@ __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restric
                                                         double *__restrict__ u, double *__restrict__ clear, int n_clear,
                                                         double *__restrict__ clear2) {
   if (clear && (blockIdx.x == 1 || gridDim.x == 1))
-    for (int e = threadIdx.x; e < n_clear; e += kBlock) clear[e] = 0.0;
-  if (clear2 && blockIdx.x == 0 && threadIdx.x < kSlots) clear2[threadIdx.x] = 0.0;
+    for (int e = threadIdx.x; e < n_clear; e += blockDim.x) clear[e] = 0.0;
+  if (clear2 && blockIdx.x == 0)
+    for (int e = threadIdx.x; e < kSlots; e += blockDim.x) clear2[e] = 0.0;
   const int t = blockIdx.x;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restric
   }
   const bool own_t = yt && shared;   // several GPUs: nodes shared with other ranks are left out of the tile level
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
+  for (int64_t i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     if (own_t && !shared[i]) {

@@ -37,6 +37,7 @@ struct Coarse {
   int n_agg = 0, nc = 0, ncp = 0;   // ncp = nc rounded up to the dense block size (padding rows are identity)
   int bw_blocks = 0;                // block bandwidth of A_c (aggregates couple to their 26 neighbours only)
   int64_t n_tiles = 0;
+  int vblock = kBlock;     // threads per workgroup of the per-tile vector kernels: the longest tile rounded up to whole waves
   TBuf<int32_t> agg_of_node, agg_of_tile;
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
@@ -96,6 +97,8 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   for (int step = 0;; ++step) {
     const double scale = 1.5 + 0.125 * step;       // bricks per aggregate and axis, at least 1.5
     for (int k = 0; k < 3; ++k) na[k] = std::max<int64_t>(1, (int64_t)std::floor((double)nbrick[k] / scale));
+    if (!local && step == 0 && grid.na[0] > 0 && 6 * grid.na[0] * grid.na[1] * grid.na[2] <= max_dofs)
+      for (int k = 0; k < 3; ++k) na[k] = grid.na[k];   // the aggregate grid the bricks were cut to fit (spatial_order)
     int64_t count = na[0] * na[1] * na[2];
     if (local) {
       used.clear();
@@ -117,7 +120,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     ai[ax[2]] = ga % na[ax[2]];
     for (int k = 0; k < 3; ++k) {   // centre of the aggregate's range of bricks
       const int64_t b_lo = (ai[k] * nbrick[k] + na[k] - 1) / na[k], b_hi = ((ai[k] + 1) * nbrick[k] + na[k] - 1) / na[k];
-      cen[3 * a + k] = grid.lo[k] + 0.5 * (double)(b_lo + b_hi) * grid.side;
+      cen[3 * a + k] = grid.lo[k] + 0.5 * (double)(b_lo + b_hi) * grid.side[k];
     }
   }
   for (int64_t t = 0; t < T; ++t) {
@@ -133,6 +136,11 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   c.n_agg = n_agg;
   c.nc = 6 * n_agg;
   c.n_tiles = T;
+  {
+    int longest = 1;
+    for (int64_t t = 0; t < T; ++t) longest = std::max(longest, (int)(tile_start[t + 1] - tile_start[t]));
+    c.vblock = std::min(kBlock, (longest + kWave - 1) / kWave * kWave);
+  }
   {
     // aggregate-crossing struts, grouped by ordered aggregate pair: a wave of the assembly kernel then works on ONE
     // coarse block and can reduce in registers before touching memory
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   double accL[6] = {0, 0, 0, 0, 0, 0};
   double accT[6] = {0, 0, 0, 0, 0, 0};      // tile level on several GPUs: the tile's restriction without shared nodes
   const bool own_t = Bt_inv && shared;
-  for (int i = n0 + threadIdx.x; i < n1; i += kBlock) {
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     if (skip_rows && skip_rows[i]) continue;    // eliminated node (opts.condense): not an unknown of this CG
     // (x += alpha p is done by k_pcg_direction_coarse, which reads p anyway: one vector pass less per iteration)
     double av[6], dv[6], rv[6];
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       accL[5] += rv[5] + (sx * rv[1] - sy * rv[0]);
     }
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;   // 1 to 4 waves per tile
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const double s = wave_sum(acc[k]);
@@ -675,17 +683,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     }
   }
   __syncthreads();
-  if (aggL_of_tile && threadIdx.x >= kWave && threadIdx.x < kWave + 6) {   // wave 1 publishes the local restriction
-    const int k = threadIdx.x - kWave;
+  const int pubL = nw > 1 ? kWave : 8;   // wave 1 publishes the local restriction (lanes 8..13 of wave 0 if it is alone)
+  if (aggL_of_tile && (int)threadIdx.x >= pubL && (int)threadIdx.x < pubL + 6) {
+    const int k = threadIdx.x - pubL;
     double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < kBlock / kWave; ++q) s += red[8 + k][q];
+    for (int q = 0; q < nw; ++q) s += red[8 + k][q];
     unsafeAtomicAdd(rcL + 6 * aL + k, s);
   }
   if (threadIdx.x < 8) {
     double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < kBlock / kWave; ++q) s += red[threadIdx.x][q];
+    for (int q = 0; q < nw; ++q) s += red[threadIdx.x][q];
     // r_c is zeroed by the previous direction kernel; ~8 tiles add into each aggregate's six entries
     if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
     else if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, s);
@@ -697,8 +704,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (own_t) {
         st = 0.0;
         if (threadIdx.x < 6) {
-#pragma unroll
-          for (int q = 0; q < kBlock / kWave; ++q) st += red[14 + threadIdx.x][q];
+          for (int q = 0; q < nw; ++q) st += red[14 + threadIdx.x][q];
         }
       }
       double tj[6];
@@ -895,21 +901,22 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   const double pap = scalar_read(scal, S_PAP);
   const double alpha = (pap != 0.0) ? old / pap : 0.0;      // the step k_pcg_update_tile took: x += alpha p_old here
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
-    for (int e = threadIdx.x; e < ncp; e += kBlock) rc[e] = 0.0;
+    for (int e = threadIdx.x; e < ncp; e += blockDim.x) rc[e] = 0.0;
   if (aggL_of_tile && (blockIdx.x == 2 || gridDim.x <= 2))
-    for (int e = threadIdx.x; e < ncpL; e += kBlock) rcL[e] = 0.0;
+    for (int e = threadIdx.x; e < ncpL; e += blockDim.x) rcL[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
     const int s = threadIdx.x;
-    double rr = (s < kSlots) ? rc[ncp + s] : 0.0;            // ||r||^2 slots in the tail of r_c (this wave alone
-#pragma unroll                                                // reads and then clears the tail)
+    double rr = 0.0;                                          // ||r||^2 slots in the tail of r_c (this wave alone
+    for (int q = s; q < kSlots; q += kWave) rr += rc[ncp + q];   // reads and then clears the tail)
+#pragma unroll
     for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o, 64);
     if (s == 0) hist[k] = rr;
-    if (s < kSlots) {
-      rc[ncp + s] = 0.0;
-      rc[ncp + kSlots + s] = 0.0;
-      scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
-      scal_next[S_RZ_NEW * kSlots + s] = 0.0;
-      scal_next[S_PAP * kSlots + s] = 0.0;
+    for (int q = s; q < kSlots; q += kWave) {
+      rc[ncp + q] = 0.0;
+      rc[ncp + kSlots + q] = 0.0;
+      scal_next[S_RZ_OLD * kSlots + q] = scal[S_RZ_NEW * kSlots + q];
+      scal_next[S_RZ_NEW * kSlots + q] = 0.0;
+      scal_next[S_PAP * kSlots + q] = 0.0;
     }
   }
   const int t = blockIdx.x;
@@ -937,7 +944,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     l1 = cenL[3 * aL + 1];
     l2 = cenL[3 * aL + 2];
   }
-  for (int64_t i = n0 + threadIdx.x; i < n1; i += kBlock) {
+  for (int64_t i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     if (zero_rows && zero_rows[i]) {   // eliminated node: only clear its row of p (the next first pass wants zeros there)
 #pragma unroll
       for (int q = 0; q < 3; ++q) store_pair(p, 3 * i + q, double2{0.0, 0.0});

@@ -479,13 +479,16 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv(int n, const WT *__restrict
     }
   }
   if (dot_out) {
+    double extra = 0.0;
+    if (blockIdx.x == 0 && add0 && wv == 0) {              // add0 = a slotted scalar (e.g. r.D^-1 r), summed by wave 0
+      for (int q = lane; q < kSlots; q += kWave) extra += add0[q];
+      extra = wave_sum(extra);
+    }
     if (lane == 0) red[wv] = sq;
     __syncthreads();
     if (threadIdx.x == 0) {
-      double s = 0.0;
+      double s = extra;
       for (int q = 0; q < kBlock / kWave; ++q) s += red[q];
-      if (blockIdx.x == 0 && add0)
-        for (int q = 0; q < kSlots; ++q) s += add0[q];     // add0 = a slotted scalar (e.g. r.D^-1 r)
       unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
     }
   }

@@ -7,7 +7,7 @@ namespace pl {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kDefaultLPN = 4;          // lanes per node in the gather kernels (64 / LPN nodes per wave / ELL slice)
-constexpr int kSlots = 32;              // every device-side reduction scalar is spread over 32 atomics targets:
+constexpr int kSlots = 64;              // every device-side reduction scalar is spread over 64 atomics targets:
                                         // 2000+ blocks adding into ONE address serialise at the memory side
 
 // blockIdx -> logical block so that each of the 8 XCDs (blocks are dealt round-robin, b and b+8 share an XCD and
@@ -32,7 +32,9 @@ __device__ __forceinline__ void scalar_add(double *scal, int which, double v) {
 // Every lane of the calling wave gets the total.
 __device__ __forceinline__ double scalar_read(const double *scal, int which) {
   const int lane = threadIdx.x & 63;
-  double v = (lane < kSlots) ? scal[which * kSlots + lane] : 0.0;
+  double v = 0.0;
+#pragma unroll
+  for (int s = lane; s < kSlots; s += 64) v += scal[which * kSlots + s];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -472,14 +474,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const doub
         hist[3 * hist_cap + k] = scal[S_ALPHA * kSlots];
       }
     }
-    if (s < kSlots) {
-      scal_next[S_RZ_OLD * kSlots + s] = scal[S_RZ_NEW * kSlots + s];
-      scal_next[S_RZ_NEW * kSlots + s] = 0.0;
-      scal_next[S_RR * kSlots + s] = 0.0;
-      scal_next[S_PAP * kSlots + s] = 0.0;
+    for (int q = s; q < kSlots; q += kWave) {
+      scal_next[S_RZ_OLD * kSlots + q] = scal[S_RZ_NEW * kSlots + q];
+      scal_next[S_RZ_NEW * kSlots + q] = 0.0;
+      scal_next[S_RR * kSlots + q] = 0.0;
+      scal_next[S_PAP * kSlots + q] = 0.0;
       if (hist_cap > 0) {
-        scal_next[S_PP * kSlots + s] = 0.0;
-        scal_next[S_XX * kSlots + s] = 0.0;
+        scal_next[S_PP * kSlots + q] = 0.0;
+        scal_next[S_XX * kSlots + q] = 0.0;
       }
     }
   }

@@ -32,15 +32,16 @@ constexpr int kTileMaxNodes = 512;   // LDS accumulator: 512 nodes * 6 * 8 B = 2
 // kTileMaxNodes are cut), ending with N.
 struct BrickGrid {
   double lo[3] = {0, 0, 0};
-  double side = 1.0;
+  double side[3] = {1.0, 1.0, 1.0};   // per axis: the box is cut into equal bricks
   int64_t nb[3] = {1, 1, 1};
+  int64_t na[3] = {0, 0, 0};          // aggregate grid the bricks were fitted to (0: none - coarse_setup chooses)
 };
 
 // If `global` is non-null it holds {lo[3], hi[3], node count} of the WHOLE lattice (multi-GPU: every rank must cut
 // the same grid); otherwise the grid is derived from these nodes.
 inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &perm, std::vector<int32_t> &tile_start,
                           double nodes_per_brick, std::vector<int64_t> &tile_brick, BrickGrid &grid,
-                          const double *global = nullptr) {
+                          const double *global = nullptr, int agg_max_dofs = 0) {
   int64_t *nbrick = grid.nb;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   int64_t Ntot = N;
@@ -65,16 +66,54 @@ inline void spatial_order(const double *xyz, int64_t N, std::vector<int32_t> &pe
       ++dims;
     }
   const double side = dims ? std::pow(vol * nodes_per_brick / (double)std::max<int64_t>(Ntot, 1), 1.0 / dims) : 1.0;
-  grid.side = side;
+  // equal bricks per axis (the count that comes closest to the cubic target): a thin leftover layer of bricks at the far
+  // faces would give the tile level and the dense level starved blocks there (measured: iteration counts jumping by
+  // 15 % with the target size)
   for (int k = 0; k < 3; ++k) grid.lo[k] = lo[k];
   int64_t *nb = nbrick;
-  for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / side));
+  double sk[3];
+  for (int k = 0; k < 3; ++k) nb[k] = std::max<int64_t>(1, (int64_t)std::llround((hi[k] - lo[k]) / side));
+  if (agg_max_dofs > 0 && dims > 0) {
+    // Multi-level preconditioner: fit the bricks (tile level) INTO the aggregates of the dense level - equal aggregates,
+    // each a whole number (>= 2 per axis) of equal bricks.  With independent grids 13 bricks per axis fall into 7 aggregates
+    // as 2,2,2,2,2,2,1: measured 116 iterations at 50^3 Octet against 106 with 14 = 7 x 2.
+    // Aggregate edge: the smallest one whose grid fits the dof budget.
+    double a = 1.5 * side;
+    int64_t na[3] = {1, 1, 1};
+    for (int it = 0; it < 4000; ++it, a *= 1.01) {
+      int64_t count = 1;
+      for (int k = 0; k < 3; ++k) {
+        na[k] = (hi[k] - lo[k]) > 0 ? std::max<int64_t>(1, (int64_t)std::llround((hi[k] - lo[k]) / a)) : 1;
+        count *= na[k];
+      }
+      if (6 * count <= agg_max_dofs) break;
+    }
+    // bricks per aggregate and axis: the count that brings the brick edge closest to the target - near-cubic bricks
+    // (splitting an aggregate 3 x 2 x 1 to hit the target volume exactly costs 30 % more iterations: measured); an
+    // aggregate no larger than a brick or two leaves the two grids independent
+    bool fits = true;
+    int64_t m[3] = {1, 1, 1};
+    for (int k = 0; k < 3; ++k)
+      if (hi[k] - lo[k] > 0) {
+        m[k] = (int64_t)std::llround((hi[k] - lo[k]) / (double)na[k] / side);
+        if (m[k] < 2) fits = false;
+      }
+    if (fits)
+      for (int k = 0; k < 3; ++k) {
+        nb[k] = m[k] * na[k];
+        grid.na[k] = na[k];
+      }
+  }
+  for (int k = 0; k < 3; ++k) {
+    sk[k] = (hi[k] - lo[k]) > 0 ? (hi[k] - lo[k]) / (double)nb[k] : 1.0;
+    grid.side[k] = sk[k];
+  }
   std::vector<int64_t> key(N);
   parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
     for (int64_t i = i0; i < i1; ++i) {
       int64_t c[3];
       for (int k = 0; k < 3; ++k)
-        c[k] = std::max<int64_t>(0, std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / side)));
+        c[k] = std::max<int64_t>(0, std::min<int64_t>(nb[k] - 1, (int64_t)std::floor((xyz[3 * i + k] - lo[k]) / sk[k])));
       key[i] = (c[0] * nb[1] + c[1]) * nb[2] + c[2];
     }
   });
