@@ -12,7 +12,8 @@ import numpy as np
 from .timing import timing as _timing
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpylattice_hip.so")
+# PYLATTICE_HIP_LIB: load another build of the library (kernel experiments: tools/exp_variants.sh)
+LIB_PATH = os.environ.get("PYLATTICE_HIP_LIB") or os.path.join(_HERE, "libpylattice_hip.so")
 
 PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 

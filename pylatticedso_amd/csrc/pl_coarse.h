@@ -908,8 +908,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     const int s = threadIdx.x;
     double rr = 0.0;                                          // ||r||^2 slots in the tail of r_c (this wave alone
     for (int q = s; q < kSlots; q += kWave) rr += rc[ncp + q];   // reads and then clears the tail)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o, 64);
+    rr = wave_sum(rr);
     if (s == 0) hist[k] = rr;
     for (int q = s; q < kSlots; q += kWave) {
       rc[ncp + q] = 0.0;

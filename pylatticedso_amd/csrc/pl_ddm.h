@@ -31,9 +31,7 @@ __global__ __launch_bounds__(kBlock) void k_ddm_apply(int64_t C, int nb, const i
     part += v;
   }
   // the reference skips the product when np.sum(displacement_cell) == 0 (lattice_sim.py:1239): same test here
-  double tot = part;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  const double tot = wave_sum(part);
   if (tot == 0.0) return;
   const double *S = St + (size_t)cell_S[c] * m * m;
   for (int i = lane; i < m; i += 64) {
@@ -64,9 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product(int64_t C, int nb, 
     ucell[wv][i] = v;
     part += v;
   }
-  double tot = part;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  const double tot = wave_sum(part);
   const bool skip = tot == 0.0;            // lattice_sim.py:1239: np.sum(displacement_cell) == 0 -> zero reactions
   const double *S = St + (size_t)cell_S[c] * m * m;
   for (int i = lane; i < m; i += 64) {
@@ -117,9 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_lds(int64_t C, int 
       u[i] = v;
       part += v;
     }
-    double tot = part;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const double tot = wave_sum(part);
     const bool skip = tot == 0.0;
     const bool own = cell_S[c] == loaded;          // (else: the rare cell whose matrix is not the staged one)
     const double *Sg = St + (size_t)cell_S[c] * m * m;
@@ -183,9 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_reg(int64_t C, int 
       loaded = id;
     }
     const double u = uu[k];
-    double tot = u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const double tot = wave_sum(u);
     double acc = 0.0;
     if (tot != 0.0) {                       // lattice_sim.py:1239
 #pragma unroll
