@@ -313,7 +313,10 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
 // Workgroup size of the tile K*p.  Measured on the 50^3 Octet (256-node tiles): 128 / 256 / 384 / 512 / 640 / 768 / 1024
 // threads -> 45.9 / 40.6 / 39.7 / 36.2 / 47.8 / 42.8 / 55.0 us: with 512 a tile's ~1900 strut visits are 3-4 per thread, so a
 // workgroup lives half as long while 4 of them still fit a CU.
-constexpr int kTileBlock = 512;
+#ifndef PL_TILE_BLOCK
+#define PL_TILE_BLOCK 512
+#endif
+constexpr int kTileBlock = PL_TILE_BLOCK;
 // VT = storage type of x and y (double, or float for the fp32 solver modes: the strut forces are still evaluated
 // and accumulated in fp64 - the forces on a node nearly cancel for the smooth fields a solve is made of, so rounding
 // them to fp32 before the sum would cost cond(K) * 6e-8, rounding the stored result costs 6e-8).
