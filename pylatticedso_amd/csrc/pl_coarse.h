@@ -807,21 +807,33 @@ __global__ __launch_bounds__(kBlock) void k_cls_insert(int64_t nc, const unsigne
                                                        unsigned long long *__restrict__ keys, int *__restrict__ owner,
                                                        uint16_t *__restrict__ cls, int *__restrict__ flags) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= nc) return;
-  const unsigned long long h = key[q];
-  unsigned slot = (unsigned)(h >> 48);
-  for (int probe = 0; probe < 32; ++probe) {
-    unsigned long long cur = keys[slot];
-    if (cur == ~0ull) cur = atomicCAS(keys + slot, ~0ull, h);
-    if (cur == ~0ull || cur == h) {
-      if ((int)q < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMin(owner + slot, (int)q);
-      cls[q] = (uint16_t)slot;
-      return;
+  int found = -1;
+  if (q < nc) {
+    const unsigned long long h = key[q];
+    unsigned slot = (unsigned)(h >> 48);
+    for (int probe = 0; probe < 32; ++probe) {
+      unsigned long long cur = keys[slot];
+      if (cur == ~0ull) cur = atomicCAS(keys + slot, ~0ull, h);
+      if (cur == ~0ull || cur == h) {
+        found = (int)slot;
+        break;
+      }
+      slot = (slot + 1) & 65535u;
     }
-    slot = (slot + 1) & 65535u;
+    if (found < 0) flags[0] = 1;
+    else cls[q] = (uint16_t)found;
   }
-  flags[0] = 1;
+  // owner = smallest node of the class: one check per wave and class (as k_pal_insert)
+  unsigned long long todo = __ballot(found >= 0);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int s = __builtin_amdgcn_readlane(found, leader);
+    const unsigned long long same = __ballot(found == s);
+    if (lane == leader && (int)q < __hip_atomic_load(owner + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(owner + s, (int)q);
+    todo &= ~same;
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_cls_publish(int64_t nc, const double *__restrict__ inv,
                                                         const int *__restrict__ owner, const uint16_t *__restrict__ cls,

@@ -30,29 +30,56 @@ __device__ __forceinline__ unsigned long long pal_hash(const Record &r) {
   return h == kPalEmpty ? 0 : h;
 }
 
-// pass 1: claim a slot per distinct hash; owner[slot] = smallest strut id that uses it; flags[0] = 1 on overflow
+// pass 1: claim a slot per distinct hash; owner[slot] = smallest strut id that uses it; flags[0] = 1 on overflow.
+// Millions of struts share a few hundred slots.  One lane per wave and distinct hash (the lowest: strut ids ascend with
+// the lane) probes the table and settles the owner, the others take its answer - otherwise the 64 lanes of every wave
+// hammer the same few addresses of one L2 channel (and, the vector L1 being incoherent, keep seeing a slot as empty
+// after another CU claimed it, so that nearly every strut issued the compare-and-swap: 0.27 ms at 3 M struts).
+// A wave with many distinct hashes (graded lattices) leaves the grouping after kPalGroups rounds and lets the
+// remaining lanes probe for themselves, in parallel.
+constexpr int kPalGroups = 12;
+__device__ __forceinline__ int pal_probe(unsigned long long h, unsigned long long *__restrict__ keys,
+                                         int *__restrict__ owner, int b) {
+  unsigned slot = (unsigned)(h >> (64 - kPalBits));
+  for (int probe = 0; probe < kPalProbes; ++probe) {
+    unsigned long long cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kPalEmpty) cur = atomicCAS(keys + slot, kPalEmpty, h);
+    if (cur == kPalEmpty || cur == h) {
+      // the owner only decreases: a read that is already smaller spares the atomic
+      if (b < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(owner + slot, b);
+      return (int)slot;
+    }
+    slot = (slot + 1) & (kPalSize - 1);
+  }
+  return -1;
+}
 __global__ __launch_bounds__(kBlock) void k_pal_insert(int64_t B, const Record *__restrict__ rec,
                                                        unsigned long long *__restrict__ keys,
                                                        int *__restrict__ owner, uint16_t *__restrict__ pal,
                                                        int *__restrict__ flags) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (b >= B) return;
-  const unsigned long long h = pal_hash(load_record(rec, b));
-  unsigned slot = (unsigned)(h >> (64 - kPalBits));
-  for (int probe = 0; probe < kPalProbes; ++probe) {
-    unsigned long long cur = keys[slot];
-    if (cur == kPalEmpty) cur = atomicCAS(keys + slot, kPalEmpty, h);
-    if (cur == kPalEmpty || cur == h) {
-      // owner = smallest strut id of the slot.  It only decreases, so a (possibly stale) read that is already
-      // smaller lets almost every thread skip the atomic: millions of struts share a few hundred slots.
-      if ((int)b < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMin(owner + slot, (int)b);
-      pal[b] = (uint16_t)slot;
-      return;
-    }
-    slot = (slot + 1) & (kPalSize - 1);
+  const bool valid = b < B;
+  const unsigned long long h = valid ? pal_hash(load_record(rec, b)) : 0ull;
+  const int lane = threadIdx.x & 63;
+  int found = -2;                                   // -2: not settled yet, -1: table full
+  unsigned long long todo = __ballot(valid);
+  for (int round = 0; round < kPalGroups && todo; ++round) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned long long hl =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h >> 32), leader) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h & 0xFFFFFFFFull), leader);
+    const unsigned long long same = __ballot(valid && found == -2 && h == hl);
+    int sl = 0;
+    if (lane == leader) sl = pal_probe(h, keys, owner, (int)b);
+    sl = __builtin_amdgcn_readlane(sl, leader);
+    if ((same >> lane) & 1ull) found = sl;
+    todo &= ~same;
   }
-  flags[0] = 1;
+  if (valid && found == -2) found = pal_probe(h, keys, owner, (int)b);
+  if (valid) {
+    if (found < 0) flags[0] = 1;
+    else pal[b] = (uint16_t)found;
+  }
 }
 // pass 2: the owner publishes its record
 __global__ __launch_bounds__(kBlock) void k_pal_publish(int64_t B, const Record *__restrict__ rec,
