@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for lib in "$@"; do
   name=$(basename $lib .so)
   if [ "$lib" = default ]; then unset PYLATTICE_HIP_LIB; else export PYLATTICE_HIP_LIB=$R/$lib; fi
-  rocprofv3 --kernel-trace --stats -d $O/$name -o s --output-format csv -- python3 tools/profile_kernels.py --reps 20 > $O/$name.json 2> $O/$name.log
+  rocprofv3 --kernel-trace --stats -d $O/$name -o s --output-format csv -- python3 tools/profile_kernels.py --reps 20 $PK_ARGS > $O/$name.json 2> $O/$name.log
   python3 - $O/$name <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
