@@ -152,7 +152,8 @@ struct pl_context {
   // exact elimination of an independent node set inside the PCG (opts.condense, pl_coarse.h)
   std::vector<uint8_t> h_cand;        // candidates (an independent set of the node graph, chosen at pl_create; device numbering)
   std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
-  DevBuf<int32_t> cnodes;
+  DevBuf<int32_t> cnodes, cbase;  // condensed nodes; node -> offset of its K_cc^-1 block (class table or per node), -1
+  int cbase_state = -1;           // what cbase was built for: -1 stale, 0 per-node blocks, 1 class table
   DevBuf<double> kcc_inv;
   DevBuf<uint8_t> maskC, cflag;       // Dirichlet bits | 0x3f on condensed nodes; 1 on condensed nodes
   // classes of eliminated nodes with the same K_cc^-1 (pl_coarse.h k_cls_*): only with a record palette
@@ -250,21 +251,45 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 }
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
+// K_cc^-1 for the fused first pass of the condensed operator (kEndsCondensedSolve)
+__global__ __launch_bounds__(pl::kBlock) void k_cond_base(int64_t nc, const int32_t *__restrict__ cnodes,
+                                                         const uint16_t *__restrict__ cls /* may be null */,
+                                                         int32_t *__restrict__ base) {
+  const int64_t q = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (q < nc) base[cnodes[q]] = 36 * (cls ? (int32_t)cls[q] : (int32_t)q);
+}
+inline pl::CondSolve cond_solve(pl_context *c, int ends) {
+  pl::CondSolve cs;
+  if (ends == pl::kEndsCondensedSolve) {
+    const int want = c->cls_ready ? 1 : 0;
+    if (c->cbase_state != want) {   // (after pl_set_bc / when the class table comes or goes: once per assembly at most)
+      (void)hipMemsetAsync(c->cbase.p, 0xFF, (size_t)c->N * sizeof(int32_t), c->stream);
+      hipLaunchKernelGGL(k_cond_base, dim3(grid_for(c->n_cond)), dim3(pl::kBlock), 0, c->stream, c->n_cond, c->cnodes.p,
+                         c->cls_ready ? (const uint16_t *)c->cls_id.p : (const uint16_t *)nullptr, c->cbase.p);
+      c->cbase_state = want;
+    }
+    cs.inv = c->cls_ready ? (const double *)c->cls_table.p : (const double *)c->kcc_inv.p;
+    cs.base = c->cbase.p;
+  }
+  return cs;
+}
+
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
                 const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll, bool reduce_dot = true) {
   const int kind = choose_kernel(c);
   if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0) {
     // tile kernel with a caller-chosen row mask and / or only one kind of strut ends (node elimination)
     const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+    const pl::CondSolve cs = cond_solve(c, ends);
     if (c->pal_ready)
       pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,
-                           (const double *)nullptr, ends, cf);
+                           (const double *)nullptr, ends, cf, cs);
     else if (c->rec5.p)
       pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
-                           dot_dev, c->stream, c->xyz.p, ends, cf);
+                           dot_dev, c->stream, c->xyz.p, ends, cf, cs);
     else
       pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
-                           (const double *)nullptr, ends, cf);
+                           (const double *)nullptr, ends, cf, cs);
     PL_HIP(hipGetLastError());
     return PL_OK;
   }
@@ -334,15 +359,16 @@ int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double
                     const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
   const uint8_t *mk = maskbits ? maskbits : (masked ? (const uint8_t *)c->fixedbits.p : (const uint8_t *)nullptr);
   const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+  const pl::CondSolve cs = cond_solve(c, ends);
   if (c->pal_ready)
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, mk, x, y, dot_dev, c->stream,
-                                (const double *)nullptr, ends, cf);
+                                (const double *)nullptr, ends, cf, cs);
   else if (c->rec5.p)
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, mk, x, y,
-                                dot_dev, c->stream, c->xyz.p, ends, cf);
+                                dot_dev, c->stream, c->xyz.p, ends, cf, cs);
   else
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, mk, x, y, dot_dev, c->stream,
-                                (const double *)nullptr, ends, cf);
+                                (const double *)nullptr, ends, cf, cs);
   if (c->dist.active) {
     int rc = pl::dist_sum_shared<float>(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
     if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
@@ -585,6 +611,8 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
     PL_HIP(c->cflag.alloc(N));
   }
   PL_HIP(hipMemcpy(c->cnodes.p, picked.data(), picked.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!c->cbase.p) PL_HIP(c->cbase.alloc(N));
+  c->cbase_state = -1;
   PL_HIP(hipMemcpy(c->maskC.p, mask.data(), N, hipMemcpyHostToDevice));
   PL_HIP(hipMemcpy(c->cflag.p, flag.data(), N, hipMemcpyHostToDevice));
   c->n_cond = (int64_t)picked.size();
@@ -599,6 +627,7 @@ int launch_condensed_blocks(pl_context *c, hipStream_t st) {
   PL_HIP(hipGetLastError());
   c->cond_ready = true;
   c->cls_ready = false;
+  c->cbase_state = -1;       // class ids are assigned anew below
   if (c->opt.palette && c->pal_id.p) {
     // Classes by the record-palette ids of the incident struts (queued behind launch_palette on the same stream; if the
     // record palette turns out not to hold, finish_condensed_classes drops the classes as well)
@@ -699,10 +728,9 @@ int pcg_iteration(pl_context *c, int k) {
   if (c->cond_use) {
     // S p: the condensed nodes take their equilibrium position under p (first pass, their rows of p are 0 on entry),
     // then the ordinary product with their rows masked like Dirichlet rows (second pass, with p.Ap)
-    int rc = launch_spmv(c, c->p.p, c->Ap.p, false, nullptr, nullptr, pl::kEndsCondensed);
+    // (first pass fused with the 6 x 6 solves: every tile writes -K_cc^-1 (K p_v)_c into the p rows of its condensed nodes)
+    int rc = launch_spmv(c, c->p.p, c->p.p, false, nullptr, nullptr, pl::kEndsCondensedSolve);
     if (rc) return rc;
-    hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->Ap.p, c->p.p, -1.0);
     rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
     if (rc) return rc;
     return pcg_tail_coarse(c, cur, nxt, k);
@@ -1145,10 +1173,8 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
       for (int q = 0; q < todo; ++q) {
         double *cur = c->scal.p + ((j + q) & 1) * set, *nxt = c->scal.p + ((j + q + 1) & 1) * set;
         if (kAll32 && c->cond_use) {
-          rc = launch_spmv_f32(c, p32, Ap32, false, nullptr, nullptr, pl::kEndsCondensed);
+          rc = launch_spmv_f32(c, p32, p32, false, nullptr, nullptr, pl::kEndsCondensedSolve);
           if (rc) return rc;
-          hipLaunchKernelGGL(pl::k_condense_solve<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
-                             c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)Ap32, p32, -1.0);
           rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
         } else {
           rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);

@@ -956,11 +956,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     l2 = cenL[3 * aL + 2];
   }
   for (int64_t i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
-    if (zero_rows && zero_rows[i]) {   // eliminated node: only clear its row of p (the next first pass wants zeros there)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) store_pair(p, 3 * i + q, double2{0.0, 0.0});
-      continue;
-    }
+    // eliminated node: not an unknown of this CG (its row of p is rewritten by the first pass of every product, which
+    // takes the old content as zero: k_spmv_tile<.., kEndsCondensedSolve>)
+    if (zero_rows && zero_rows[i]) continue;
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     if (own_t && !shared[i]) {

@@ -278,7 +278,15 @@ struct __attribute__((aligned(8))) Rec5 {
 
 // ENDS: which strut ends are accumulated - kEndsAll, or (node elimination, pl_coarse.h) only the ends at condensed nodes
 // / only the others, told apart by the byte flag cflag[node].
-enum { kEndsAll = 0, kEndsCondensed = 1, kEndsOthers = 2 };
+// kEndsCondensedSolve: as kEndsCondensed, and the tile then puts v = -K_cc^-1 (accumulated row) into row `node` of y for
+// each of its condensed nodes - the equilibrium position under the other nodes' x.  Called with y = x, this is the whole
+// first half of the Schur-complement product in one launch (pl_coarse.h): x of a condensed end counts as zero on the way
+// in, so nobody reads the rows another tile is writing.
+enum { kEndsAll = 0, kEndsCondensed = 1, kEndsOthers = 2, kEndsCondensedSolve = 3 };
+struct CondSolve {            // K_cc^-1 of the condensed nodes (pl_coarse.h)
+  const double *inv = nullptr;     // 6 x 6 blocks: the class table, or one block per condensed node
+  const int32_t *base = nullptr;   // node -> offset of its block in inv (doubles); < 0: not a condensed node
+};
 template <int REC, int ENDS, typename VT>
 __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
                                            const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
@@ -297,12 +305,18 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
   load6(x + 6 * (int64_t)c.y, uB, tB);
-  tip_force(r, uA, tA, uB, tB, F, M);
+  constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
   bool takeB = c.y >= n0 && c.y < n1, takeA = c.x >= n0 && c.x < n1;
   if (ENDS != kEndsAll) {
-    if (takeB) takeB = (cflag[c.y] != 0) == (ENDS == kEndsCondensed);
-    if (takeA) takeA = (cflag[c.x] != 0) == (ENDS == kEndsCondensed);
+    const bool cB = cflag[c.y] != 0, cA = cflag[c.x] != 0;
+    if (ENDS == kEndsCondensedSolve) {     // a condensed end's own row is being rewritten by its tile: it counts as zero
+      if (cA) { uA = {0, 0, 0}; tA = {0, 0, 0}; }
+      if (cB) { uB = {0, 0, 0}; tB = {0, 0, 0}; }
+    }
+    takeB = takeB && (cB == kToCondensed);
+    takeA = takeA && (cA == kToCondensed);
   }
+  tip_force(r, uA, tA, uB, tB, F, M);
   if (takeB) lds_add6(ys + (c.y - n0), stride, F, M);
   if (takeA) {
     const V3 d = {r.dx, r.dy, r.dz};
@@ -331,13 +345,17 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
                                                       const uint8_t *__restrict__ fixedbits,
                                                       const VT *__restrict__ x, VT *__restrict__ y,
                                                       double *__restrict__ dot_out, int stride,
-                                                      const uint8_t *__restrict__ cflag = nullptr) {
+                                                      const uint8_t *__restrict__ cflag = nullptr,
+                                                      CondSolve cs = CondSolve()) {
   extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
   __shared__ double red[kTileBlock / kWave];
+  __shared__ int32_t sbase[ENDS == kEndsCondensedSolve ? kTileMaxNodes : 1];
   const unsigned t = xcd_block(blockIdx.x, gridDim.x);
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int nn = n1 - n0;
   for (int i = threadIdx.x; i < 6 * stride; i += kTileBlock) ys[i] = 0.0;
+  if (ENDS == kEndsCondensedSolve)           // fetched now, needed after the strut loops: no dependent load in the tail
+    for (int i = threadIdx.x; i < nn; i += kTileBlock) sbase[i] = cs.base[n0 + i];
   __syncthreads();
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
 #pragma unroll 4
@@ -348,6 +366,19 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
     tile_strut<REC, ENDS, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, xyz, cflag, x, ys, stride);
   __syncthreads();
+  if (ENDS == kEndsCondensedSolve) {
+    for (int i = threadIdx.x; i < nn * 6; i += kTileBlock) {
+      const int node = i / 6, k = i - 6 * node;
+      const int32_t b0 = sbase[node];
+      if (b0 < 0) continue;
+      const double *A = cs.inv + b0 + 6 * k;
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) v += A[j] * ys[j * stride + node];
+      y[6 * (int64_t)(n0 + node) + k] = (VT)(-v);
+    }
+    return;
+  }
   double acc = 0.0;
   const int64_t pair0 = 3 * (int64_t)n0;
   for (int i = threadIdx.x; i < nn * 3; i += kTileBlock) {
@@ -381,14 +412,15 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
 template <typename VT>
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
                              const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s,
-                             const double *xyz = nullptr, int ends = kEndsAll, const uint8_t *cflag = nullptr) {
+                             const double *xyz = nullptr, int ends = kEndsAll, const uint8_t *cflag = nullptr,
+                             CondSolve cs = CondSolve()) {
   const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
 #define PL_T(M, D, P, E)                                                                                          \
   hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT, E>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p,           \
-                     plan.foreign_ptr.p, plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride, cflag)
+                     plan.foreign_ptr.p, plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride, cflag, cs)
 #define PL_TT(P, E)                                           \
   do {                                                        \
     if (fixedbits && dot_dev) PL_T(true, true, P, E);         \
@@ -399,6 +431,7 @@ inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Re
 #define PL_TE(P)                                   \
   do {                                             \
     if (ends == kEndsCondensed) PL_TT(P, kEndsCondensed); \
+    else if (ends == kEndsCondensedSolve) PL_T(false, false, P, kEndsCondensedSolve); \
     else if (ends == kEndsOthers) PL_TT(P, kEndsOthers);  \
     else PL_TT(P, kEndsAll);                       \
   } while (0)
