@@ -287,12 +287,12 @@ struct CondSolve {            // K_cc^-1 of the condensed nodes (pl_coarse.h)
   const double *inv = nullptr;     // 6 x 6 blocks: the class table, or one block per condensed node
   const int32_t *base = nullptr;   // node -> offset of its block in inv (doubles); < 0: not a condensed node
 };
+// (c = conn2[b] and pid = pal[b] come from the caller, which fetches them one visit ahead: tile_struts)
 template <int REC, int ENDS, typename VT>
-__device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2 *__restrict__ conn2,
-                                           const Record *__restrict__ rec, const uint16_t *__restrict__ pal,
+__device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsigned pid, int n0, int n1,
+                                           const Record *__restrict__ rec,
                                            const double *__restrict__ xyz, const uint8_t *__restrict__ cflag,
                                            const VT *__restrict__ x, double *ys, int stride) {
-  const int2 c = conn2[b];
   Record r;
   if (REC == kRecCompact) {
     const Rec5 q = reinterpret_cast<const Rec5 *>(rec)[b];
@@ -300,7 +300,7 @@ __device__ __forceinline__ void tile_strut(int64_t b, int n0, int n1, const int2
     r.a = q.a; r.c = q.c; r.e1 = q.e1; r.e2 = q.e2; r.e3 = q.e3;
     r.dx = pb[0] - pa[0]; r.dy = pb[1] - pa[1]; r.dz = pb[2] - pa[2];
   } else {
-    r = (REC == kRecPalette) ? load_record(rec, pal[b]) : load_record(rec, b);
+    r = (REC == kRecPalette) ? load_record(rec, pid) : load_record(rec, b);
   }
   V3 uA, tA, uB, tB, F, M;
   load6(x + 6 * (int64_t)c.x, uA, tA);
@@ -357,14 +357,48 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   if (ENDS == kEndsCondensedSolve)           // fetched now, needed after the strut loops: no dependent load in the tail
     for (int i = threadIdx.x; i < nn; i += kTileBlock) sbase[i] = cs.base[n0 + i];
   __syncthreads();
+  // A thread makes 2-3 visits per tile, each a chain of two memory hops (conn -> x rows, palette id -> record) before
+  // the arithmetic.  The first hop of the NEXT visit (10 bytes) is issued before the current visit's second hop, so only
+  // a thread's first visit pays both (SQ counters: the waves of this kernel spent 52 % of their life in s_waitcnt).
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
-#pragma unroll 4
-  for (int64_t b = h0 + threadIdx.x; b < h1; b += kTileBlock)
-    tile_strut<REC, ENDS, VT>(b, n0, n1, conn2, rec, pal, xyz, cflag, x, ys, stride);
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
-#pragma unroll 4
-  for (int64_t k = f0 + threadIdx.x; k < f1; k += kTileBlock)
-    tile_strut<REC, ENDS, VT>(foreign_idx[k], n0, n1, conn2, rec, pal, xyz, cflag, x, ys, stride);
+  int64_t b = h0 + threadIdx.x, kf = f0 + threadIdx.x;
+  bool home = b < h1;
+  if (!home && kf < f1) b = foreign_idx[kf];
+  bool live = home || kf < f1;
+  int2 cn = {0, 0};
+  unsigned pid = 0;
+  if (live) {
+    cn = conn2[b];
+    if (REC == kRecPalette) pid = pal[b];
+  }
+  while (live) {
+    // next visit: the following home strut, else this thread's first / next foreign one
+    int64_t bn = b;
+    bool home_n = false, live_n = false;
+    if (home && b + kTileBlock < h1) {
+      bn = b + kTileBlock;
+      home_n = live_n = true;
+    } else {
+      if (!home) kf += kTileBlock;
+      if (kf < f1) {
+        bn = foreign_idx[kf];
+        live_n = true;
+      }
+    }
+    int2 cn_n = {0, 0};
+    unsigned pid_n = 0;
+    if (live_n) {
+      cn_n = conn2[bn];
+      if (REC == kRecPalette) pid_n = pal[bn];
+    }
+    tile_strut<REC, ENDS, VT>(b, cn, pid, n0, n1, rec, xyz, cflag, x, ys, stride);
+    b = bn;
+    cn = cn_n;
+    pid = pid_n;
+    home = home_n;
+    live = live_n;
+  }
   __syncthreads();
   if (ENDS == kEndsCondensedSolve) {
     for (int i = threadIdx.x; i < nn * 6; i += kTileBlock) {
