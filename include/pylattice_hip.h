@@ -108,6 +108,8 @@ typedef struct {
   int32_t cg_form;       /* multi-level PCG (precond 2 / 3, fp64, no node elimination): 1 = single-reduction form (Chronopoulos-
                           * Gear recurrences, the dense level's residual carried by recurrence): ONE all-reduce per iteration on
                           * several GPUs instead of three exchanges, for three more stored vectors.  0 = ordinary form. */
+  int32_t tile_modes;    /* tile level of the multi-level PCG: 0 / 12 = rigid-body + uniform-strain modes per tile (12 x 12 blocks;
+                          * single-GPU handles, ordinary CG form), 6 = rigid-body modes only */
 } pl_opts_t;
 
 typedef struct {

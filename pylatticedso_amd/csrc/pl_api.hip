@@ -487,13 +487,29 @@ int launch_local_mask(pl_context *c) {
   return PL_OK;
 }
 
+// modes of the tile level in use: the strain modes need every node of a tile on this rank (no communicator, no rank-local
+// level); decided the same way when the blocks are built and when they are applied
+inline int tile_modes_now(const pl_context *c) {
+  return (c->coarse.tile_level && c->coarse.tile_modes == 12 && !c->dist.active && !c->coarseL.enabled) ? 12 : 6;
+}
+
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
   pl::Coarse &cs = c->coarse;
   if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
+  const uint8_t *fb = c->dist.active ? c->maskL.p : c->fixedbits.p;
+  const bool twelve = tile_modes_now(c) == 12;
   hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
                      c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                      reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                     c->dist.active ? c->maskL.p : c->fixedbits.p, cs.Bt_inv);
+                     fb, cs.Bt_inv, twelve ? cs.Bt_raw : (double *)nullptr);
+  if (twelve) {
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st,
+                       c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
+                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, fb,
+                       cs.Bt_raw);
+    hipLaunchKernelGGL(pl::k_tile_invert12, dim3(grid_for(cs.n_tiles)), dim3(pl::kBlock), 0, st, cs.n_tiles,
+                       (const double *)cs.Bt_raw, cs.Bt_inv);
+  }
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -688,13 +704,17 @@ template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream,
-                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,
-                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,
-                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,
-                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,
-                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
+#define PL_UPD(TM)                                                                                                  \
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, \
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,                       \
+                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,             \
+                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
+                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr)
+  if (tile_modes_now(c) == 12) PL_UPD(12);
+  else PL_UPD(6);
+#undef PL_UPD
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
     pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
@@ -705,14 +725,17 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cs.rc + cs.ncp + pl::kSlots, c->stream);
-  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream,
-                     c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,
-                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur,
-                     nxt,
-                     c->hist.p, hist_slot, cs.rc, cs.ncp,
-                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,
-                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,
-                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr);
+#define PL_DIR(TM)                                                                                                       \
+  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT, TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, \
+                     c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,         \
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur, nxt,     \
+                     c->hist.p, hist_slot, cs.rc, cs.ncp,                                                                \
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
+                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr)
+  if (tile_modes_now(c) == 12) PL_DIR(12);
+  else PL_DIR(6);
+#undef PL_DIR
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -1432,6 +1455,7 @@ void pl_default_opts(pl_opts_t *o) {
 }
 
 namespace {
+inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
 // dofs the dense level may have (see the comment at its set-up in pl_create)
 inline int coarse_budget(const pl_opts_t *o, int64_t N) {
   const bool multi_rank = o->grid_nodes > 0;
@@ -1655,6 +1679,9 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (o->precond >= 2 && o->precond <= 4) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
     c->coarse.tile_level = (o->precond >= 3);
+    // 12-mode tile level (rigid + uniform strains): single-GPU handles in the ordinary CG form; opts.tile_modes = 6 keeps
+    // the rigid-body blocks
+    c->coarse.tile_modes = (o->tile_modes == 6 || multi_rank_handle(o) || o->precond == 4 || o->cg_form == 1) ? 6 : 12;
     // default size of the dense level: its factorisation is a ~45 us-per-64-dofs latency chain in every assembly, its
     // benefit grows with the cost of an iteration - up to 1 M nodes on one GPU the optimum is ~2 000 dofs (measured on
     // 50^3 Octet: 7^3 aggregates 18.9 ms per step, 8^3 20.7 ms), beyond that and in multi-rank runs (collectives in

@@ -50,7 +50,12 @@ struct Coarse {
   // tile level: every K*p tile is an aggregate of its own between the Jacobi level and the dense level
   bool tile_level = true;
   std::vector<int32_t> h_tile_start;
-  double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles*36], [n_tiles*6]
+  double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles * tm * tm], [n_tiles * tm], tm = tile_modes
+  // Modes of the tile level: 6 (rigid body) or 12 (+ the six uniform strains u = eps (x - c), no rotation).  A piecewise
+  // rigid field follows a macroscopic strain only with jumps across tile faces; the strain modes let a tile deform with
+  // it.  Measured: 134 -> ... iterations at 50^3 Octet, 509 -> ... at 100^3 BCC.
+  int tile_modes = 6;
+  double *Bt_raw = nullptr;                  // [n_tiles * 144] B_t before the inversion (12 modes only)
   // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
   // symmetric operator in every iteration, so rounding the Jacobi weights is free).  The node positions stay fp64:
   // the coarse modes must be EXACTLY rigid per aggregate - their energy is tiny next to ||K||, and a 1e-7 error in
@@ -63,7 +68,8 @@ struct Coarse {
   int64_t n_fix = -1;                        // -1: stale
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
-                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)bar})
+                    (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)bar,
+                    (void *)Bt_raw})
       if (q) (void)hipFree(q);
   }
 };
@@ -199,10 +205,12 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   if (hipMalloc((void **)&c.bar, sizeof(unsigned)) != hipSuccess) return 2;
   {
     c.h_tile_start = tile_start;
-    if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
-    if (hipMalloc((void **)&c.yt, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
-    if (hipMemset(c.Bt_inv, 0, (size_t)T * 36 * sizeof(double)) != hipSuccess) return 2;
-    if (hipMemset(c.yt, 0, (size_t)T * 6 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMalloc((void **)&c.Bt_inv, (size_t)T * 144 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMalloc((void **)&c.Bt_raw, (size_t)T * 144 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMalloc((void **)&c.yt, (size_t)T * 12 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMemset(c.Bt_inv, 0, (size_t)T * 144 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMemset(c.Bt_raw, 0, (size_t)T * 144 * sizeof(double)) != hipSuccess) return 2;
+    if (hipMemset(c.yt, 0, (size_t)T * 12 * sizeof(double)) != hipSuccess) return 2;
   }
   if (hipMemset(c.rc, 0, (size_t)(c.ncp + 2 * kSlots) * sizeof(double)) != hipSuccess) return 2;
   if (hipMemset(c.W, 0, n2 * sizeof(float)) != hipSuccess) return 2;
@@ -485,7 +493,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
                                                         const int32_t *__restrict__ agg_of_tile,
                                                         const double *__restrict__ cen, const double *__restrict__ xyz,
                                                         const uint8_t *__restrict__ fixedbits,
-                                                        double *__restrict__ Bt_inv) {
+                                                        double *__restrict__ Bt_inv,
+                                                        double *__restrict__ raw /* 12 modes: [T][144], no inversion */) {
   __shared__ double red[36][kBlock / kWave];
   __shared__ double A[36];
   const int t = blockIdx.x;
@@ -544,6 +553,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
     A[threadIdx.x] = s;
   }
   __syncthreads();
+  if (raw) {                                 // rigid x rigid block of the 12 x 12 matrix (k_tile_blocks_strain adds the rest)
+    if (threadIdx.x < 36) raw[(size_t)t * 144 + (threadIdx.x / 6) * 12 + threadIdx.x % 6] = A[threadIdx.x];
+    return;
+  }
   if (threadIdx.x == 0) {
     double M[36];
 #pragma unroll
@@ -552,6 +565,167 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
 #pragma unroll
     for (int e = 0; e < 36; ++e) Bt_inv[(size_t)t * 36 + e] = M[e];
   }
+}
+
+// ---- 12-mode tile level: the strain rows / columns of B_t.  Mode 6 + q of a node at r = x - c (translations only):
+//   q = 0, 1, 2: eps_xx, eps_yy, eps_zz -> u = (rx, 0, 0), (0, ry, 0), (0, 0, rz);
+//   q = 3, 4, 5: eps_xy, eps_yz, eps_xz -> u = (ry, rx, 0) / 2, (0, rz, ry) / 2, (rz, 0, rx) / 2.
+__device__ __forceinline__ V3 strain_disp(int q, const double *r) {
+  switch (q) {
+    case 0: return {r[0], 0.0, 0.0};
+    case 1: return {0.0, r[1], 0.0};
+    case 2: return {0.0, 0.0, r[2]};
+    case 3: return {0.5 * r[1], 0.5 * r[0], 0.0};
+    case 4: return {0.0, 0.5 * r[2], 0.5 * r[1]};
+    default: return {0.5 * r[2], 0.0, 0.5 * r[0]};
+  }
+}
+// Z_S^T f for a force F at r: the six strain restrictions
+__device__ __forceinline__ void strain_restrict(const V3 &F, const double *r, double *s6, double sign) {
+  s6[0] += sign * r[0] * F.x;
+  s6[1] += sign * r[1] * F.y;
+  s6[2] += sign * r[2] * F.z;
+  s6[3] += sign * 0.5 * (r[1] * F.x + r[0] * F.y);
+  s6[4] += sign * 0.5 * (r[2] * F.y + r[1] * F.z);
+  s6[5] += sign * 0.5 * (r[2] * F.x + r[0] * F.z);
+}
+__device__ __forceinline__ V3 mask3(V3 v, unsigned bits) {
+  return {(bits & 1u) ? 0.0 : v.x, (bits & 2u) ? 0.0 : v.y, (bits & 4u) ? 0.0 : v.z};
+}
+// One workgroup per tile over ALL the struts the tile visits (a strain mode stores energy in every strut, unlike a rigid
+// one): per strut six evaluations of the tip force under the masked strain displacements of its in-tile ends, restricted
+// back by the strain modes (S x S, 6 x 6 symmetric) and - only for struts that cross the tile boundary or touch a
+// Dirichlet dof: the others answer a strain with a self-equilibrated force pair - by the rigid modes (R x S).
+__global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__restrict__ tile_start,
+                                                               const int64_t *__restrict__ home_ptr,
+                                                               const int64_t *__restrict__ foreign_ptr,
+                                                               const int32_t *__restrict__ foreign_idx,
+                                                               const int2 *__restrict__ conn2,
+                                                               const Record *__restrict__ rec,
+                                                               const int32_t *__restrict__ agg_of_tile,
+                                                               const double *__restrict__ cen,
+                                                               const double *__restrict__ xyz,
+                                                               const uint8_t *__restrict__ fixedbits,
+                                                               double *__restrict__ raw) {
+  __shared__ double red[72][kBlock / kWave];
+  const int t = blockIdx.x;
+  const int n0 = tile_start[t], n1 = tile_start[t + 1];
+  const int a = agg_of_tile[t];
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double SS[36], RS[36];                     // [p][q]: restriction p of the force answering strain q
+#pragma unroll
+  for (int e = 0; e < 36; ++e) SS[e] = RS[e] = 0.0;
+  const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1], f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
+  const int64_t total = (h1 - h0) + (f1 - f0);
+  for (int64_t v = threadIdx.x; v < total; v += kBlock) {
+    const int64_t b = v < (h1 - h0) ? h0 + v : (int64_t)foreign_idx[f0 + (v - (h1 - h0))];
+    const int2 cn = conn2[b];
+    const bool ina = cn.x >= n0 && cn.x < n1, inb = cn.y >= n0 && cn.y < n1;
+    if (!ina && !inb) continue;
+    const unsigned fa = fixedbits ? fixedbits[cn.x] : 0u, fb = fixedbits ? fixedbits[cn.y] : 0u;
+    const bool free_inside = ina && inb && fa == 0u && fb == 0u;
+    const Record r = load_record(rec, b);
+    const double rela[3] = {xyz[3 * (int64_t)cn.x] - c0, xyz[3 * (int64_t)cn.x + 1] - c1, xyz[3 * (int64_t)cn.x + 2] - c2};
+    const double relb[3] = {xyz[3 * (int64_t)cn.y] - c0, xyz[3 * (int64_t)cn.y + 1] - c1, xyz[3 * (int64_t)cn.y + 2] - c2};
+    const V3 d = {r.dx, r.dy, r.dz}, zero = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const V3 uA = ina ? mask3(strain_disp(q, rela), fa) : zero, uB = inb ? mask3(strain_disp(q, relb), fb) : zero;
+      V3 F, M;
+      tip_force(r, uA, zero, uB, zero, F, M);                  // on B; on A: -F, -M - d x F
+      const V3 FB = mask3(F, fb), MB = mask3(M, fb >> 3);
+      const V3 FA = mask3((-1.0) * F, fa), MA = mask3((-1.0) * M - cross(d, F), fa >> 3);
+      double s6[6] = {0, 0, 0, 0, 0, 0};
+      if (inb) strain_restrict(FB, relb, s6, 1.0);
+      if (ina) strain_restrict(FA, rela, s6, 1.0);
+#pragma unroll
+      for (int p = 0; p < 6; ++p) SS[p * 6 + q] += s6[p];
+      if (!free_inside) {
+        if (inb) {
+          RS[0 * 6 + q] += FB.x;
+          RS[1 * 6 + q] += FB.y;
+          RS[2 * 6 + q] += FB.z;
+          RS[3 * 6 + q] += MB.x + (relb[1] * FB.z - relb[2] * FB.y);
+          RS[4 * 6 + q] += MB.y + (relb[2] * FB.x - relb[0] * FB.z);
+          RS[5 * 6 + q] += MB.z + (relb[0] * FB.y - relb[1] * FB.x);
+        }
+        if (ina) {
+          RS[0 * 6 + q] += FA.x;
+          RS[1 * 6 + q] += FA.y;
+          RS[2 * 6 + q] += FA.z;
+          RS[3 * 6 + q] += MA.x + (rela[1] * FA.z - rela[2] * FA.y);
+          RS[4 * 6 + q] += MA.y + (rela[2] * FA.x - rela[0] * FA.z);
+          RS[5 * 6 + q] += MA.z + (rela[0] * FA.y - rela[1] * FA.x);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 36; ++e) {
+    const double s1 = wave_sum(SS[e]), s2 = wave_sum(RS[e]);
+    if (lane == 0) {
+      red[e][wv] = s1;
+      red[36 + e][wv] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 72) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBlock / kWave; ++q) v += red[threadIdx.x][q];
+    const int e = threadIdx.x % 36, p = e / 6, q = e % 6;
+    double *B = raw + (size_t)t * 144;
+    if (threadIdx.x < 36) {
+      B[(6 + p) * 12 + 6 + q] = v;            // S x S (symmetrised by k_tile_invert12)
+    } else {
+      B[p * 12 + 6 + q] = v;                  // R x S and its transpose
+      B[(6 + q) * 12 + p] = v;
+    }
+  }
+}
+// B_t^-1 of the 12-mode tile level, one thread per tile (modes without stiffness are dropped, as in spd6_inverse)
+__global__ __launch_bounds__(kBlock) void k_tile_invert12(int64_t T, const double *__restrict__ raw,
+                                                          double *__restrict__ Bt_inv) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T) return;
+  constexpr int n = 12;
+  double A[n * n], L[n * n], W[n * n];
+  bool keep[n];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) A[i * n + j] = 0.5 * (raw[t * 144 + i * n + j] + raw[t * 144 + j * n + i]);
+  for (int e = 0; e < n * n; ++e) L[e] = W[e] = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double sdiag = A[j * n + j];
+    for (int k = 0; k < j; ++k) sdiag -= L[j * n + k] * L[j * n + k];
+    keep[j] = sdiag > 1e-10 * A[j * n + j] && A[j * n + j] > 0.0;
+    if (!keep[j]) {
+      for (int k = 0; k < n; ++k) L[j * n + k] = 0.0;
+      L[j * n + j] = 1.0;
+      continue;
+    }
+    const double dd = sqrt(sdiag);
+    L[j * n + j] = dd;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = v / dd;
+    }
+  }
+  for (int j = 0; j < n; ++j) {
+    W[j * n + j] = 1.0 / L[j * n + j];
+    for (int i = j + 1; i < n; ++i) {
+      double v = 0.0;
+      for (int k = j; k < i; ++k) v -= L[i * n + k] * W[k * n + j];
+      W[i * n + j] = v / L[i * n + i];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double v = 0.0;
+      for (int k = (i > j ? i : j); k < n; ++k) v += W[k * n + i] * W[k * n + j];
+      Bt_inv[t * 144 + i * n + j] = (keep[i] && keep[j]) ? v : 0.0;
+    }
 }
 // ---------------------------------------------------------------------------------------------------------------
 // r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
@@ -563,7 +737,8 @@ __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__
 
 // PT = storage type of the search direction p and of Ap, RT = of the iterate x and the residual r (double / float:
 // opts.precision).  Every sum is accumulated in fp64 whatever the storage.
-template <typename PT, typename RT>
+// TM = modes of the tile level: 6, or 12 (rigid + uniform strains, single-GPU handles: Coarse::tile_modes)
+template <typename PT, typename RT, int TM = 6>
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
@@ -580,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const uint8_t *__restrict__ shared /* may be null */,
                                                             double *__restrict__ rcL, int ncp,
                                                             const uint8_t *__restrict__ skip_rows /* may be null */) {
-  __shared__ double red[20][kBlock / kWave];
+  __shared__ double red[26][kBlock / kWave];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -588,11 +763,19 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  double bi[6] = {0, 0, 0, 0, 0, 0};   // row threadIdx.x of B_t^-1, fetched early: it is needed at the very end
-  if (Bt_inv && threadIdx.x < 6) {
+  // row of B_t^-1 of the lane that will need it at the very end, fetched early.  TM = 12: lanes 0-5 hold the rigid
+  // modes, 8-13 the strain modes (6, 7 carry r.r and r.D^-1 r as before)
+  double bi[TM];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bi[j] = Bt_inv[(size_t)t * 36 + 6 * threadIdx.x + j];
+  for (int j = 0; j < TM; ++j) bi[j] = 0.0;
+  const int my_mode = (TM == 12) ? ((int)threadIdx.x < 6 ? (int)threadIdx.x : ((int)threadIdx.x >= 8 && (int)threadIdx.x < 14
+                                                                                   ? (int)threadIdx.x - 2 : -1))
+                                 : ((int)threadIdx.x < 6 ? (int)threadIdx.x : -1);
+  if (Bt_inv && my_mode >= 0) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) bi[j] = Bt_inv[(size_t)t * (TM * TM) + TM * my_mode + j];
   }
+  double accS[6] = {0, 0, 0, 0, 0, 0};   // TM = 12: strain restrictions of the tile
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // rank-local dense level (multi-GPU): its own aggregates / reference points, nodes shared with other ranks left out
   const int aL = aggL_of_tile ? aggL_of_tile[t] : 0;
@@ -644,6 +827,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
     }
+    if (TM == 12) {
+      accS[0] += rx * ru[0];
+      accS[1] += ry * ru[1];
+      accS[2] += rz * ru[2];
+      accS[3] += 0.5 * (ry * ru[0] + rx * ru[1]);
+      accS[4] += 0.5 * (rz * ru[1] + ry * ru[2]);
+      accS[5] += 0.5 * (rz * ru[0] + rx * ru[2]);
+    }
     if (own_t && !shared[i]) {
       accT[0] += rv[0];
       accT[1] += rv[1];
@@ -682,6 +873,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (lane == 0) red[14 + k][wv] = s;
     }
   }
+  if (TM == 12) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double s = wave_sum(accS[k]);
+      if (lane == 0) red[20 + k][wv] = s;
+    }
+  }
   __syncthreads();
   const int pubL = nw > 1 ? kWave : 8;   // wave 1 publishes the local restriction (lanes 8..13 of wave 0 if it is alone)
   if (aggL_of_tile && (int)threadIdx.x >= pubL && (int)threadIdx.x < pubL + 6) {
@@ -689,6 +887,32 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     double s = 0.0;
     for (int q = 0; q < nw; ++q) s += red[8 + k][q];
     unsafeAtomicAdd(rcL + 6 * aL + k, s);
+  }
+  if (TM == 12) {   // lanes 0-5 rigid sums, 6 r.r, 7 r.D^-1 r, 8-13 strain sums
+    if (threadIdx.x < 16) {
+      const int src = (int)threadIdx.x < 8 ? (int)threadIdx.x : 12 + (int)threadIdx.x;    // rows 20..25 of red for lanes 8..13
+      double s = 0.0;
+      if (threadIdx.x < 14)
+        for (int q = 0; q < nw; ++q) s += red[src][q];
+      if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
+      else if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, s);
+      if (!Bt_inv) {
+        if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
+      } else {
+        const double st = my_mode >= 0 ? s : 0.0;          // this lane's component of the tile restriction
+        double y = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y += bi[j] * __shfl(st, j < 6 ? j : j + 2, 16);
+        if (my_mode >= 0) yt[12 * (size_t)t + my_mode] = y;
+        double v = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
+        v += __shfl_xor(v, 1, 16);
+        v += __shfl_xor(v, 2, 16);
+        v += __shfl_xor(v, 4, 16);
+        v += __shfl_xor(v, 8, 16);
+        if (threadIdx.x == 0) unsafeAtomicAdd(rdr_slot, v);
+      }
+    }
+    return;
   }
   if (threadIdx.x < 8) {
     double s = 0.0;
@@ -887,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void k_condense_backsubst(int64_t nc, const
 
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
 // One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
-template <typename PT, typename RT>
+template <typename PT, typename RT, int TM = 6>
 __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *__restrict__ tile_start,
                                                                  const RT *__restrict__ r,
                                                                  const float *__restrict__ dinv32,
@@ -935,11 +1159,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   const int a = agg_of_tile[t];
   const double *y = yc + 6 * a;
   double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
-  double T[6] = {0, 0, 0, 0, 0, 0};
-  if (yt) {   // the tile's modes use the same reference point, so the two rigid motions just add ...
-    const double *q = yt + 6 * (size_t)t;
+  double T[TM];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) T[k] = q[k];
+  for (int k = 0; k < TM; ++k) T[k] = 0.0;
+  if (yt) {   // the tile's modes use the same reference point, so the two rigid motions just add ...
+    const double *q = yt + TM * (size_t)t;
+#pragma unroll
+    for (int k = 0; k < TM; ++k) T[k] = q[k];
     if (!shared) {
       U0 += T[0]; U1 += T[1]; U2 += T[2]; W0 += T[3]; W1 += T[4]; W2 += T[5];
     }
@@ -961,6 +1187,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     if (zero_rows && zero_rows[i]) continue;
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
+    if (TM == 12) {   // the tile's uniform strains: u += eps r
+      zc[0] += T[6] * rx + 0.5 * (T[9] * ry + T[11] * rz);
+      zc[1] += T[7] * ry + 0.5 * (T[9] * rx + T[10] * rz);
+      zc[2] += T[8] * rz + 0.5 * (T[10] * ry + T[11] * rx);
+    }
     if (own_t && !shared[i]) {
       zc[0] += T[0] + (T[4] * rz - T[5] * ry);
       zc[1] += T[1] + (T[5] * rx - T[3] * rz);

@@ -91,16 +91,34 @@ b = f[v]
 reg = lambda M: M + 1e-12 * np.trace(M) / len(M) * np.eye(len(M))
 
 
-def level(gc, dense):
+def strain_modes(xyz, agg, n_agg):
+    """six uniform strains per aggregate: u = eps (x - c), no rotation"""
+    cnt = np.maximum(np.bincount(agg, minlength=n_agg), 1)
+    cen = np.stack([np.bincount(agg, xyz[:, k], n_agg) for k in range(3)], 1) / cnt[:, None]
+    r = xyz - cen[agg]
+    N = len(xyz)
+    rows, cols, vals = [], [], []
+    for q, (a, b2) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)]):
+        rows.append(6 * np.arange(N) + a); cols.append(6 * agg + q); vals.append(r[:, b2] if a == b2 else 0.5 * r[:, b2])
+        if a != b2:
+            rows.append(6 * np.arange(N) + b2); cols.append(6 * agg + q); vals.append(0.5 * r[:, a])
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(6 * N, 6 * n_agg))
+
+
+def level(gc, dense, affine=False):
     na = int(np.ceil(n / gc - 1e-9))
     cell = np.minimum((xyz / gc).astype(int), na - 1)
     agg = (cell[:, 0] * na + cell[:, 1]) * na + cell[:, 2]
-    Z = rigid_modes(xyz, agg, na ** 3)[v]
+    Z = rigid_modes(xyz, agg, na ** 3)
+    if affine:      # columns interleaved per aggregate: [6 rigid | 6 strain] -> block id = column // 6 % ... keep it simple:
+        Zs = strain_modes(xyz, agg, na ** 3)
+        Z = sp.hstack([Z, Zs]).tocsr()
+    Z = Z[v]
     keep = np.flatnonzero(np.asarray(abs(Z).sum(axis=0)).ravel() > 0)
     Z = Z[:, keep].tocsr()
     B = (Z.T @ A @ Z).toarray()
     if not dense:
-        aid = keep // 6
+        aid = (keep % (6 * na ** 3)) // 6
         B = B * (aid[:, None] == aid[None, :])
     cfac = sla.cho_factor(reg(B))
     return lambda r: Z @ sla.cho_solve(cfac, Z.T @ r), Z.shape[1]
@@ -110,9 +128,10 @@ print(f"{geom} {n}^3: {lat.n_beams} struts, {len(v)} unknowns", flush=True)
 dense_apply, nd = level(g_dense, True)
 x_ref, it = pcg(A, b, lambda r: r / d + dense_apply(r))
 print(f"  Jacobi + dense level ({g_dense:g}^3 cells, {nd} dofs): {it}", flush=True)
+affine = bool(int(os.environ.get("AFFINE", "0")))
 applied = []
 for gb in g_blocks:
-    fn, nb = level(gb, False)
+    fn, nb = level(gb, False, affine)
     applied.append(fn)
     x, it = pcg(A, b, lambda r: r / d + dense_apply(r) + sum(fn(r) for fn in applied))
     assert np.linalg.norm(x - x_ref) < 1e-5 * np.linalg.norm(x_ref)
