@@ -53,7 +53,7 @@ struct Coarse {
   double *Bt_inv = nullptr, *yt = nullptr;   // [n_tiles * tm * tm], [n_tiles * tm], tm = tile_modes
   // Modes of the tile level: 6 (rigid body) or 12 (+ the six uniform strains u = eps (x - c), no rotation).  A piecewise
   // rigid field follows a macroscopic strain only with jumps across tile faces; the strain modes let a tile deform with
-  // it.  Measured: 134 -> ... iterations at 50^3 Octet, 509 -> ... at 100^3 BCC.
+  // it.  Measured: 134 -> 126 iterations at 50^3 Octet, 396 -> 369 at 100^3 BCC (rtol 1e-6), DESIGN.md section 7.
   int tile_modes = 6;
   double *Bt_raw = nullptr;                  // [n_tiles * 144] B_t before the inversion (12 modes only)
   // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
@@ -755,7 +755,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const uint8_t *__restrict__ shared /* may be null */,
                                                             double *__restrict__ rcL, int ncp,
                                                             const uint8_t *__restrict__ skip_rows /* may be null */) {
-  __shared__ double red[26][kBlock / kWave];
+  __shared__ double red[26][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
+  __shared__ double sst[16], sv[16];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -853,35 +854,38 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       accL[5] += rv[5] + (sx * rv[1] - sy * rv[0]);
     }
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;   // 1 to 4 waves per tile
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nw = 4 * (blockDim.x >> 6);         // partial sums per quantity: one per row of 16 lanes
+  const bool row_end = (lane & 15) == 15;
+  const int slot = 4 * wv + (lane >> 4);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const double s = wave_sum(acc[k]);
-    if (lane == 0) red[k][wv] = s;
+    const double s = row_sums(acc[k]);
+    if (row_end) red[k][slot] = s;
   }
   if (aggL_of_tile) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double s = wave_sum(accL[k]);
-      if (lane == 0) red[8 + k][wv] = s;
+      const double s = row_sums(accL[k]);
+      if (row_end) red[8 + k][slot] = s;
     }
   }
   if (own_t) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double s = wave_sum(accT[k]);
-      if (lane == 0) red[14 + k][wv] = s;
+      const double s = row_sums(accT[k]);
+      if (row_end) red[14 + k][slot] = s;
     }
   }
   if (TM == 12) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double s = wave_sum(accS[k]);
-      if (lane == 0) red[20 + k][wv] = s;
+      const double s = row_sums(accS[k]);
+      if (row_end) red[20 + k][slot] = s;
     }
   }
   __syncthreads();
-  const int pubL = nw > 1 ? kWave : 8;   // wave 1 publishes the local restriction (lanes 8..13 of wave 0 if it is alone)
+  const int pubL = blockDim.x > kWave ? kWave : 8;   // wave 1 publishes the local restriction (lanes 8..13 of wave 0 if it is alone)
   if (aggL_of_tile && (int)threadIdx.x >= pubL && (int)threadIdx.x < pubL + 6) {
     const int k = threadIdx.x - pubL;
     double s = 0.0;
@@ -899,17 +903,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (!Bt_inv) {
         if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
       } else {
+        // the 12 x 12 product through LDS (one wave, its LDS operations are in order): 12 independent broadcast reads
+        // per lane instead of 24 dependent ds_bpermute
         const double st = my_mode >= 0 ? s : 0.0;          // this lane's component of the tile restriction
+        sst[threadIdx.x] = st;
         double y = 0.0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) y += bi[j] * __shfl(st, j < 6 ? j : j + 2, 16);
+        for (int j = 0; j < 12; ++j) y += bi[j] * sst[j < 6 ? j : j + 2];
         if (my_mode >= 0) yt[12 * (size_t)t + my_mode] = y;
-        double v = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
-        v += __shfl_xor(v, 1, 16);
-        v += __shfl_xor(v, 2, 16);
-        v += __shfl_xor(v, 4, 16);
-        v += __shfl_xor(v, 8, 16);
-        if (threadIdx.x == 0) unsafeAtomicAdd(rdr_slot, v);
+        sv[threadIdx.x] = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
+        if (threadIdx.x == 0) {
+          double v = 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v += sv[j];
+          unsafeAtomicAdd(rdr_slot, v);
+        }
       }
     }
     return;

@@ -34,6 +34,14 @@ __device__ __forceinline__ double dpp_row_shr_add(double v, const int ctrl_tag) 
   }
   return v + __hiloint2double(hi, lo);
 }
+// The first half of wave_sum alone: afterwards lanes 15, 31, 47, 63 hold the totals of their rows of 16 lanes (callers
+// that go through LDS anyway store those four instead of paying the v_readlane round)
+__device__ __forceinline__ double row_sums(double v) {
+  v = dpp_row_shr_add(v, 1);
+  v = dpp_row_shr_add(v, 2);
+  v = dpp_row_shr_add(v, 4);
+  return dpp_row_shr_add(v, 8);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_row_shr_add(v, 1);
   v = dpp_row_shr_add(v, 2);
