@@ -362,10 +362,10 @@ def main():
                                    "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
         streaming.update({"bound": "hbm", "kernel": "K*p: k_spmv_tile<.., kRecCompact>", "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "algorithmic_bytes": ab["spmv"],
-                          "traffic": (2.0 * 131265.84375 + 24286.015625) * 1024.0,
-                          "traffic_source": "profiles/r02_ak_pmc_streaming_p0.json / _gr.json (separate rocprofv3 --pmc FETCH_SIZE and "
-                                            "WRITE_SIZE passes of tools/prof_stream.sh: 2 x 134.4 MB fetched + 24.9 MB "
-                                            "written per launch, 1.10 x the algorithmic bytes)"})
+                          "traffic": (2.0 * 128243.78125 + 24283.578125) * 1024.0,
+                          "traffic_source": "profiles/r02_bm_pmc_streaming_p0.json / _gr.json (separate rocprofv3 --pmc FETCH_SIZE and "
+                                            "WRITE_SIZE passes of tools/prof_stream.sh: 2 x 131.3 MB fetched + 24.9 MB "
+                                            "written per launch, 1.07 x the algorithmic bytes)"})
 
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
