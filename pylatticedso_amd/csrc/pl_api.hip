@@ -507,7 +507,7 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
                        c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                        reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, fb,
                        cs.Bt_raw);
-    hipLaunchKernelGGL(pl::k_tile_invert12, dim3(grid_for(cs.n_tiles)), dim3(pl::kBlock), 0, st, cs.n_tiles,
+    hipLaunchKernelGGL(pl::k_tile_invert12, dim3(grid_for(cs.n_tiles, pl::kInv12Block)), dim3(pl::kInv12Block), 0, st, cs.n_tiles,
                        (const double *)cs.Bt_raw, cs.Bt_inv);
   }
   PL_HIP(hipGetLastError());

@@ -684,47 +684,53 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
     }
   }
 }
-// B_t^-1 of the 12-mode tile level, one thread per tile (modes without stiffness are dropped, as in spd6_inverse)
-__global__ __launch_bounds__(kBlock) void k_tile_invert12(int64_t T, const double *__restrict__ raw,
-                                                          double *__restrict__ Bt_inv) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+// B_t^-1 of the 12-mode tile level: one thread per tile, the matrix in LDS (column of 64 threads: conflict-free), inverted
+// in place by twelve symmetric sweeps (Gauss-Jordan on an SPD matrix needs no pivoting); a mode whose pivot has lost ten
+// digits against its own diagonal entry has no stiffness of its own (all its dofs fixed, or it repeats earlier modes) and
+// is dropped - zero row and column, as in spd6_inverse.
+constexpr int kInv12Block = 64;
+__global__ __launch_bounds__(kInv12Block) void k_tile_invert12(int64_t T, const double *__restrict__ raw,
+                                                              double *__restrict__ Bt_inv) {
+  __shared__ double As[144][kInv12Block];
+  const int64_t t = (int64_t)blockIdx.x * kInv12Block + threadIdx.x;
   if (t >= T) return;
   constexpr int n = 12;
-  double A[n * n], L[n * n], W[n * n];
-  bool keep[n];
+  const int me = threadIdx.x;
+  double diag0[n];
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) A[i * n + j] = 0.5 * (raw[t * 144 + i * n + j] + raw[t * 144 + j * n + i]);
-  for (int e = 0; e < n * n; ++e) L[e] = W[e] = 0.0;
-  for (int j = 0; j < n; ++j) {
-    double sdiag = A[j * n + j];
-    for (int k = 0; k < j; ++k) sdiag -= L[j * n + k] * L[j * n + k];
-    keep[j] = sdiag > 1e-10 * A[j * n + j] && A[j * n + j] > 0.0;
-    if (!keep[j]) {
-      for (int k = 0; k < n; ++k) L[j * n + k] = 0.0;
-      L[j * n + j] = 1.0;
+    for (int j = 0; j < n; ++j) As[i * n + j][me] = 0.5 * (raw[t * 144 + i * n + j] + raw[t * 144 + j * n + i]);
+#pragma unroll
+  for (int i = 0; i < n; ++i) diag0[i] = As[i * n + i][me];
+  unsigned dropped = 0u;
+  for (int k = 0; k < n; ++k) {
+    const double d = As[k * n + k][me];
+    if (!(d > 1e-10 * diag0[k]) || !(diag0[k] > 0.0)) {
+      dropped |= 1u << k;
       continue;
     }
-    const double dd = sqrt(sdiag);
-    L[j * n + j] = dd;
-    for (int i = j + 1; i < n; ++i) {
-      double v = A[i * n + j];
-      for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
-      L[i * n + j] = v / dd;
+    const double inv = 1.0 / d;
+    // sweep on pivot k (rows / columns of dropped modes stay out of it)
+    for (int i = 0; i < n; ++i) {
+      if (i == k || ((dropped >> i) & 1u)) continue;
+      const double f = As[i * n + k][me] * inv;
+      for (int j = 0; j < n; ++j) {
+        if (j == k || ((dropped >> j) & 1u)) continue;
+        As[i * n + j][me] -= f * As[k * n + j][me];
+      }
     }
-  }
-  for (int j = 0; j < n; ++j) {
-    W[j * n + j] = 1.0 / L[j * n + j];
-    for (int i = j + 1; i < n; ++i) {
-      double v = 0.0;
-      for (int k = j; k < i; ++k) v -= L[i * n + k] * W[k * n + j];
-      W[i * n + j] = v / L[i * n + i];
+    for (int j = 0; j < n; ++j) {
+      if (j == k) continue;
+      const double v = As[k * n + j][me] * inv;
+      As[k * n + j][me] = v;
+      As[j * n + k][me] = v;
     }
+    As[k * n + k][me] = -inv;
   }
+  // after sweeping every kept pivot the kept block holds -B^-1 (off-diagonal signs flipped back below)
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) {
-      double v = 0.0;
-      for (int k = (i > j ? i : j); k < n; ++k) v += W[k * n + i] * W[k * n + j];
-      Bt_inv[t * 144 + i * n + j] = (keep[i] && keep[j]) ? v : 0.0;
+      const bool out = ((dropped >> i) & 1u) || ((dropped >> j) & 1u);
+      Bt_inv[t * 144 + i * n + j] = out ? 0.0 : -As[i * n + j][me];
     }
 }
 // ---------------------------------------------------------------------------------------------------------------
