@@ -152,6 +152,7 @@ struct pl_context {
   // exact elimination of an independent node set inside the PCG (opts.condense, pl_coarse.h)
   std::vector<uint8_t> h_cand;        // candidates (an independent set of the node graph, chosen at pl_create; device numbering)
   std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
+  DevBuf<uint8_t> cend;           // strut -> bits: end A / B is a condensed node (pl_tile.h CondSolve)
   DevBuf<int32_t> cnodes, cbase;  // condensed nodes; node -> offset of its K_cc^-1 block (class table or per node), -1
   int cbase_state = -1;           // what cbase was built for: -1 stale, 0 per-node blocks, 1 class table
   DevBuf<double> kcc_inv;
@@ -253,6 +254,13 @@ int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, doub
 
 // y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
 // K_cc^-1 for the fused first pass of the condensed operator (kEndsCondensedSolve)
+__global__ __launch_bounds__(pl::kBlock) void k_cond_ends(int64_t B, const int2 *__restrict__ conn2,
+                                                         const uint8_t *__restrict__ cflag, uint8_t *__restrict__ cend) {
+  const int64_t b = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int2 c = conn2[b];
+  cend[b] = (uint8_t)((cflag[c.x] ? 1 : 0) | (cflag[c.y] ? 2 : 0));
+}
 __global__ __launch_bounds__(pl::kBlock) void k_cond_base(int64_t nc, const int32_t *__restrict__ cnodes,
                                                          const uint16_t *__restrict__ cls /* may be null */,
                                                          int32_t *__restrict__ base) {
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(pl::kBlock) void k_cond_base(int64_t nc, const int3
 }
 inline pl::CondSolve cond_solve(pl_context *c, int ends) {
   pl::CondSolve cs;
+  if (ends != pl::kEndsAll) cs.cend = c->cend.p;
   if (ends == pl::kEndsCondensedSolve) {
     const int want = c->cls_ready ? 1 : 0;
     if (c->cbase_state != want) {   // (after pl_set_bc / when the class table comes or goes: once per assembly at most)
@@ -632,6 +641,11 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   c->cbase_state = -1;
   PL_HIP(hipMemcpy(c->maskC.p, mask.data(), N, hipMemcpyHostToDevice));
   PL_HIP(hipMemcpy(c->cflag.p, flag.data(), N, hipMemcpyHostToDevice));
+  // per strut: which ends are condensed (read by every pass of the condensed operator)
+  if (!c->cend.p) PL_HIP(c->cend.alloc(c->B));
+  hipLaunchKernelGGL(k_cond_ends, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B,
+                     reinterpret_cast<const int2 *>(c->conn.p), (const uint8_t *)c->cflag.p, c->cend.p);
+  PL_HIP(hipGetLastError());
   c->n_cond = (int64_t)picked.size();
   return PL_OK;
 }

@@ -286,6 +286,8 @@ enum { kEndsAll = 0, kEndsCondensed = 1, kEndsOthers = 2, kEndsCondensedSolve = 
 struct CondSolve {            // K_cc^-1 of the condensed nodes (pl_coarse.h)
   const double *inv = nullptr;     // 6 x 6 blocks: the class table, or one block per condensed node
   const int32_t *base = nullptr;   // node -> offset of its block in inv (doubles); < 0: not a condensed node
+  const uint8_t *cend = nullptr;   // strut -> bit 0 / 1: end A / B is a condensed node (every pass of the condensed operator:
+                                   // fetched one visit ahead with conn, instead of two dependent byte loads per visit)
 };
 // (c = conn2[b] and pid = pal[b] come from the caller, which fetches them one visit ahead: tile_struts)
 template <int REC, int ENDS, typename VT>
@@ -300,19 +302,17 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
     r.a = q.a; r.c = q.c; r.e1 = q.e1; r.e2 = q.e2; r.e3 = q.e3;
     r.dx = pb[0] - pa[0]; r.dy = pb[1] - pa[1]; r.dz = pb[2] - pa[2];
   } else {
-    r = (REC == kRecPalette) ? load_record(rec, pid) : load_record(rec, b);
+    r = (REC == kRecPalette) ? load_record(rec, pid & 0xFFFFu) : load_record(rec, b);
   }
-  V3 uA, tA, uB, tB, F, M;
-  load6(x + 6 * (int64_t)c.x, uA, tA);
-  load6(x + 6 * (int64_t)c.y, uB, tB);
+  V3 uA = {0, 0, 0}, tA = {0, 0, 0}, uB = {0, 0, 0}, tB = {0, 0, 0}, F, M;
   constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
   bool takeB = c.y >= n0 && c.y < n1, takeA = c.x >= n0 && c.x < n1;
+  // (pid carries the strut's condensed-end bits above the palette id: CondSolve::cend)
+  const bool cA = ENDS != kEndsAll && ((pid >> 16) & 1u), cB = ENDS != kEndsAll && ((pid >> 17) & 1u);
+  // a condensed end's own row is being rewritten by its tile in the fused first pass: it counts as zero and is not read
+  if (!(ENDS == kEndsCondensedSolve && cA)) load6(x + 6 * (int64_t)c.x, uA, tA);
+  if (!(ENDS == kEndsCondensedSolve && cB)) load6(x + 6 * (int64_t)c.y, uB, tB);
   if (ENDS != kEndsAll) {
-    const bool cB = cflag[c.y] != 0, cA = cflag[c.x] != 0;
-    if (ENDS == kEndsCondensedSolve) {     // a condensed end's own row is being rewritten by its tile: it counts as zero
-      if (cA) { uA = {0, 0, 0}; tA = {0, 0, 0}; }
-      if (cB) { uB = {0, 0, 0}; tB = {0, 0, 0}; }
-    }
     takeB = takeB && (cB == kToCondensed);
     takeA = takeA && (cA == kToCondensed);
   }
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   if (live) {
     cn = conn2[b];
     if (REC == kRecPalette) pid = pal[b];
+    if (ENDS != kEndsAll) pid |= (unsigned)cs.cend[b] << 16;
   }
   while (live) {
     // next visit: the following home strut, else this thread's first / next foreign one
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     if (live_n) {
       cn_n = conn2[bn];
       if (REC == kRecPalette) pid_n = pal[bn];
+      if (ENDS != kEndsAll) pid_n |= (unsigned)cs.cend[bn] << 16;
     }
     tile_strut<REC, ENDS, VT>(b, cn, pid, n0, n1, rec, xyz, cflag, x, ys, stride);
     b = bn;
