@@ -1041,36 +1041,46 @@ __global__ __launch_bounds__(kBlock) void k_cls_hash(int64_t nc, const int32_t *
   }
   key[q] = h == ~0ull ? 0 : h;
 }
+// (one probe per wave and distinct key, as k_pal_insert: a million nodes share a few dozen classes)
+__device__ __forceinline__ int cls_probe(unsigned long long h, unsigned long long *__restrict__ keys,
+                                         int *__restrict__ owner, int q) {
+  unsigned slot = (unsigned)(h >> 48);
+  for (int probe = 0; probe < 32; ++probe) {
+    unsigned long long cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == ~0ull) cur = atomicCAS(keys + slot, ~0ull, h);
+    if (cur == ~0ull || cur == h) {
+      if (q < __hip_atomic_load(owner + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(owner + slot, q);
+      return (int)slot;
+    }
+    slot = (slot + 1) & 65535u;
+  }
+  return -1;
+}
 __global__ __launch_bounds__(kBlock) void k_cls_insert(int64_t nc, const unsigned long long *__restrict__ key,
                                                        unsigned long long *__restrict__ keys, int *__restrict__ owner,
                                                        uint16_t *__restrict__ cls, int *__restrict__ flags) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int found = -1;
-  if (q < nc) {
-    const unsigned long long h = key[q];
-    unsigned slot = (unsigned)(h >> 48);
-    for (int probe = 0; probe < 32; ++probe) {
-      unsigned long long cur = keys[slot];
-      if (cur == ~0ull) cur = atomicCAS(keys + slot, ~0ull, h);
-      if (cur == ~0ull || cur == h) {
-        found = (int)slot;
-        break;
-      }
-      slot = (slot + 1) & 65535u;
-    }
+  const bool valid = q < nc;
+  const unsigned long long h = valid ? key[q] : 0ull;
+  const int lane = threadIdx.x & 63;
+  int found = -2;                                   // -2: not settled yet, -1: table full
+  unsigned long long todo = __ballot(valid);
+  for (int round = 0; round < 12 && todo; ++round) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned long long hl =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h >> 32), leader) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h & 0xFFFFFFFFull), leader);
+    const unsigned long long same = __ballot(valid && found == -2 && h == hl);
+    int sl = 0;
+    if (lane == leader) sl = cls_probe(h, keys, owner, (int)q);   // the lowest lane of the group: the smallest node
+    sl = __builtin_amdgcn_readlane(sl, leader);
+    if ((same >> lane) & 1ull) found = sl;
+    todo &= ~same;
+  }
+  if (valid && found == -2) found = cls_probe(h, keys, owner, (int)q);
+  if (valid) {
     if (found < 0) flags[0] = 1;
     else cls[q] = (uint16_t)found;
-  }
-  // owner = smallest node of the class: one check per wave and class (as k_pal_insert)
-  unsigned long long todo = __ballot(found >= 0);
-  const int lane = threadIdx.x & 63;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int s = __builtin_amdgcn_readlane(found, leader);
-    const unsigned long long same = __ballot(found == s);
-    if (lane == leader && (int)q < __hip_atomic_load(owner + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMin(owner + s, (int)q);
-    todo &= ~same;
   }
 }
 __global__ __launch_bounds__(kBlock) void k_cls_publish(int64_t nc, const double *__restrict__ inv,
