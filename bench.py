@@ -170,6 +170,8 @@ def main():
                          "graphs such as BCC), 1 = whenever possible, -1 = never (see pylattice_hip.h)")
     ap.add_argument("--tile-modes", type=int, default=0,
                     help="modes per block of the preconditioner's tile level: 0 / 12 = rigid + uniform strains, 6 = rigid")
+    ap.add_argument("--coarse-modes", type=int, default=0,
+                    help="modes per aggregate of the dense level: 0 / 6 = rigid, 12 = rigid + uniform strains")
     ap.add_argument("--cg-form", type=int, default=0,
                     help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
                          "vectors); 0 = ordinary form")
@@ -246,7 +248,8 @@ def main():
     dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                            reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
                            tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision,
-                           condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes)
+                           condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes,
+                           coarse_modes=args.coarse_modes)
     n_beams_total = len(conn)
     if multi:
         keys = [None] * world

@@ -75,7 +75,8 @@ struct pl_context {
   // pl_assemble overlaps the latency-bound dense factorisation chain (main stream) with the bandwidth-bound fills
   // (palette, Jacobi diagonal, tile blocks, explicit BSR) on a second stream
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipStream_t side2 = nullptr;   // tile blocks of the 12-mode dense level beside its strain rows
   bool assembled = false, have_bc = false, have_bsr = false;
   int pal_fallback_flags[2] = {1, 0};
   int *pal_host_flags = pal_fallback_flags;   // pinned once the palette is in use: a D2H copy into pageable memory blocks the host
@@ -180,6 +181,9 @@ struct pl_context {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_chol) (void)hipEventDestroy(ev_chol);
+    if (ev_t0) (void)hipEventDestroy(ev_t0);
+    if (ev_t1) (void)hipEventDestroy(ev_t1);
+    if (side2) (void)hipStreamDestroy(side2);
     if (side) (void)hipStreamDestroy(side);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -505,6 +509,7 @@ inline int tile_modes_now(const pl_context *c) {
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
   pl::Coarse &cs = c->coarse;
   if (!cs.enabled || !c->have_bc || !cs.tile_level) return PL_OK;
+  if (cs.cm == 12) return PL_OK;        // built inside build_coarse_level, which needs them first
   const uint8_t *fb = c->dist.active ? c->maskL.p : c->fixedbits.p;
   const bool twelve = tile_modes_now(c) == 12;
   hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
@@ -531,10 +536,40 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     if (after_chol) after_chol();
     return PL_OK;
   }
+  bool tile_invert_pending = false;
   const int n = cs.ncp;
   if (!cs.ac_clean) PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), c->stream));
   cs.ac_clean = false;
   PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), c->stream));
+  if (cs.cm == 12) {
+    // 12 modes per aggregate: A_c from the 12 x 12 tile blocks (built HERE, ahead of the factorisation that needs them,
+    // instead of beside it on the side stream) plus the cross-tile struts
+    const dim3 gt((unsigned)cs.n_tiles), blk(pl::kBlock);
+    const int2 *conn2 = reinterpret_cast<const int2 *>(c->conn.p);
+    // (the rigid x rigid part on a second stream beside the strain rows and the cross-tile struts; the inversion of the
+    // tile blocks, which only the solve needs, beside the factorisation)
+    PL_HIP(hipEventRecord(c->ev_t0, c->stream));
+    PL_HIP(hipStreamWaitEvent(c->side2, c->ev_t0, 0));
+    hipLaunchKernelGGL(pl::k_tile_blocks, gt, blk, 0, c->side2, c->tile.tile_start.p, c->tile.home_ptr.p,
+                       c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                       mask, cs.Bt_inv, cs.Bt_raw);
+    PL_HIP(hipEventRecord(c->ev_t1, c->side2));
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+                       c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                       mask, cs.Bt_raw);
+    if (cs.n_cross > 0)
+      hipLaunchKernelGGL(pl::k_coarse_cross12, dim3(grid_for(cs.n_cross)), blk, 0, c->stream, cs.n_cross,
+                         cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, mask, n, cs.Ac);
+    PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
+    hipLaunchKernelGGL(pl::k_agg_add_tiles, dim3(grid_for(cs.n_tiles * 144)), blk, 0, c->stream, cs.n_tiles,
+                       cs.agg_of_tile.p, (const double *)cs.Bt_raw, n, cs.Ac);
+    PL_HIP(hipEventRecord(c->ev_t0, c->stream));
+    PL_HIP(hipStreamWaitEvent(c->side2, c->ev_t0, 0));
+    hipLaunchKernelGGL(pl::k_tile_invert12, dim3(grid_for(cs.n_tiles, pl::kInv12Block)), dim3(pl::kInv12Block), 0,
+                       c->side2, cs.n_tiles, (const double *)cs.Bt_raw, cs.Bt_inv);
+    PL_HIP(hipEventRecord(c->ev_t1, c->side2));
+    tile_invert_pending = true;
+  } else {
   if (cs.n_fix < 0) {   // Dirichlet set changed: list the in-aggregate struts that touch it, grouped by aggregate
     if (!cs.fix_count) PL_HIP(hipMalloc((void **)&cs.fix_count, sizeof(int)));
     int cnt = 0;
@@ -575,6 +610,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     hipLaunchKernelGGL(pl::k_coarse_assemble_cross, dim3(grid_for(cs.n_cross)), dim3(pl::kBlock), 0, c->stream,
                        cs.n_cross, cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p,
                        mask, n, cs.Ac);
+  }
   if (reduce && c->dist.active) {   // every rank holds the contribution of ITS struts; all ranks then factor the same matrix
     const int nb = n / pl::kNB;
     if (cs.bw_blocks > 0 && cs.bw_blocks + 1 < nb) {   // only the block band of the lower triangle travels (L_f is free)
@@ -592,6 +628,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
   pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream, after_chol,
                            c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr);
+  if (tile_invert_pending) PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
   PL_HIP(hipMemcpyAsync(info, cs.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
@@ -725,7 +762,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
-                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr)
+                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
   if (tile_modes_now(c) == 12) PL_UPD(12);
   else PL_UPD(6);
 #undef PL_UPD
@@ -746,7 +783,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      c->hist.p, hist_slot, cs.rc, cs.ncp,                                                                \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
-                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr)
+                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
   if (tile_modes_now(c) == 12) PL_DIR(12);
   else PL_DIR(6);
 #undef PL_DIR
@@ -1470,10 +1507,23 @@ void pl_default_opts(pl_opts_t *o) {
 
 namespace {
 inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
+// modes per aggregate of the dense level: 12 (rigid + strains) needs the 12-mode tile level, i.e. a single-GPU handle in
+// the ordinary CG form with precond = 3
+inline int coarse_modes_of(const pl_opts_t *o, int64_t N = -1) {
+  const bool tile12 = o->precond == 3 && !(o->tile_modes == 6 || multi_rank_handle(o) || o->cg_form == 1);
+  if (!tile12 || o->coarse_modes == 6) return 6;
+  // automatic: from a quarter of a million nodes on (below, the longer set-up of the richer level costs what its
+  // iterations save: 32^3 Octet 178 M beams/s with 6 modes, 169 M with 12)
+  return (o->coarse_modes == 12 || N < 0 || N >= 250000) ? 12 : 6;
+}
 // dofs the dense level may have (see the comment at its set-up in pl_create)
 inline int coarse_budget(const pl_opts_t *o, int64_t N) {
   const bool multi_rank = o->grid_nodes > 0;
-  return o->coarse_max_dofs > 0 ? o->coarse_max_dofs : ((multi_rank || N >= 1000000) ? 3072 : 2100);
+  if (o->coarse_max_dofs > 0) return o->coarse_max_dofs;
+  // 12 modes per aggregate: 5^3 aggregates (1 500 dofs) beat 7^3 x 6 (2 058) below a million nodes - 120 against 126
+  // iterations at 50^3 Octet, 24 chain links instead of 33 (measured: 1 536 -> 203, 2 600 -> 200, 800 -> 193 M beams/s)
+  if (coarse_modes_of(o, N) == 12) return N >= 1000000 ? 3072 : (N >= 250000 ? 1536 : 768);   // 6^3 / 5^3 / 4^3 aggregates
+  return (multi_rank || N >= 1000000) ? 3072 : 2100;
 }
 }  // namespace
 
@@ -1547,6 +1597,9 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_chol, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
+  PL_HIPC(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
 
   // node ordering on the device
   const double global_grid[7] = {o->grid_lo[0], o->grid_lo[1], o->grid_lo[2], o->grid_hi[0], o->grid_hi[1],
@@ -1560,7 +1613,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     pl::spatial_order(m->node_xyz, N, c->perm, tile_start,
                       (double)(o->tile_nodes > 0 ? std::min(o->tile_nodes, pl::kTileMaxNodes) : 256), tile_brick,
                       grid, o->grid_nodes > 0 ? global_grid : nullptr,
-                      (o->precond >= 2 && o->precond <= 4) ? coarse_budget(o, N) : 0);
+                      (o->precond >= 2 && o->precond <= 4) ? coarse_budget(o, N) * 6 / coarse_modes_of(o, N) : 0);
     c->reordered = true;
   } else {
     pl::chunk_tiles(N, tile_start);
@@ -1702,7 +1755,8 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     // every iteration) the full 3 072
     const bool multi_rank = o->grid_nodes > 0;
     const int max_dofs = coarse_budget(o, N);
-    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn, false, multi_rank);
+    int rc = pl::coarse_setup(c->coarse, tile_start, tile_brick, grid, xyz.data(), N, max_dofs, conn, false, multi_rank,
+                              coarse_modes_of(o, N));
     if (rc == 4)
       return bail(fail(PL_ERR_ARG, "pl_create: a strut spans more than neighbouring aggregates; the band-packed "
                                    "all-reduce of the coarse operator of a multi-GPU handle cannot hold it (use "
@@ -1798,6 +1852,9 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_chol, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
+  PL_HIPC(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   c->perm.resize(n_nodes);
   std::iota(c->perm.begin(), c->perm.end(), 0);
   c->iperm = c->perm;
@@ -2518,6 +2575,8 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   if (!valid(h) || !unique_id || world < 1 || rank < 0 || rank >= world || n_shared < 0)
     return fail(PL_ERR_ARG, "pl_dist_init: bad argument");
   if (n_shared > 0 && (!shared_local || !shared_global)) return fail(PL_ERR_ARG, "pl_dist_init: null index array");
+  if (h->coarse.cm == 12)
+    return fail(PL_ERR_STATE, "pl_dist_init: opts.coarse_modes = 12 is a single-GPU setting (create the handle with 0 / 6)");
   PL_HIP(hipSetDevice(h->opt.device));
   std::vector<int32_t> loc(n_shared);
   for (int i = 0; i < n_shared; ++i) {

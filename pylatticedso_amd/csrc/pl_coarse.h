@@ -35,6 +35,10 @@ struct Coarse {
   bool enabled = false;     // topology prepared (pl_create)
   bool ready = false;       // A_c^-1 valid (pl_assemble)
   int n_agg = 0, nc = 0, ncp = 0;   // ncp = nc rounded up to the dense block size (padding rows are identity)
+  // modes per aggregate: 6 rigid-body modes, or 12 = rigid + the six uniform strains (as the tile level's; needs
+  // tile_modes = 12, whose per-tile sums it shares).  Host experiment (tools/experiments/multilevel_aggregates.py, 24^3
+  // Octet): 5^3 aggregates x 12 modes (1500 dofs) need 11 % fewer iterations than 7^3 x 6 (2058 dofs).
+  int cm = 6;
   int bw_blocks = 0;                // block bandwidth of A_c (aggregates couple to their 26 neighbours only)
   int64_t n_tiles = 0;
   int vblock = kBlock;     // threads per workgroup of the per-tile vector kernels: the longest tile rounded up to whole waves
@@ -81,8 +85,9 @@ struct Coarse {
 // handle are numbered, and g is chosen from their count - the level is never summed over ranks.
 inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const std::vector<int64_t> &tile_brick,
                         const BrickGrid &grid, const double *xyz_dev_order, int64_t N, int max_dofs,
-                        const std::vector<int32_t> &conn, bool local = false, bool multi_rank = false) {
+                        const std::vector<int32_t> &conn, bool local = false, bool multi_rank = false, int modes = 6) {
   const int64_t T = (int64_t)tile_start.size() - 1;
+  c.cm = modes;
   const int64_t *nbrick = grid.nb;
   // aggregate index of a brick along axis k: floor(b * na_k / nb_k) - groups of bricks whose sizes differ by at most one,
   // so that the aggregate grid can use the dofs it is allowed (13 bricks per axis -> 8 aggregates, not ceil(13/2) = 7)
@@ -103,7 +108,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
   for (int step = 0;; ++step) {
     const double scale = 1.5 + 0.125 * step;       // bricks per aggregate and axis, at least 1.5
     for (int k = 0; k < 3; ++k) na[k] = std::max<int64_t>(1, (int64_t)std::floor((double)nbrick[k] / scale));
-    if (!local && step == 0 && grid.na[0] > 0 && 6 * grid.na[0] * grid.na[1] * grid.na[2] <= max_dofs)
+    if (!local && step == 0 && grid.na[0] > 0 && modes * grid.na[0] * grid.na[1] * grid.na[2] <= max_dofs)
       for (int k = 0; k < 3; ++k) na[k] = grid.na[k];   // the aggregate grid the bricks were cut to fit (spatial_order)
     int64_t count = na[0] * na[1] * na[2];
     if (local) {
@@ -113,7 +118,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
       used.erase(std::unique(used.begin(), used.end()), used.end());
       count = (int64_t)used.size();
     }
-    if (count * 6 <= max_dofs || scale > 64.0) break;
+    if (count * modes <= max_dofs || scale > 64.0) break;
   }
   const int n_agg = local ? (int)used.size() : (int)(na[0] * na[1] * na[2]);
   std::vector<int32_t> agg_of_tile(T), agg_of_node(N);
@@ -140,7 +145,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     if (hipMalloc((void **)&c.dinv32, (size_t)N * 6 * sizeof(float)) != hipSuccess) return 2;
   }
   c.n_agg = n_agg;
-  c.nc = 6 * n_agg;
+  c.nc = modes * n_agg;
   c.n_tiles = T;
   {
     int longest = 1;
@@ -152,9 +157,16 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     // coarse block and can reduce in registers before touching memory
     const int64_t B = (int64_t)conn.size() / 2;
     std::vector<std::pair<int64_t, int32_t>> cross;
+    std::vector<int32_t> tile_of_node;
+    if (modes == 12) {   // 12 modes: the list holds every strut whose ends lie in different TILES (k_coarse_cross12)
+      tile_of_node.resize(N);
+      for (int64_t t = 0; t < T; ++t)
+        for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of_node[i] = (int32_t)t;
+    }
     for (int64_t b = 0; b < B; ++b) {
       const int I = agg_of_node[conn[2 * b]], J = agg_of_node[conn[2 * b + 1]];
-      if (I != J) cross.push_back({(int64_t)I * n_agg + J, (int32_t)b});
+      if (I != J || (modes == 12 && tile_of_node[conn[2 * b]] != tile_of_node[conn[2 * b + 1]]))
+        cross.push_back({(int64_t)I * n_agg + J, (int32_t)b});
     }
     // struts join neighbouring bricks only, so aggregates couple to their 26 neighbours: a bound from the aggregate
     // grid alone (identical on every rank of a multi-GPU run, whatever struts this rank holds)
@@ -163,7 +175,7 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
       max_diff = 0;
       for (const auto &pr : cross) max_diff = std::max<int64_t>(max_diff, std::abs(pr.first / n_agg - pr.first % n_agg));
     }
-    c.bw_blocks = (int)((6 * (max_diff + 1) + kNB - 1) / kNB + 1);
+    c.bw_blocks = (int)((modes * (max_diff + 1) + kNB - 1) / kNB + 1);
     for (const auto &pr : cross)   // struts longer than an aggregate (degenerate tiling): no band assumption
       if (std::abs(pr.first / n_agg - pr.first % n_agg) > max_diff) {
         // ... on one GPU.  On several, bw_blocks decides the size of the all-reduce of A_c and must be the same on
@@ -386,6 +398,118 @@ __global__ __launch_bounds__(kBlock) void k_coarse_assemble_cross(int64_t n_cros
   }
 }
 
+// ---- 12-mode tile level: the strain rows / columns of B_t.  Mode 6 + q of a node at r = x - c (translations only):
+//   q = 0, 1, 2: eps_xx, eps_yy, eps_zz -> u = (rx, 0, 0), (0, ry, 0), (0, 0, rz);
+//   q = 3, 4, 5: eps_xy, eps_yz, eps_xz -> u = (ry, rx, 0) / 2, (0, rz, ry) / 2, (rz, 0, rx) / 2.
+__device__ __forceinline__ V3 strain_disp(int q, const double *r) {
+  switch (q) {
+    case 0: return {r[0], 0.0, 0.0};
+    case 1: return {0.0, r[1], 0.0};
+    case 2: return {0.0, 0.0, r[2]};
+    case 3: return {0.5 * r[1], 0.5 * r[0], 0.0};
+    case 4: return {0.0, 0.5 * r[2], 0.5 * r[1]};
+    default: return {0.5 * r[2], 0.0, 0.5 * r[0]};
+  }
+}
+// Z_S^T f for a force F at r: the six strain restrictions
+__device__ __forceinline__ void strain_restrict(const V3 &F, const double *r, double *s6, double sign) {
+  s6[0] += sign * r[0] * F.x;
+  s6[1] += sign * r[1] * F.y;
+  s6[2] += sign * r[2] * F.z;
+  s6[3] += sign * 0.5 * (r[1] * F.x + r[0] * F.y);
+  s6[4] += sign * 0.5 * (r[2] * F.y + r[1] * F.z);
+  s6[5] += sign * 0.5 * (r[2] * F.x + r[0] * F.z);
+}
+__device__ __forceinline__ V3 mask3(V3 v, unsigned bits) {
+  return {(bits & 1u) ? 0.0 : v.x, (bits & 2u) ? 0.0 : v.y, (bits & 4u) ? 0.0 : v.z};
+}
+// ---- 12 modes per aggregate (rigid + uniform strains).  With the tile blocks B_t = Z_t^T P K P Z_t taken about the
+// aggregate's reference point (k_tile_blocks + k_tile_blocks_strain, 12 x 12),
+//     A_c = sum over tiles of B_t (into the diagonal block of the tile's aggregate)
+//         + sum over struts whose ends lie in different tiles of Z_A^T K_AB Z_B and its transpose,
+// since a tile block already holds K_AA / K_BB of every strut that touches the tile.
+__global__ __launch_bounds__(kBlock) void k_agg_add_tiles(int64_t T, const int32_t *__restrict__ agg_of_tile,
+                                                          const double *__restrict__ raw, int nc,
+                                                          double *__restrict__ Ac) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = q / 144;
+  if (t >= T) return;
+  const int e = (int)(q - 144 * t), i = e / 12, j = e - 12 * i;
+  if (j > i) return;                                       // the factorisation reads the lower triangle
+  const int a = agg_of_tile[t];
+  const double v = 0.5 * (raw[t * 144 + i * 12 + j] + raw[t * 144 + j * 12 + i]);
+  if (v != 0.0) unsafeAtomicAdd(Ac + ((size_t)12 * a + i) * nc + 12 * a + j, v);
+}
+// displacement of mode n (0-5 rigid, 6-11 strain) of an aggregate at a node r = x - c
+__device__ __forceinline__ void mode_disp(int n, const double *r, V3 &u, V3 &th) {
+  th = {0.0, 0.0, 0.0};
+  if (n >= 6) {
+    u = strain_disp(n - 6, r);
+    return;
+  }
+  switch (n) {
+    case 0: u = {1.0, 0.0, 0.0}; break;
+    case 1: u = {0.0, 1.0, 0.0}; break;
+    case 2: u = {0.0, 0.0, 1.0}; break;
+    case 3: u = {0.0, -r[2], r[1]}; th = {1.0, 0.0, 0.0}; break;      // e_x x r
+    case 4: u = {r[2], 0.0, -r[0]}; th = {0.0, 1.0, 0.0}; break;
+    default: u = {-r[1], r[0], 0.0}; th = {0.0, 0.0, 1.0}; break;
+  }
+}
+// Cross-tile struts in (I, J)-sorted order, every ordered pair padded to whole waves (dead lanes replicate lane 0 and add
+// nothing).  Column n of X = Z_A^T K_AB Z_B is the force on end A under mode n of B's aggregate at B (A held), restricted
+// by the twelve modes of A's aggregate; X goes to (I, J) and its transpose to (J, I) (for I = J both into the same block).
+__global__ __launch_bounds__(kBlock) void k_coarse_cross12(int64_t n_cross, const int32_t *__restrict__ list,
+                                                           const int32_t *__restrict__ conn,
+                                                           const Record *__restrict__ rec,
+                                                           const int32_t *__restrict__ agg,
+                                                           const double *__restrict__ cen,
+                                                           const double *__restrict__ xyz,
+                                                           const uint8_t *__restrict__ fixedbits, int nc,
+                                                           double *__restrict__ Ac) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((q & ~(int64_t)(kWave - 1)) >= n_cross) return;        // whole wave past the end
+  const bool live = list[q] >= 0;
+  const int64_t b = live ? list[q] : list[q & ~(int64_t)(kWave - 1)];   // lane 0 of a wave is never padding
+  const int ia = conn[2 * b], ib = conn[2 * b + 1];
+  const int I = agg[ia], J = agg[ib];
+  const unsigned fa = fixedbits ? fixedbits[ia] : 0u, fb = fixedbits ? fixedbits[ib] : 0u;
+  const Record r = load_record(rec, b);
+  double rela[3], relb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rela[k] = xyz[3 * (int64_t)ia + k] - cen[3 * I + k];
+    relb[k] = xyz[3 * (int64_t)ib + k] - cen[3 * J + k];
+  }
+  const V3 d = {r.dx, r.dy, r.dz}, zero = {0.0, 0.0, 0.0};
+  const int lane = threadIdx.x & 63;
+  for (int n = 0; n < 12; ++n) {
+    V3 uB, tB;
+    mode_disp(n, relb, uB, tB);
+    uB = mask3(uB, fb);
+    tB = mask3(tB, fb >> 3);
+    V3 F, M;
+    tip_force(r, zero, zero, uB, tB, F, M);                  // force on B; on A: -F, -M - d x F
+    const V3 FA = mask3((-1.0) * F, fa), MA = mask3((-1.0) * M - cross(d, F), fa >> 3);
+    double x[12] = {FA.x, FA.y, FA.z,
+                    MA.x + (rela[1] * FA.z - rela[2] * FA.y), MA.y + (rela[2] * FA.x - rela[0] * FA.z),
+                    MA.z + (rela[0] * FA.y - rela[1] * FA.x), 0, 0, 0, 0, 0, 0};
+    strain_restrict(FA, rela, x + 6, 1.0);
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      const double v = wave_sum(live ? x[m] : 0.0);
+      if (lane == 0 && v != 0.0) {
+        const size_t ri = (size_t)12 * I + m, cj = (size_t)12 * J + n;
+        // lower triangle only: X[m][n] at (ri, cj) or its mirror image; inside one aggregate X and X^T meet in the same
+        // block, so its diagonal takes X[m][m] twice
+        if (ri > cj) unsafeAtomicAdd(Ac + ri * nc + cj, v);
+        else if (cj > ri) unsafeAtomicAdd(Ac + cj * nc + ri, v);
+        else unsafeAtomicAdd(Ac + ri * nc + cj, 2.0 * v);
+      }
+    }
+  }
+}
+
 // Rows/cols with a zero diagonal (aggregate without free support for that mode) -> identity; symmetrise round-off.
 __global__ void k_coarse_regularize(int nc, double *__restrict__ Ac) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,31 +691,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
   }
 }
 
-// ---- 12-mode tile level: the strain rows / columns of B_t.  Mode 6 + q of a node at r = x - c (translations only):
-//   q = 0, 1, 2: eps_xx, eps_yy, eps_zz -> u = (rx, 0, 0), (0, ry, 0), (0, 0, rz);
-//   q = 3, 4, 5: eps_xy, eps_yz, eps_xz -> u = (ry, rx, 0) / 2, (0, rz, ry) / 2, (rz, 0, rx) / 2.
-__device__ __forceinline__ V3 strain_disp(int q, const double *r) {
-  switch (q) {
-    case 0: return {r[0], 0.0, 0.0};
-    case 1: return {0.0, r[1], 0.0};
-    case 2: return {0.0, 0.0, r[2]};
-    case 3: return {0.5 * r[1], 0.5 * r[0], 0.0};
-    case 4: return {0.0, 0.5 * r[2], 0.5 * r[1]};
-    default: return {0.5 * r[2], 0.0, 0.5 * r[0]};
-  }
-}
-// Z_S^T f for a force F at r: the six strain restrictions
-__device__ __forceinline__ void strain_restrict(const V3 &F, const double *r, double *s6, double sign) {
-  s6[0] += sign * r[0] * F.x;
-  s6[1] += sign * r[1] * F.y;
-  s6[2] += sign * r[2] * F.z;
-  s6[3] += sign * 0.5 * (r[1] * F.x + r[0] * F.y);
-  s6[4] += sign * 0.5 * (r[2] * F.y + r[1] * F.z);
-  s6[5] += sign * 0.5 * (r[2] * F.x + r[0] * F.z);
-}
-__device__ __forceinline__ V3 mask3(V3 v, unsigned bits) {
-  return {(bits & 1u) ? 0.0 : v.x, (bits & 2u) ? 0.0 : v.y, (bits & 4u) ? 0.0 : v.z};
-}
 // One workgroup per tile over ALL the struts the tile visits (a strain mode stores energy in every strut, unlike a rigid
 // one): per strut six evaluations of the tip force under the masked strain displacements of its in-tile ends, restricted
 // back by the strain modes (S x S, 6 x 6 symmetric) and - only for struts that cross the tile boundary or touch a
@@ -760,7 +859,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const double *__restrict__ cenL,
                                                             const uint8_t *__restrict__ shared /* may be null */,
                                                             double *__restrict__ rcL, int ncp,
-                                                            const uint8_t *__restrict__ skip_rows /* may be null */) {
+                                                            const uint8_t *__restrict__ skip_rows /* may be null */,
+                                                            int cm = 6 /* modes per aggregate of the dense level */) {
   __shared__ double red[26][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
   __shared__ double sst[16], sv[16];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
@@ -904,8 +1004,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       double s = 0.0;
       if (threadIdx.x < 14)
         for (int q = 0; q < nw; ++q) s += red[src][q];
-      if (threadIdx.x < 6) unsafeAtomicAdd(rc + 6 * a + threadIdx.x, s);
+      if (threadIdx.x < 6) unsafeAtomicAdd(rc + cm * a + threadIdx.x, s);
       else if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, s);
+      else if (cm == 12 && threadIdx.x >= 8 && threadIdx.x < 14) unsafeAtomicAdd(rc + cm * a + threadIdx.x - 2, s);
       if (!Bt_inv) {
         if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
       } else {
@@ -1155,7 +1256,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const double *__restrict__ ycL,
                                                                  const uint8_t *__restrict__ shared /* may be null */,
                                                                  double *__restrict__ rcL, int ncpL,
-                                                                 const uint8_t *__restrict__ zero_rows /* may be null */) {
+                                                                 const uint8_t *__restrict__ zero_rows /* may be null */,
+                                                                 int cm = 6) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   const double pap = scalar_read(scal, S_PAP);
@@ -1181,7 +1283,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   const int t = blockIdx.x;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
-  const double *y = yc + 6 * a;
+  const double *y = yc + cm * a;
   double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
   double T[TM];
 #pragma unroll
@@ -1192,6 +1294,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     for (int k = 0; k < TM; ++k) T[k] = q[k];
     if (!shared) {
       U0 += T[0]; U1 += T[1]; U2 += T[2]; W0 += T[3]; W1 += T[4]; W2 += T[5];
+    }
+  }
+  if constexpr (TM == 12) {   // the aggregate's uniform strains share the tile's reference point: they just add
+    if (cm == 12) {
+#pragma unroll
+      for (int k = 6; k < 12; ++k) T[k] += y[k];
     }
   }
   const bool own_t = yt && shared;   // ... except on several GPUs, where nodes shared with other ranks are left out
@@ -1211,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     if (zero_rows && zero_rows[i]) continue;
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
-    if (TM == 12) {   // the tile's uniform strains: u += eps r
+    if constexpr (TM == 12) {   // the tile's uniform strains: u += eps r
       zc[0] += T[6] * rx + 0.5 * (T[9] * ry + T[11] * rz);
       zc[1] += T[7] * ry + 0.5 * (T[9] * rx + T[10] * rz);
       zc[2] += T[8] * rz + 0.5 * (T[10] * ry + T[11] * rx);

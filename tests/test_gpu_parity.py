@@ -482,8 +482,10 @@ def test_two_rank_workload_emulated_on_one_gpu():
     assert len(shared) == 5101
     out = []
     for emulate in (False, True):
+        # (what a rank of a multi-GPU run uses: rigid-body modes in both block levels; the strain modes are a
+        # single-GPU setting)
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
-                              precond=3, palette=1) as dev:
+                              precond=3, palette=1, coarse_modes=6, tile_modes=6) as dev:
             if emulate:
                 dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
             dev.set_bc(fixed, None, f)
@@ -514,6 +516,32 @@ def test_multilevel_preconditioners_same_solution(golden_dir, name):
     # lattices this small have next to nothing for a coarse space to capture (the gain is asserted on a 16^3 lattice
     # below); here the coarse levels must simply not hurt
     assert s2["iterations"] < 1.1 * s1["iterations"]
+
+
+def test_strain_modes_of_the_dense_level():
+    """opts.coarse_modes = 12 (rigid + uniform strains per aggregate, fewer aggregates) against 6: same displacements on a
+    bending-dominated lattice with its cell centres eliminated and on a stretch-dominated one."""
+    from pylatticedso_amd import lattice_arrays as LA
+    for geom, n, r in ((["BCC"], 20, [0.05]), (["Octet"], 20, [0.03])):
+        lat = LA.generate((1, 1, 1), (n, n, n), geom, r)
+        pen = LA.penalize(lat, LA.compute_lzone(lat))
+        fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+        fixed[lat.node_xyz[:, 0] == 0.0] = 1
+        tgt = lat.node_xyz[:, 0] == float(n)
+        f = np.zeros((lat.n_nodes, 6))
+        f[tgt, 2] = -0.1 / tgt.sum()
+        out = {}
+        for cm in (6, 12):
+            with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                                  precond=3, coarse_modes=cm, coarse_max_dofs=768) as dev:
+                dev.set_bc(fixed, None, f)
+                dev.assemble()
+                out[cm] = dev.solve(rtol=1e-10, max_iter=20000)
+                assert out[cm][1]["converged"] == 1
+                res = np.where(fixed != 0, 0.0, f - dev.spmv(out[cm][0]))
+                assert np.linalg.norm(res) <= 2e-10 * np.linalg.norm(f)
+        assert _rel(out[12][0], out[6][0]) < 1e-7
+        assert out[12][1]["iterations"] < 1.05 * out[6][1]["iterations"]
 
 
 def test_strain_modes_of_the_tile_level():

@@ -125,7 +125,7 @@ def level(gc, dense, affine=False):
 
 
 print(f"{geom} {n}^3: {lat.n_beams} struts, {len(v)} unknowns", flush=True)
-dense_apply, nd = level(g_dense, True)
+dense_apply, nd = level(g_dense, True, bool(int(os.environ.get("DENSE_AFFINE", "0"))))
 x_ref, it = pcg(A, b, lambda r: r / d + dense_apply(r))
 print(f"  Jacobi + dense level ({g_dense:g}^3 cells, {nd} dofs): {it}", flush=True)
 affine = bool(int(os.environ.get("AFFINE", "0")))

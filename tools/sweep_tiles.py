@@ -31,7 +31,8 @@ for case in cases:
     for tn in tiles:
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, rad, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
                               precond=3, palette=1, tile_nodes=tn,
-                              tile_modes=int(os.environ.get("TILE_MODES", "0"))) as dev:
+                              tile_modes=int(os.environ.get("TILE_MODES", "0")),
+                              coarse_modes=int(os.environ.get("COARSE_MODES", "0"))) as dev:
             dev.set_bc(fixed, None, f)
             best = None
             for rep in range(3):
