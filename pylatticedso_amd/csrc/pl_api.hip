@@ -1522,7 +1522,9 @@ inline int coarse_budget(const pl_opts_t *o, int64_t N) {
   if (o->coarse_max_dofs > 0) return o->coarse_max_dofs;
   // 12 modes per aggregate: 5^3 aggregates (1 500 dofs) beat 7^3 x 6 (2 058) below a million nodes - 120 against 126
   // iterations at 50^3 Octet, 24 chain links instead of 33 (measured: 1 536 -> 203, 2 600 -> 200, 800 -> 193 M beams/s)
-  if (coarse_modes_of(o, N) == 12) return N >= 1000000 ? 3072 : (N >= 250000 ? 1536 : 768);   // 6^3 / 5^3 / 4^3 aggregates
+  // (the level's cost does not grow with the lattice, its benefit does: 100^3 BCC 3 072 -> 59.7, 6 144 -> 61.4 M beams/s;
+  // 200 x 200 x 50 BCC + Octet 3 072 -> 104.9, 6 144 -> 136.4 M beams/s)
+  if (coarse_modes_of(o, N) == 12) return N >= 2000000 ? 6144 : (N >= 1000000 ? 3072 : (N >= 250000 ? 1536 : 768));
   return (multi_rank || N >= 1000000) ? 3072 : 2100;
 }
 }  // namespace

@@ -455,8 +455,8 @@ def test_full_size_properties_config3():
         dev.assemble()                       # the coarse levels need the Dirichlet set
         u, st = dev.solve(rtol=1e-8, max_iter=50000)
         # BCC is bipartite: the automatic node elimination takes the 10^6 cell centres out (793 -> 503 iterations; 474 with
-        # the strain modes of the tile level)
-        assert st["converged"] == 1 and int(st["precond_used"]) == 3 and st["iterations"] < 520
+        # the strain modes of the tile level, 334 with those of the dense level: the round-1 verdict asked for <= 400)
+        assert st["converged"] == 1 and int(st["precond_used"]) == 3 and st["iterations"] < 400
         assert int(st["condensed_nodes"]) == 1_000_000
         res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
         assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8

@@ -28,7 +28,8 @@ for precision in modes:
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
                           precond=3, palette=1, precision=precision,
                           tile_modes=int(os.environ.get("TILE_MODES", "0")),
-                          coarse_modes=int(os.environ.get("COARSE_MODES", "0"))) as dev:
+                          coarse_modes=int(os.environ.get("COARSE_MODES", "0")),
+                          coarse_max_dofs=int(os.environ.get("COARSE_DOFS", "0"))) as dev:
         t_create = time.time() - t0
         dev.set_bc(fixed, None, f)
         dev.assemble()
