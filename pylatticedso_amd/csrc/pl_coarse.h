@@ -706,14 +706,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
                                                                const double *__restrict__ xyz,
                                                                const uint8_t *__restrict__ fixedbits,
                                                                double *__restrict__ raw) {
-  __shared__ double red[72][kBlock / kWave];
+  __shared__ double red[57][kBlock / kWave];
   const int t = blockIdx.x;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  double SS[36], RS[36];                     // [p][q]: restriction p of the force answering strain q
+  double SS[21], RS[36];                     // [p][q]: restriction p of the force answering strain q (S x S: p <= q only)
 #pragma unroll
-  for (int e = 0; e < 36; ++e) SS[e] = RS[e] = 0.0;
+  for (int e = 0; e < 21; ++e) SS[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 36; ++e) RS[e] = 0.0;
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1], f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
   const int64_t total = (h1 - h0) + (f1 - f0);
   for (int64_t v = threadIdx.x; v < total; v += kBlock) {
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
       if (inb) strain_restrict(FB, relb, s6, 1.0);
       if (ina) strain_restrict(FA, rela, s6, 1.0);
 #pragma unroll
-      for (int p = 0; p < 6; ++p) SS[p * 6 + q] += s6[p];
+      for (int p = 0; p <= q; ++p) SS[q * (q + 1) / 2 + p] += s6[p];        // upper triangle, packed by columns
       if (!free_inside) {
         if (inb) {
           RS[0 * 6 + q] += FB.x;
@@ -761,23 +763,29 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
+  for (int e = 0; e < 21; ++e) {
+    const double s1 = wave_sum(SS[e]);
+    if (lane == 0) red[e][wv] = s1;
+  }
+#pragma unroll
   for (int e = 0; e < 36; ++e) {
-    const double s1 = wave_sum(SS[e]), s2 = wave_sum(RS[e]);
-    if (lane == 0) {
-      red[e][wv] = s1;
-      red[36 + e][wv] = s2;
-    }
+    const double s2 = wave_sum(RS[e]);
+    if (lane == 0) red[21 + e][wv] = s2;
   }
   __syncthreads();
-  if (threadIdx.x < 72) {
+  if (threadIdx.x < 57) {
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < kBlock / kWave; ++q) v += red[threadIdx.x][q];
-    const int e = threadIdx.x % 36, p = e / 6, q = e % 6;
     double *B = raw + (size_t)t * 144;
-    if (threadIdx.x < 36) {
-      B[(6 + p) * 12 + 6 + q] = v;            // S x S (symmetrised by k_tile_invert12)
+    if (threadIdx.x < 21) {
+      int q = 0;
+      while ((q + 1) * (q + 2) / 2 <= (int)threadIdx.x) ++q;     // column of the packed upper triangle
+      const int p = (int)threadIdx.x - q * (q + 1) / 2;
+      B[(6 + p) * 12 + 6 + q] = v;            // S x S, both halves
+      B[(6 + q) * 12 + 6 + p] = v;
     } else {
+      const int e = (int)threadIdx.x - 21, p = e / 6, q = e % 6;
       B[p * 12 + 6 + q] = v;                  // R x S and its transpose
       B[(6 + q) * 12 + p] = v;
     }
