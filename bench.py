@@ -365,10 +365,10 @@ def main():
                                    "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
         streaming.update({"bound": "hbm", "kernel": "K*p: k_spmv_tile<.., kRecCompact>", "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "algorithmic_bytes": ab["spmv"],
-                          "traffic": (2.0 * 128243.78125 + 24283.578125) * 1024.0,
-                          "traffic_source": "profiles/r02_bm_pmc_streaming_p0.json / _gr.json (separate rocprofv3 --pmc FETCH_SIZE and "
-                                            "WRITE_SIZE passes of tools/prof_stream.sh: 2 x 131.3 MB fetched + 24.9 MB "
-                                            "written per launch, 1.07 x the algorithmic bytes)"})
+                          "traffic": (2.0 * 126177.28125 + 24322.515625) * 1024.0,
+                          "traffic_source": "profiles/r02_cj_pmc_streaming_p0.json / _gr.json (separate rocprofv3 --pmc FETCH_SIZE and "
+                                            "WRITE_SIZE passes of tools/prof_stream.sh: 2 x 129.2 MB fetched + 24.9 MB "
+                                            "written per launch, 1.06 x the algorithmic bytes)"})
 
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
@@ -398,8 +398,9 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
                      "note": "tiles are the bricks of the preconditioner's tile level, nested into the aggregates of its "
-                             "dense level (DESIGN.md section 7): 14^3 tiles of 188 nodes at 50^3 Octet cost K*p 2 us "
-                             "against the 13^3 tiles of round 1 (0.93 -> 0.87) and save 21 of 155 PCG iterations"},
+                             "dense level (DESIGN.md section 7): 15^3 tiles of 152 nodes at 50^3 Octet cost K*p 3 us "
+                             "against the 13^3 tiles of round 1 (0.93 -> 0.86) and, with the strain modes of both block "
+                             "levels, save 35 of 155 PCG iterations"},
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
