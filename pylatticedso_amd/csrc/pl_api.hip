@@ -500,10 +500,11 @@ int launch_local_mask(pl_context *c) {
   return PL_OK;
 }
 
-// modes of the tile level in use: the strain modes need every node of a tile on this rank (no communicator, no rank-local
-// level); decided the same way when the blocks are built and when they are applied
+// modes of the tile level in use (not with the rank-local level of precond = 4); decided the same way when the blocks are
+// built and when they are applied.  With a communicator the strain modes, like the rigid ones, leave out the nodes shared
+// with other ranks.
 inline int tile_modes_now(const pl_context *c) {
-  return (c->coarse.tile_level && c->coarse.tile_modes == 12 && !c->dist.active && !c->coarseL.enabled) ? 12 : 6;
+  return (c->coarse.tile_level && c->coarse.tile_modes == 12 && !c->coarseL.enabled) ? 12 : 6;
 }
 
 int launch_tile_blocks(pl_context *c, hipStream_t st) {
@@ -1510,8 +1511,8 @@ inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
 // modes per aggregate of the dense level: 12 (rigid + strains) needs the 12-mode tile level, i.e. a single-GPU handle in
 // the ordinary CG form with precond = 3
 inline int coarse_modes_of(const pl_opts_t *o, int64_t N = -1) {
-  const bool tile12 = o->precond == 3 && !(o->tile_modes == 6 || multi_rank_handle(o) || o->cg_form == 1);
-  if (!tile12 || o->coarse_modes == 6) return 6;
+  const bool tile12 = o->precond == 3 && !(o->tile_modes == 6 || o->cg_form == 1);
+  if (!tile12 || o->coarse_modes == 6 || multi_rank_handle(o)) return 6;   // (several GPUs: A_c is summed over ranks)
   // automatic: from a quarter of a million nodes on (below, the longer set-up of the richer level costs what its
   // iterations save: 32^3 Octet 178 M beams/s with 6 modes, 169 M with 12)
   return (o->coarse_modes == 12 || N < 0 || N >= 250000) ? 12 : 6;
@@ -1750,7 +1751,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     c->coarse.tile_level = (o->precond >= 3);
     // 12-mode tile level (rigid + uniform strains): single-GPU handles in the ordinary CG form; opts.tile_modes = 6 keeps
     // the rigid-body blocks
-    c->coarse.tile_modes = (o->tile_modes == 6 || multi_rank_handle(o) || o->precond == 4 || o->cg_form == 1) ? 6 : 12;
+    c->coarse.tile_modes = (o->tile_modes == 6 || o->precond == 4 || o->cg_form == 1) ? 6 : 12;
     // default size of the dense level: its factorisation is a ~45 us-per-64-dofs latency chain in every assembly, its
     // benefit grows with the cost of an iteration - up to 1 M nodes on one GPU the optimum is ~2 000 dofs (measured on
     // 50^3 Octet: 7^3 aggregates 18.9 ms per step, 8^3 20.7 ms), beyond that and in multi-rank runs (collectives in

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
     }
-    if (TM == 12) {
+    if (TM == 12 && !(shared && shared[i])) {   // (several GPUs: the tile's strain modes live on this rank's own nodes)
       accS[0] += rx * ru[0];
       accS[1] += ry * ru[1];
       accS[2] += rz * ru[2];
@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       } else {
         // the 12 x 12 product through LDS (one wave, its LDS operations are in order): 12 independent broadcast reads
         // per lane instead of 24 dependent ds_bpermute
-        const double st = my_mode >= 0 ? s : 0.0;          // this lane's component of the tile restriction
+        double st = my_mode >= 0 ? s : 0.0;                // this lane's component of the tile restriction
+        if (own_t && threadIdx.x < 6) {                    // several GPUs: the rigid part without the shared nodes
+          st = 0.0;
+          for (int q = 0; q < nw; ++q) st += red[14 + threadIdx.x][q];
+        }
         sst[threadIdx.x] = st;
         double y = 0.0;
 #pragma unroll
@@ -1328,9 +1332,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     if constexpr (TM == 12) {   // the tile's uniform strains: u += eps r
+     if (!(shared && shared[i])) {
       zc[0] += T[6] * rx + 0.5 * (T[9] * ry + T[11] * rz);
       zc[1] += T[7] * ry + 0.5 * (T[9] * rx + T[10] * rz);
       zc[2] += T[8] * rz + 0.5 * (T[10] * ry + T[11] * rx);
+     }
     }
     if (own_t && !shared[i]) {
       zc[0] += T[0] + (T[4] * rz - T[5] * ry);

@@ -482,10 +482,10 @@ def test_two_rank_workload_emulated_on_one_gpu():
     assert len(shared) == 5101
     out = []
     for emulate in (False, True):
-        # (what a rank of a multi-GPU run uses: rigid-body modes in both block levels; the strain modes are a
-        # single-GPU setting)
+        # (what a rank of a multi-GPU run uses: rigid-body modes in the dense level, whose operator is summed over
+        # ranks; the tile level keeps its strain modes, on the rank's own nodes)
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
-                              precond=3, palette=1, coarse_modes=6, tile_modes=6) as dev:
+                              precond=3, palette=1, coarse_modes=6) as dev:
             if emulate:
                 dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
             dev.set_bc(fixed, None, f)
