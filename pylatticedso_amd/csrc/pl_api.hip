@@ -549,21 +549,35 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     const int2 *conn2 = reinterpret_cast<const int2 *>(c->conn.p);
     // (the rigid x rigid part on a second stream beside the strain rows and the cross-tile struts; the inversion of the
     // tile blocks, which only the solve needs, beside the factorisation)
+    // Several GPUs: A_c is the sum over ranks of what each rank's struts give on ALL nodes (Dirichlet mask only), while the
+    // tile LEVEL lives on this rank's own nodes (mask | shared): two sets of tile blocks, the second one for the level.
+    const bool two_sets = c->dist.active;
+    if (two_sets) {
+      if (!cs.Bt_rawA && hipMalloc((void **)&cs.Bt_rawA, (size_t)cs.n_tiles * 144 * sizeof(double)) != hipSuccess)
+        return fail(PL_ERR_HIP, "pl_assemble: out of device memory for the tile blocks");
+      hipLaunchKernelGGL(pl::k_tile_blocks, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+                         c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p,
+                         c->xyz.p, (const uint8_t *)c->maskL.p, cs.Bt_inv, cs.Bt_raw);
+      hipLaunchKernelGGL(pl::k_tile_blocks_strain, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+                         c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p,
+                         c->xyz.p, (const uint8_t *)c->maskL.p, cs.Bt_raw);
+    }
+    double *rawA = two_sets ? cs.Bt_rawA : cs.Bt_raw;
     PL_HIP(hipEventRecord(c->ev_t0, c->stream));
     PL_HIP(hipStreamWaitEvent(c->side2, c->ev_t0, 0));
     hipLaunchKernelGGL(pl::k_tile_blocks, gt, blk, 0, c->side2, c->tile.tile_start.p, c->tile.home_ptr.p,
                        c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                       mask, cs.Bt_inv, cs.Bt_raw);
+                       mask, cs.Bt_inv, rawA);
     PL_HIP(hipEventRecord(c->ev_t1, c->side2));
     hipLaunchKernelGGL(pl::k_tile_blocks_strain, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
                        c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                       mask, cs.Bt_raw);
+                       mask, rawA);
     if (cs.n_cross > 0)
       hipLaunchKernelGGL(pl::k_coarse_cross12, dim3(grid_for(cs.n_cross)), blk, 0, c->stream, cs.n_cross,
                          cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, mask, n, cs.Ac);
     PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
     hipLaunchKernelGGL(pl::k_agg_add_tiles, dim3(grid_for(cs.n_tiles * 144)), blk, 0, c->stream, cs.n_tiles,
-                       cs.agg_of_tile.p, (const double *)cs.Bt_raw, n, cs.Ac);
+                       cs.agg_of_tile.p, (const double *)rawA, n, cs.Ac);
     PL_HIP(hipEventRecord(c->ev_t0, c->stream));
     PL_HIP(hipStreamWaitEvent(c->side2, c->ev_t0, 0));
     hipLaunchKernelGGL(pl::k_tile_invert12, dim3(grid_for(cs.n_tiles, pl::kInv12Block)), dim3(pl::kInv12Block), 0,
@@ -1512,7 +1526,8 @@ inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
 // the ordinary CG form with precond = 3
 inline int coarse_modes_of(const pl_opts_t *o, int64_t N = -1) {
   const bool tile12 = o->precond == 3 && !(o->tile_modes == 6 || o->cg_form == 1);
-  if (!tile12 || o->coarse_modes == 6 || multi_rank_handle(o)) return 6;   // (several GPUs: A_c is summed over ranks)
+  if (!tile12 || o->coarse_modes == 6) return 6;
+  if (multi_rank_handle(o)) N = o->grid_nodes;       // every rank must decide alike: the node count of the whole lattice
   // automatic: from a quarter of a million nodes on (below, the longer set-up of the richer level costs what its
   // iterations save: 32^3 Octet 178 M beams/s with 6 modes, 169 M with 12)
   return (o->coarse_modes == 12 || N < 0 || N >= 250000) ? 12 : 6;
@@ -1525,8 +1540,12 @@ inline int coarse_budget(const pl_opts_t *o, int64_t N) {
   // iterations at 50^3 Octet, 24 chain links instead of 33 (measured: 1 536 -> 203, 2 600 -> 200, 800 -> 193 M beams/s)
   // (the level's cost does not grow with the lattice, its benefit does: 100^3 BCC 3 072 -> 59.7, 6 144 -> 61.4 M beams/s;
   // 200 x 200 x 50 BCC + Octet 3 072 -> 104.9, 6 144 -> 136.4 M beams/s)
+  // several GPUs: replicated on every rank and all-reduced per assembly, decided on the node count of the WHOLE lattice so
+  // that every rank decides alike.  Emulated 4 / 8 ranks (50 x 50N x 50 Octet): 161 / 179 iterations with 6 modes and 3 072
+  // dofs, 139 / 174 with 12 modes and 3 072, 120 / 139 with 12 modes and 6 144
+  if (multi_rank) return (coarse_modes_of(o, N) == 12 && o->grid_nodes >= 2000000) ? 6144 : 3072;
   if (coarse_modes_of(o, N) == 12) return N >= 2000000 ? 6144 : (N >= 1000000 ? 3072 : (N >= 250000 ? 1536 : 768));
-  return (multi_rank || N >= 1000000) ? 3072 : 2100;
+  return N >= 1000000 ? 3072 : 2100;
 }
 }  // namespace
 
@@ -2578,8 +2597,6 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   if (!valid(h) || !unique_id || world < 1 || rank < 0 || rank >= world || n_shared < 0)
     return fail(PL_ERR_ARG, "pl_dist_init: bad argument");
   if (n_shared > 0 && (!shared_local || !shared_global)) return fail(PL_ERR_ARG, "pl_dist_init: null index array");
-  if (h->coarse.cm == 12)
-    return fail(PL_ERR_STATE, "pl_dist_init: opts.coarse_modes = 12 is a single-GPU setting (create the handle with 0 / 6)");
   PL_HIP(hipSetDevice(h->opt.device));
   std::vector<int32_t> loc(n_shared);
   for (int i = 0; i < n_shared; ++i) {

@@ -60,6 +60,7 @@ struct Coarse {
   // it.  Measured: 134 -> 126 iterations at 50^3 Octet, 396 -> 369 at 100^3 BCC (rtol 1e-6), DESIGN.md section 7.
   int tile_modes = 6;
   double *Bt_raw = nullptr;                  // [n_tiles * 144] B_t before the inversion (12 modes only)
+  double *Bt_rawA = nullptr;                 // several GPUs, 12-mode dense level: the tile blocks on ALL nodes (for A_c)
   // fp32 copy of D^-1 [6N] read by the two per-iteration vector kernels (a preconditioner only has to be the SAME
   // symmetric operator in every iteration, so rounding the Jacobi weights is free).  The node positions stay fp64:
   // the coarse modes must be EXACTLY rigid per aggregate - their energy is tiny next to ||K||, and a 1e-7 error in
@@ -73,7 +74,7 @@ struct Coarse {
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
                     (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)bar,
-                    (void *)Bt_raw})
+                    (void *)Bt_raw, (void *)Bt_rawA})
       if (q) (void)hipFree(q);
   }
 };
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             double *__restrict__ rcL, int ncp,
                                                             const uint8_t *__restrict__ skip_rows /* may be null */,
                                                             int cm = 6 /* modes per aggregate of the dense level */) {
-  __shared__ double red[26][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
+  __shared__ double red[32][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
   __shared__ double sst[16], sv[16];
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
@@ -891,6 +892,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     for (int j = 0; j < TM; ++j) bi[j] = Bt_inv[(size_t)t * (TM * TM) + TM * my_mode + j];
   }
   double accS[6] = {0, 0, 0, 0, 0, 0};   // TM = 12: strain restrictions of the tile
+  double accD[6] = {0, 0, 0, 0, 0, 0};   // ... and, on several GPUs with a 12-mode dense level, of the aggregate (weighted,
+                                         // shared nodes included; on one GPU the two are the same sums)
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // rank-local dense level (multi-GPU): its own aggregates / reference points, nodes shared with other ranks left out
   const int aL = aggL_of_tile ? aggL_of_tile[t] : 0;
@@ -941,6 +944,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
     for (int k = 0; k < 6; ++k) {
       acc[6] += wt[k] * rv[k] * rv[k];
       acc[7] += wt[k] * dv[k] * rv[k] * rv[k];
+    }
+    if (TM == 12 && cm == 12 && shared) {
+      accD[0] += rx * ru[0];
+      accD[1] += ry * ru[1];
+      accD[2] += rz * ru[2];
+      accD[3] += 0.5 * (ry * ru[0] + rx * ru[1]);
+      accD[4] += 0.5 * (rz * ru[1] + ry * ru[2]);
+      accD[5] += 0.5 * (rz * ru[0] + rx * ru[2]);
     }
     if (TM == 12 && !(shared && shared[i])) {   // (several GPUs: the tile's strain modes live on this rank's own nodes)
       accS[0] += rx * ru[0];
@@ -997,6 +1008,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       const double s = row_sums(accS[k]);
       if (row_end) red[20 + k][slot] = s;
     }
+    if (cm == 12 && shared) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double s = row_sums(accD[k]);
+        if (row_end) red[26 + k][slot] = s;
+      }
+    }
   }
   __syncthreads();
   const int pubL = blockDim.x > kWave ? kWave : 8;   // wave 1 publishes the local restriction (lanes 8..13 of wave 0 if it is alone)
@@ -1014,7 +1032,14 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
         for (int q = 0; q < nw; ++q) s += red[src][q];
       if (threadIdx.x < 6) unsafeAtomicAdd(rc + cm * a + threadIdx.x, s);
       else if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, s);
-      else if (cm == 12 && threadIdx.x >= 8 && threadIdx.x < 14) unsafeAtomicAdd(rc + cm * a + threadIdx.x - 2, s);
+      else if (cm == 12 && threadIdx.x >= 8 && threadIdx.x < 14) {
+        double sd = s;                                       // the aggregate's strain sums
+        if (shared) {
+          sd = 0.0;
+          for (int q = 0; q < nw; ++q) sd += red[18 + threadIdx.x][q];      // rows 26..31
+        }
+        unsafeAtomicAdd(rc + cm * a + threadIdx.x - 2, sd);
+      }
       if (!Bt_inv) {
         if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
       } else {
@@ -1308,10 +1333,18 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       U0 += T[0]; U1 += T[1]; U2 += T[2]; W0 += T[3]; W1 += T[4]; W2 += T[5];
     }
   }
-  if constexpr (TM == 12) {   // the aggregate's uniform strains share the tile's reference point: they just add
+  double ED[6] = {0, 0, 0, 0, 0, 0};   // the aggregate's uniform strains (12-mode dense level)
+  if constexpr (TM == 12) {
     if (cm == 12) {
 #pragma unroll
-      for (int k = 6; k < 12; ++k) T[k] += y[k];
+      for (int k = 0; k < 6; ++k) ED[k] = y[6 + k];
+      if (!shared) {            // one GPU: same reference point, same nodes - they just add to the tile's
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          T[6 + k] += ED[k];
+          ED[k] = 0.0;
+        }
+      }
     }
   }
   const bool own_t = yt && shared;   // ... except on several GPUs, where nodes shared with other ranks are left out
@@ -1331,7 +1364,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     if (zero_rows && zero_rows[i]) continue;
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
-    if constexpr (TM == 12) {   // the tile's uniform strains: u += eps r
+    if constexpr (TM == 12) {   // uniform strains: u += eps r (several GPUs: the aggregate's everywhere, the tile's on own nodes)
+     if (shared && cm == 12) {
+      zc[0] += ED[0] * rx + 0.5 * (ED[3] * ry + ED[5] * rz);
+      zc[1] += ED[1] * ry + 0.5 * (ED[3] * rx + ED[4] * rz);
+      zc[2] += ED[2] * rz + 0.5 * (ED[4] * ry + ED[5] * rx);
+     }
      if (!(shared && shared[i])) {
       zc[0] += T[6] * rx + 0.5 * (T[9] * ry + T[11] * rz);
       zc[1] += T[7] * ry + 0.5 * (T[9] * rx + T[10] * rz);

@@ -15,7 +15,8 @@ shared = np.flatnonzero((np.abs(y / 50.0 - np.round(y / 50.0)) < 1e-9) & (y > 0)
 print(f"N={N}: {lat.n_beams} struts, {len(shared)} shared nodes", flush=True)
 for pc, lmax in ((3, 0), (4, 2200 * N)):
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, 1013.0, 0.3,
-                          precond=pc, palette=1, local_max_dofs=lmax, coarse_modes=6) as dev:
+                          precond=pc, palette=1, local_max_dofs=lmax, coarse_modes=int(os.environ.get("COARSE_MODES", "0")), coarse_max_dofs=int(os.environ.get("COARSE_DOFS", "3072")),
+                          grid=((0.0, 0.0, 0.0), (50.0, 50.0 * N, 50.0), lat.n_nodes)) as dev:
         dev.dist_init(0, 1, _capi.HipLattice.dist_unique_id(), shared, np.arange(len(shared)), len(shared))
         dev.set_bc(fixed, None, f)
         t0 = time.time(); dev.assemble(); ta = time.time() - t0
