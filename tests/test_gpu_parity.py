@@ -518,6 +518,28 @@ def test_multilevel_preconditioners_same_solution(golden_dir, name):
     assert s2["iterations"] < 1.1 * s1["iterations"]
 
 
+@pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "octet_3x2x2_size",
+                                  "bcchybrid1hybrid4_3x2x1_size"])
+def test_strain_mode_levels_match_oracle(golden_dir, name):
+    """The 12-mode block levels (opts.tile_modes = 12, opts.coarse_modes = 12: rigid + uniform strains per tile and per
+    aggregate) forced on the small reference lattices, prescribed displacements and node elimination included: the
+    displacements are the oracle's direct solve."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    for cond in (-1, 1):
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=cond, tile_modes=12, coarse_modes=12) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st["converged"] == 1 and int(st["precond_used"]) == 3
+            assert _rel(u, uref) < 1e-8
+
+
 def test_strain_modes_of_the_dense_level():
     """opts.coarse_modes = 12 (rigid + uniform strains per aggregate, fewer aggregates) against 6: same displacements on a
     bending-dominated lattice with its cell centres eliminated and on a stretch-dominated one."""
