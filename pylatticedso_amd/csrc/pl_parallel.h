@@ -1,16 +1,39 @@
 // Host-side parallel loops of libpylattice_hip (plain std::thread; no OpenMP runtime to clash with the ones PyTorch and
 // numpy bring along).
 #pragma once
+#include <sched.h>
+
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 namespace pl {
 
+// Threads per host loop: the CPUs this process may run on (affinity mask), shared between the ranks of a node when a
+// launcher says how many there are (LOCAL_WORLD_SIZE, as torch.distributed.run sets it), at most 64; PL_HOST_THREADS
+// overrides.
 inline unsigned host_workers() {
-  const unsigned n = std::thread::hardware_concurrency();
-  return std::max(1u, std::min(n ? n : 4u, 64u));
+  static const unsigned cached = []() -> unsigned {
+    if (const char *e = std::getenv("PL_HOST_THREADS")) {
+      const int v = std::atoi(e);
+      if (v > 0) return (unsigned)std::min(v, 256);
+    }
+    unsigned n = std::thread::hardware_concurrency();
+    if (!n) n = 4;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const int c = CPU_COUNT(&set);
+      if (c > 0) n = std::min(n, (unsigned)c);
+    }
+    if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) {
+      const int v = std::atoi(e);
+      if (v > 1) n = std::max(1u, n / (unsigned)v);
+    }
+    return std::max(1u, std::min(n, 64u));
+  }();
+  return cached;
 }
 
 // body(begin, end, worker) on [0, n) cut into one contiguous piece per worker; sequential below `grain` items per worker
