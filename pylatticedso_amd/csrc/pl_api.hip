@@ -799,8 +799,18 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
                      cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
-  if (tile_modes_now(c) == 12) PL_DIR(12);
+#define PL_DIRF(TM)                                                                                                      \
+  hipLaunchKernelGGL((pl::k_pcg_direction_flat<PT, RT, TM>), dim3((unsigned)((3 * c->N + pl::kBlock - 1) / pl::kBlock)),   \
+                     dim3(pl::kBlock), 0, c->stream, c->N, cs.tile_of_node.p, (const RT *)r, cs.dinv32, c->xyz.p,         \
+                     cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
+                     c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
+                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+  if (!c->dist.active && !useL) {   // one GPU: flat mapping (no shared nodes, no rank-local level), contiguous per wave
+    if (tile_modes_now(c) == 12) PL_DIRF(12);
+    else PL_DIRF(6);
+  } else if (tile_modes_now(c) == 12) PL_DIR(12);
   else PL_DIR(6);
+#undef PL_DIRF
 #undef PL_DIR
   PL_HIP(hipGetLastError());
   return PL_OK;

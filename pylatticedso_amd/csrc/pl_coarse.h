@@ -43,6 +43,7 @@ struct Coarse {
   int64_t n_tiles = 0;
   int vblock = kBlock;     // threads per workgroup of the per-tile vector kernels: the longest tile rounded up to whole waves
   TBuf<int32_t> agg_of_node, agg_of_tile;
+  TBuf<int32_t> tile_of_node;   // K*p tile of every node (k_pcg_direction_flat)
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
@@ -158,12 +159,11 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     // coarse block and can reduce in registers before touching memory
     const int64_t B = (int64_t)conn.size() / 2;
     std::vector<std::pair<int64_t, int32_t>> cross;
-    std::vector<int32_t> tile_of_node;
-    if (modes == 12) {   // 12 modes: the list holds every strut whose ends lie in different TILES (k_coarse_cross12)
-      tile_of_node.resize(N);
-      for (int64_t t = 0; t < T; ++t)
-        for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of_node[i] = (int32_t)t;
-    }
+    // 12 modes: the list holds every strut whose ends lie in different TILES (k_coarse_cross12)
+    std::vector<int32_t> tile_of_node(N);
+    for (int64_t t = 0; t < T; ++t)
+      for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of_node[i] = (int32_t)t;
+    if (c.tile_of_node.upload(tile_of_node) != hipSuccess) return 1;
     for (int64_t b = 0; b < B; ++b) {
       const int I = agg_of_node[conn[2 * b]], J = agg_of_node[conn[2 * b + 1]];
       if (I != J || (modes == 12 && tile_of_node[conn[2 * b]] != tile_of_node[conn[2 * b + 1]]))
@@ -1411,6 +1411,98 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
       store_pair(p, 3 * i + q, pp);
     }
   }
+}
+
+// The same update with a flat mapping (one GPU, no rank-local level): one lane per PAIR of vector entries (three lanes per
+// node), so a wave's loads and stores of r, p, x are 1 KB contiguous (the per-tile kernel strides lanes by 48 bytes and
+// leaves the last wave of a 152-node tile at 24 of 64 lanes); the tile's and the aggregate's coefficients come through
+// the caches, the same address for almost every lane of a wave.  50^3 Octet: iteration 99.4 -> 97.0 us.
+// (All six components are formed and the lane's pair selected afterwards: an if / else-if chain over the pair index with
+// the strain terms inside was miscompiled by hipcc 7.2 for TM = 12 - components 4, 5 came out as 0 / garbage.)
+template <typename PT, typename RT, int TM>
+__global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const int32_t *__restrict__ tile_of_node,
+                                                               const RT *__restrict__ r,
+                                                               const float *__restrict__ dinv32,
+                                                               const double *__restrict__ xyz,
+                                                               const int32_t *__restrict__ agg_of_tile,
+                                                               const double *__restrict__ cen,
+                                                               const double *__restrict__ yc,
+                                                               const double *__restrict__ yt /* may be null */,
+                                                               const uint8_t *__restrict__ fixedbits,
+                                                               PT *__restrict__ p, RT *__restrict__ x,
+                                                               const double *__restrict__ scal,
+                                                               double *__restrict__ scal_next,
+                                                               double *__restrict__ hist, int k,
+                                                               double *__restrict__ rc, int ncp,
+                                                               const uint8_t *__restrict__ zero_rows /* may be null */,
+                                                               int cm) {
+  const double old = scalar_read(scal, S_RZ_OLD);
+  const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
+  const double pap = scalar_read(scal, S_PAP);
+  const double alpha = (pap != 0.0) ? old / pap : 0.0;
+  if (blockIdx.x == 1 || gridDim.x == 1)
+    for (int e = threadIdx.x; e < ncp; e += blockDim.x) rc[e] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < kWave) {
+    const int s = threadIdx.x;
+    double rr = 0.0;
+    for (int q = s; q < kSlots; q += kWave) rr += rc[ncp + q];
+    rr = wave_sum(rr);
+    if (s == 0) hist[k] = rr;
+    for (int q = s; q < kSlots; q += kWave) {
+      rc[ncp + q] = 0.0;
+      rc[ncp + kSlots + q] = 0.0;
+      scal_next[S_RZ_OLD * kSlots + q] = scal[S_RZ_NEW * kSlots + q];
+      scal_next[S_RZ_NEW * kSlots + q] = 0.0;
+      scal_next[S_PAP * kSlots + q] = 0.0;
+    }
+  }
+  const int64_t pair = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= 3 * N) return;
+  const int64_t i = pair / 3;
+  const int q = (int)(pair - 3 * i);
+  if (zero_rows && zero_rows[i]) return;
+  const int t = tile_of_node[i];
+  const int a = agg_of_tile[t];
+  const double *y = yc + cm * a;
+  double C[12];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) C[m] = y[m];
+#pragma unroll
+  for (int m = 6; m < 12; ++m) C[m] = 0.0;
+  if constexpr (TM == 12) {
+    if (cm == 12) {
+#pragma unroll
+      for (int m = 6; m < 12; ++m) C[m] = y[m];
+    }
+  }
+  if (yt) {   // same reference point, same nodes: the tile's coefficients add to the aggregate's
+    const double *w = yt + TM * (size_t)t;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) C[m] += w[m];
+  }
+  const double rx = xyz[3 * i] - cen[3 * a], ry = xyz[3 * i + 1] - cen[3 * a + 1], rz = xyz[3 * i + 2] - cen[3 * a + 2];
+  double zc[6] = {C[0] + (C[4] * rz - C[5] * ry), C[1] + (C[5] * rx - C[3] * rz), C[2] + (C[3] * ry - C[4] * rx),
+                  C[3], C[4], C[5]};
+  if constexpr (TM == 12) {
+    zc[0] += C[6] * rx + 0.5 * (C[9] * ry + C[11] * rz);
+    zc[1] += C[7] * ry + 0.5 * (C[9] * rx + C[10] * rz);
+    zc[2] += C[8] * rz + 0.5 * (C[10] * ry + C[11] * rx);
+  }
+  double z0 = q == 0 ? zc[0] : (q == 1 ? zc[2] : zc[4]);
+  double z1 = q == 0 ? zc[1] : (q == 1 ? zc[3] : zc[5]);
+  const unsigned fb = fixedbits[i];
+  const float2 dd = reinterpret_cast<const float2 *>(dinv32)[pair];
+  const double2 rr = load_pair(r, pair);
+  double2 pp = load_pair(p, pair);
+  double2 xx = load_pair(x, pair);
+  xx.x += alpha * pp.x;
+  xx.y += alpha * pp.y;
+  store_pair(x, pair, xx);
+  z0 = dd.x * rr.x + (((fb >> (2 * q)) & 1u) ? 0.0 : z0);
+  z1 = dd.y * rr.y + (((fb >> (2 * q + 1)) & 1u) ? 0.0 : z1);
+  pp.x = z0 + beta * pp.x;
+  pp.y = z1 + beta * pp.y;
+  store_pair(p, pair, pp);
 }
 
 }  // namespace pl
