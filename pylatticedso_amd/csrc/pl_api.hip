@@ -770,16 +770,21 @@ template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-#define PL_UPD(TM)                                                                                                  \
-  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, \
+  const bool flat = !c->dist.active && !useL;   // one GPU: one lane per pair of vector entries
+#define PL_UPD(TM, PAIRS)                                                                                           \
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM, PAIRS>), dim3((unsigned)cs.n_tiles),                         \
+                     dim3(PAIRS ? pl::kBlock : cs.vblock), 0, c->stream,                                             \
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,                       \
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,             \
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
                      cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
-  if (tile_modes_now(c) == 12) PL_UPD(12);
-  else PL_UPD(6);
+  if (flat) {
+    if (tile_modes_now(c) == 12) PL_UPD(12, true);
+    else PL_UPD(6, true);
+  } else if (tile_modes_now(c) == 12) PL_UPD(12, false);
+  else PL_UPD(6, false);
 #undef PL_UPD
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
@@ -805,7 +810,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
                      c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
                      c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
-  if (!c->dist.active && !useL) {   // one GPU: flat mapping (no shared nodes, no rank-local level), contiguous per wave
+  if (flat) {   // one GPU: flat mapping (no shared nodes, no rank-local level), contiguous per wave
     if (tile_modes_now(c) == 12) PL_DIRF(12);
     else PL_DIRF(6);
   } else if (tile_modes_now(c) == 12) PL_DIR(12);
