@@ -770,7 +770,7 @@ template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-  const bool flat = !c->dist.active && !useL;   // one GPU: one lane per pair of vector entries
+  const bool flat = !useL;   // one lane per pair of vector entries (the rank-local level keeps one lane per node)
 #define PL_UPD(TM, PAIRS)                                                                                           \
   hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM, PAIRS>), dim3((unsigned)cs.n_tiles),                         \
                      dim3(PAIRS ? pl::kBlock : cs.vblock), 0, c->stream,                                             \
@@ -809,8 +809,9 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      dim3(pl::kBlock), 0, c->stream, c->N, cs.tile_of_node.p, (const RT *)r, cs.dinv32, c->xyz.p,         \
                      cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
                      c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
-                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
-  if (flat) {   // one GPU: flat mapping (no shared nodes, no rank-local level), contiguous per wave
+                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm,                      \
+                     c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr)
+  if (flat) {   // flat mapping (no rank-local level), contiguous per wave
     if (tile_modes_now(c) == 12) PL_DIRF(12);
     else PL_DIRF(6);
   } else if (tile_modes_now(c) == 12) PL_DIR(12);

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__
 // PT = storage type of the search direction p and of Ap, RT = of the iterate x and the residual r (double / float:
 // opts.precision).  Every sum is accumulated in fp64 whatever the storage.
 // TM = modes of the tile level: 6, or 12 (rigid + uniform strains, single-GPU handles: Coarse::tile_modes)
-// PAIRS (one GPU: no weights, no shared nodes, no rank-local level): one lane per PAIR of vector entries of the tile (three
+// PAIRS (no rank-local level): one lane per PAIR of vector entries of the tile (three
 // lanes per node) instead of one per node - a wave's loads and stores of r and K p are contiguous, 456 of 512 lane slots
 // busy on a 152-node tile instead of 152 of 192; every lane adds its two entries' share to the same sums.
 template <typename PT, typename RT, int TM = 6, bool PAIRS = false>
@@ -925,24 +925,52 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
         rr.y = (double)(float)rr.y;
       }
       const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
+      double wx = 1.0, wy = 1.0;           // several GPUs: 1 / (ranks holding the node), so that the global sums count it once
+      if (w) {
+        wx = w[2 * pr];
+        wy = w[2 * pr + 1];
+      }
+      const bool own = !(shared && shared[i]);
       // the lane's two entries as a node-sized vector that is zero elsewhere (selects, no branches)
-      const double ru0 = q == 0 ? rr.x : 0.0, ru1 = q == 0 ? rr.y : 0.0, ru2 = q == 1 ? rr.x : 0.0;
-      const double m3 = q == 1 ? rr.y : 0.0, m4 = q == 2 ? rr.x : 0.0, m5 = q == 2 ? rr.y : 0.0;
+      const double vx = wx * rr.x, vy = wy * rr.y;
+      const double ru0 = q == 0 ? vx : 0.0, ru1 = q == 0 ? vy : 0.0, ru2 = q == 1 ? vx : 0.0;
+      const double m3 = q == 1 ? vy : 0.0, m4 = q == 2 ? vx : 0.0, m5 = q == 2 ? vy : 0.0;
       acc[0] += ru0;
       acc[1] += ru1;
       acc[2] += ru2;
       acc[3] += m3 + (ry * ru2 - rz * ru1);
       acc[4] += m4 + (rz * ru0 - rx * ru2);
       acc[5] += m5 + (rx * ru1 - ry * ru0);
-      acc[6] += rr.x * rr.x + rr.y * rr.y;
-      acc[7] += dd.x * rr.x * rr.x + dd.y * rr.y * rr.y;
+      acc[6] += vx * rr.x + vy * rr.y;
+      acc[7] += dd.x * vx * rr.x + dd.y * vy * rr.y;
       if (TM == 12) {
-        accS[0] += rx * ru0;
-        accS[1] += ry * ru1;
-        accS[2] += rz * ru2;
-        accS[3] += 0.5 * (ry * ru0 + rx * ru1);
-        accS[4] += 0.5 * (rz * ru1 + ry * ru2);
-        accS[5] += 0.5 * (rz * ru0 + rx * ru2);
+        const double s0 = rx * ru0, s1 = ry * ru1, s2 = rz * ru2, s3 = 0.5 * (ry * ru0 + rx * ru1),
+                     s4 = 0.5 * (rz * ru1 + ry * ru2), s5 = 0.5 * (rz * ru0 + rx * ru2);
+        if (cm == 12 && shared) {
+          accD[0] += s0;
+          accD[1] += s1;
+          accD[2] += s2;
+          accD[3] += s3;
+          accD[4] += s4;
+          accD[5] += s5;
+        }
+        if (own) {
+          accS[0] += s0;
+          accS[1] += s1;
+          accS[2] += s2;
+          accS[3] += s3;
+          accS[4] += s4;
+          accS[5] += s5;
+        }
+      }
+      if (own_t && own) {                  // the tile's rigid restriction on own nodes (their weight is 1)
+        const double t0 = q == 0 ? rr.x : 0.0, t1 = q == 0 ? rr.y : 0.0, t2 = q == 1 ? rr.x : 0.0;
+        accT[0] += t0;
+        accT[1] += t1;
+        accT[2] += t2;
+        accT[3] += (q == 1 ? rr.y : 0.0) + (ry * t2 - rz * t1);
+        accT[4] += (q == 2 ? rr.x : 0.0) + (rz * t0 - rx * t2);
+        accT[5] += (q == 2 ? rr.y : 0.0) + (rx * t1 - ry * t0);
       }
     }
   } else
@@ -1453,7 +1481,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
   }
 }
 
-// The same update with a flat mapping (one GPU, no rank-local level): one lane per PAIR of vector entries (three lanes per
+// The same update with a flat mapping (no rank-local level): one lane per PAIR of vector entries (three lanes per
 // node), so a wave's loads and stores of r, p, x are 1 KB contiguous (the per-tile kernel strides lanes by 48 bytes and
 // leaves the last wave of a 152-node tile at 24 of 64 lanes); the tile's and the aggregate's coefficients come through
 // the caches, the same address for almost every lane of a wave.  50^3 Octet: iteration 99.4 -> 97.0 us.
@@ -1475,7 +1503,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
                                                                double *__restrict__ hist, int k,
                                                                double *__restrict__ rc, int ncp,
                                                                const uint8_t *__restrict__ zero_rows /* may be null */,
-                                                               int cm) {
+                                                               int cm, const uint8_t *__restrict__ shared /* may be null */) {
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   const double pap = scalar_read(scal, S_PAP);
@@ -1515,8 +1543,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
       for (int m = 6; m < 12; ++m) C[m] = y[m];
     }
   }
-  if (yt) {   // same reference point, same nodes: the tile's coefficients add to the aggregate's
-    const double *w = yt + TM * (size_t)t;
+  if (yt && !(shared && shared[i])) {   // same reference point: the tile's coefficients add to the aggregate's (several
+    const double *w = yt + TM * (size_t)t;   // GPUs: on this rank's own nodes only, as in k_pcg_direction_coarse)
 #pragma unroll
     for (int m = 0; m < TM; ++m) C[m] += w[m];
   }
