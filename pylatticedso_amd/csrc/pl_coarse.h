@@ -852,10 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__
 // PT = storage type of the search direction p and of Ap, RT = of the iterate x and the residual r (double / float:
 // opts.precision).  Every sum is accumulated in fp64 whatever the storage.
 // TM = modes of the tile level: 6, or 12 (rigid + uniform strains, single-GPU handles: Coarse::tile_modes)
-// PAIRS (no rank-local level): one lane per PAIR of vector entries of the tile (three
-// lanes per node) instead of one per node - a wave's loads and stores of r and K p are contiguous, 456 of 512 lane slots
-// busy on a 152-node tile instead of 152 of 192; every lane adds its two entries' share to the same sums.
-template <typename PT, typename RT, int TM = 6, bool PAIRS = false>
+template <typename PT, typename RT, int TM = 6>
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
@@ -909,71 +906,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   double accL[6] = {0, 0, 0, 0, 0, 0};
   double accT[6] = {0, 0, 0, 0, 0, 0};      // tile level on several GPUs: the tile's restriction without shared nodes
   const bool own_t = Bt_inv && shared;
-  if constexpr (PAIRS) {
-    for (int64_t pr = 3 * (int64_t)n0 + threadIdx.x; pr < 3 * (int64_t)n1; pr += blockDim.x) {
-      const int64_t i = pr / 3;
-      const int q = (int)(pr - 3 * i);
-      if (skip_rows && skip_rows[i]) continue;
-      const double2 aa = load_pair(Ap, pr);
-      double2 rr = load_pair(r, pr);
-      const float2 dd = reinterpret_cast<const float2 *>(dinv32)[pr];
-      rr.x -= alpha * aa.x;
-      rr.y -= alpha * aa.y;
-      store_pair(r, pr, rr);
-      if (sizeof(RT) == 4) {
-        rr.x = (double)(float)rr.x;
-        rr.y = (double)(float)rr.y;
-      }
-      const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
-      double wx = 1.0, wy = 1.0;           // several GPUs: 1 / (ranks holding the node), so that the global sums count it once
-      if (w) {
-        wx = w[2 * pr];
-        wy = w[2 * pr + 1];
-      }
-      const bool own = !(shared && shared[i]);
-      // the lane's two entries as a node-sized vector that is zero elsewhere (selects, no branches)
-      const double vx = wx * rr.x, vy = wy * rr.y;
-      const double ru0 = q == 0 ? vx : 0.0, ru1 = q == 0 ? vy : 0.0, ru2 = q == 1 ? vx : 0.0;
-      const double m3 = q == 1 ? vy : 0.0, m4 = q == 2 ? vx : 0.0, m5 = q == 2 ? vy : 0.0;
-      acc[0] += ru0;
-      acc[1] += ru1;
-      acc[2] += ru2;
-      acc[3] += m3 + (ry * ru2 - rz * ru1);
-      acc[4] += m4 + (rz * ru0 - rx * ru2);
-      acc[5] += m5 + (rx * ru1 - ry * ru0);
-      acc[6] += vx * rr.x + vy * rr.y;
-      acc[7] += dd.x * vx * rr.x + dd.y * vy * rr.y;
-      if (TM == 12) {
-        const double s0 = rx * ru0, s1 = ry * ru1, s2 = rz * ru2, s3 = 0.5 * (ry * ru0 + rx * ru1),
-                     s4 = 0.5 * (rz * ru1 + ry * ru2), s5 = 0.5 * (rz * ru0 + rx * ru2);
-        if (cm == 12 && shared) {
-          accD[0] += s0;
-          accD[1] += s1;
-          accD[2] += s2;
-          accD[3] += s3;
-          accD[4] += s4;
-          accD[5] += s5;
-        }
-        if (own) {
-          accS[0] += s0;
-          accS[1] += s1;
-          accS[2] += s2;
-          accS[3] += s3;
-          accS[4] += s4;
-          accS[5] += s5;
-        }
-      }
-      if (own_t && own) {                  // the tile's rigid restriction on own nodes (their weight is 1)
-        const double t0 = q == 0 ? rr.x : 0.0, t1 = q == 0 ? rr.y : 0.0, t2 = q == 1 ? rr.x : 0.0;
-        accT[0] += t0;
-        accT[1] += t1;
-        accT[2] += t2;
-        accT[3] += (q == 1 ? rr.y : 0.0) + (ry * t2 - rz * t1);
-        accT[4] += (q == 2 ? rr.x : 0.0) + (rz * t0 - rx * t2);
-        accT[5] += (q == 2 ? rr.y : 0.0) + (rx * t1 - ry * t0);
-      }
-    }
-  } else
   for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     if (skip_rows && skip_rows[i]) continue;    // eliminated node (opts.condense): not an unknown of this CG
     // (x += alpha p is done by k_pcg_direction_coarse, which reads p anyway: one vector pass less per iteration)
