@@ -290,11 +290,14 @@ struct CondSolve {            // K_cc^-1 of the condensed nodes (pl_coarse.h)
                                    // fetched one visit ahead with conn, instead of two dependent byte loads per visit)
 };
 // (c = conn2[b] and pid = pal[b] come from the caller, which fetches them one visit ahead: tile_struts)
-template <int REC, int ENDS, typename VT>
+// `after_loads()` runs once this visit's gathers have been requested and before anything waits for them: the caller's
+// fetch of the NEXT visit's indices goes there - vector loads return in order, so requested earlier it would stand
+// between this visit's gathers and the arithmetic that needs them.
+template <int REC, int ENDS, typename VT, typename AfterLoads>
 __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsigned pid, int n0, int n1,
                                            const Record *__restrict__ rec,
                                            const double *__restrict__ xyz, const uint8_t *__restrict__ cflag,
-                                           const VT *__restrict__ x, double *ys, int stride) {
+                                           const VT *__restrict__ x, double *ys, int stride, AfterLoads &&after_loads) {
   Record r;
   if (REC == kRecCompact) {
     const Rec5 q = reinterpret_cast<const Rec5 *>(rec)[b];
@@ -312,6 +315,7 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
   // a condensed end's own row is being rewritten by its tile in the fused first pass: it counts as zero and is not read
   if (!(ENDS == kEndsCondensedSolve && cA)) load6(x + 6 * (int64_t)c.x, uA, tA);
   if (!(ENDS == kEndsCondensedSolve && cB)) load6(x + 6 * (int64_t)c.y, uB, tB);
+  after_loads();
   if (ENDS != kEndsAll) {
     takeB = takeB && (cB == kToCondensed);
     takeA = takeA && (cA == kToCondensed);
@@ -358,8 +362,10 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     for (int i = threadIdx.x; i < nn; i += kTileBlock) sbase[i] = cs.base[n0 + i];
   __syncthreads();
   // A thread makes 2-3 visits per tile, each a chain of two memory hops (conn -> x rows, palette id -> record) before
-  // the arithmetic.  The first hop of the NEXT visit (10 bytes) is issued before the current visit's second hop, so only
-  // a thread's first visit pays both (SQ counters: the waves of this kernel spent 52 % of their life in s_waitcnt).
+  // the arithmetic.  The first hop of the NEXT visit (10 bytes) is requested right AFTER the current visit's second hop
+  // (tile_strut's after_loads), so only a thread's first visit pays both (SQ counters: the waves of this kernel spent 52 %
+  // of their life in s_waitcnt).  (Requested before it - vector loads return in order - K*p is 1 us slower, 39.0 against
+  // 38.0 us; requesting the FIRST visit's indices above the clearing of the accumulator takes that microsecond back again.)
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1];
   const int64_t f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
   int64_t b = h0 + threadIdx.x, kf = f0 + threadIdx.x;
@@ -389,12 +395,13 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     }
     int2 cn_n = {0, 0};
     unsigned pid_n = 0;
-    if (live_n) {
-      cn_n = conn2[bn];
-      if (REC == kRecPalette) pid_n = pal[bn];
-      if (ENDS != kEndsAll) pid_n |= (unsigned)cs.cend[bn] << 16;
-    }
-    tile_strut<REC, ENDS, VT>(b, cn, pid, n0, n1, rec, xyz, cflag, x, ys, stride);
+    tile_strut<REC, ENDS, VT>(b, cn, pid, n0, n1, rec, xyz, cflag, x, ys, stride, [&]() {
+      if (live_n) {
+        cn_n = conn2[bn];
+        if (REC == kRecPalette) pid_n = pal[bn];
+        if (ENDS != kEndsAll) pid_n |= (unsigned)cs.cend[bn] << 16;
+      }
+    });
     b = bn;
     cn = cn_n;
     pid = pid_n;
