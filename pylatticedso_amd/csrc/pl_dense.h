@@ -53,6 +53,23 @@ __device__ __forceinline__ void stage_rows_as_k_major(const double *G, int ld, d
   }
 }
 
+// A 64 x 64 tile through registers: all 16 loads of a thread are in flight at once (a plain load -> LDS-store loop is
+// compiled as sixteen dependent round trips: global_load, s_waitcnt vmcnt(0), ds_write per element).
+__device__ __forceinline__ void tile_fetch(const double *__restrict__ G, int ld, double regs[kNB * kNB / kBlock]) {
+#pragma unroll
+  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
+    const int e = threadIdx.x + q * kBlock;
+    regs[q] = G[(size_t)(e / kNB) * ld + e % kNB];
+  }
+}
+__device__ __forceinline__ void tile_store_k_minor(const double regs[kNB * kNB / kBlock], double *T) {
+#pragma unroll
+  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
+    const int e = threadIdx.x + q * kBlock;
+    T[(e % kNB) * kLdT + e / kNB] = regs[q];                            // T[m][row] = G[row][m]
+  }
+}
+
 // Diagonal block: L_kk and its inverse by ONE workgroup.
 // Cholesky: right-looking over tile columns of width 4, every thread keeps a 4 x 4 register tile of the block; per
 // step the diagonal tile is factored and inverted by its owner, the tiles below it are solved by theirs and travel
@@ -233,8 +250,18 @@ __device__ __forceinline__ void chol_step_body(double *__restrict__ A, double *_
   double *X = S, *Y = S + kNB * kLdT, *D = S + 2 * kNB * kLdT;
   static_assert(kDiagLds <= 2 * kNB * kLdT, "diagonal-block scratch must fit into X|Y");
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  stage_rows_as_k_minor(Dinv + (size_t)kb * kNB * kNB, kNB, D);                          // D[m][col] = Dinv_k[col][m]
-  stage_rows_as_k_minor(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, X);          // X[m][row] = A_jk[row][m]
+  double *Aij = A + ((size_t)ib * kNB) * ld + (size_t)jb * kNB;
+  // every global operand of this workgroup is requested up front: one memory round trip per link of the chain
+  double rd[kNB * kNB / kBlock], rj[kNB * kNB / kBlock], ri[kNB * kNB / kBlock], a[4][4];
+  tile_fetch(Dinv + (size_t)kb * kNB * kNB, kNB, rd);
+  tile_fetch(A + ((size_t)jb * kNB) * ld + (size_t)kb * kNB, ld, rj);
+  if (ib != jb) tile_fetch(A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB, ld, ri);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[i][j] = Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j];
+  tile_store_k_minor(rd, D);                                                             // D[m][col] = Dinv_k[col][m]
+  tile_store_k_minor(rj, X);                                                             // X[m][row] = A_jk[row][m]
   __syncthreads();
   {
     double l[4][4] = {};
@@ -254,7 +281,7 @@ __device__ __forceinline__ void chol_step_body(double *__restrict__ A, double *_
   __syncthreads();
   const double *Li = Y;
   if (ib != jb) {
-    stage_rows_as_k_minor(A + ((size_t)ib * kNB) * ld + (size_t)kb * kNB, ld, X);        // X[m][row] = A_ik[row][m]
+    tile_store_k_minor(ri, X);                                                           // X[m][row] = A_ik[row][m]
     __syncthreads();
     double l[4][4] = {};
     tile_fma(X, D, tx, ty, l);                                                           // L_ik
@@ -268,12 +295,10 @@ __device__ __forceinline__ void chol_step_body(double *__restrict__ A, double *_
   }
   double acc[4][4] = {};
   tile_fma(Li, Y, tx, ty, acc);                                                          // L_ik L_jk^T
-  double *Aij = A + ((size_t)ib * kNB) * ld + (size_t)jb * kNB;
-  double a[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[i][j] = Aij[(size_t)(4 * ty + i) * ld + 4 * tx + j] - acc[i][j];
+    for (int j = 0; j < 4; ++j) a[i][j] -= acc[i][j];
   if (ib == kb + 1 && jb == kb + 1) {        // look-ahead: this block is final now - factor it here
     __syncthreads();                         // X, Y are scratch from here on
 #pragma unroll
@@ -349,21 +374,6 @@ __global__ __launch_bounds__(kBlock) void k_chol_chain(double *__restrict__ A, d
 // W^T is written alongside (the second triangular GEMV wants rows).
 constexpr int kCw = 8;
 constexpr int kRing = 12;
-
-__device__ __forceinline__ void tile_fetch(const double *__restrict__ G, int ld, double regs[kNB * kNB / kBlock]) {
-#pragma unroll
-  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
-    const int e = threadIdx.x + q * kBlock;
-    regs[q] = G[(size_t)(e / kNB) * ld + e % kNB];
-  }
-}
-__device__ __forceinline__ void tile_store_k_minor(const double regs[kNB * kNB / kBlock], double *T) {
-#pragma unroll
-  for (int q = 0; q < kNB * kNB / kBlock; ++q) {
-    const int e = threadIdx.x + q * kBlock;
-    T[(e % kNB) * kLdT + e / kNB] = regs[q];                            // T[m][row] = G[row][m]
-  }
-}
 
 template <typename WT, bool RING>
 __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict__ L, int ld, int nb, int bw,
@@ -452,6 +462,8 @@ __device__ __forceinline__ double row_dot(const float *__restrict__ Wr, const do
   const float4 *W4 = reinterpret_cast<const float4 *>(Wr);
   const double2 *v2 = reinterpret_cast<const double2 *>(v);
   double s = 0.0;
+  // (tried: all loads of up to 8 trips of a row in flight at once, clamped or predicated - a row of the 1 536-dof operator in
+  // ONE memory round trip instead of the 2 + 4 this loop compiles to: the PCG iteration got 1 us SLOWER both ways)
 #pragma unroll 4
   for (int j = (c_lo >> 2) + lane; j < ((c_hi + 3) >> 2); j += 64) {
     const float4 w = W4[j];
