@@ -344,18 +344,38 @@ __global__ __launch_bounds__(kBsrBlock) void k_bsr_fill(int64_t N, const int64_t
   const unsigned fi = (live && with_bc && fixedbits) ? fixedbits[i] : 0u;
   const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
   const int64_t row0 = live ? rowptr[i] : 0;
+  // A trip is a chain entry -> record -> blocks -> stores, and a wave makes 3-4 of them with 8 waves per CU (LDS): the NEXT
+  // trip's entry and slot are requested right after this trip's record (vector loads return in order: requested before
+  // it they would stand between the record and the arithmetic), so only the first trip pays both hops.
+  int2 e_next = {-1, 0};
+  int32_t slot_next = 0;
+  if (p0 + lane < p1) {
+    e_next = ent[p0 + lane];
+    slot_next = ent_slot[p0 + lane];
+  }
   for (int64_t pb = p0; pb < p1; pb += 64) {            // whole wave takes every trip (the staged stores are collective)
     const int64_t p = pb + lane;
     int64_t my_block = -1;
+    const int2 e = e_next;
+    const int32_t slot = slot_next;
+    Record r;
+    unsigned fo = 0u;
+    const bool have = p < p1 && e.x >= 0;
+    if (have) {
+      r = load_record(rec, e.y & 0x7fffffff);
+      if (with_bc && fixedbits) fo = fixedbits[e.x];
+    }
+    e_next = int2{-1, 0};
+    if (p + 64 < p1) {
+      e_next = ent[p + 64];
+      slot_next = ent_slot[p + 64];
+    }
     if (p < p1) {
-      const int2 e = ent[p];
       if (e.x >= 0) {
-        Record r = load_record(rec, e.y & 0x7fffffff);
         if (e.y < 0) r = reversed(r);
         double Kss[36], Kso[36];
         tip_blocks(r, Kss, Kso);
-        const unsigned fo = (with_bc && fixedbits) ? fixedbits[e.x] : 0u;
-        my_block = row0 + ent_slot[p];
+        my_block = row0 + slot;
         double *dst = stage + lane * kBsrPitch;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
