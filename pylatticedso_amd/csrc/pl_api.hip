@@ -770,16 +770,23 @@ template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
   pl::Coarse &cs = c->coarse, &cl = c->coarseL;
   const bool useL = cl.ready;
-#define PL_UPD(TM)                                                                                                  \
-  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, \
+#define PL_UPD(TM, MULTI, LOCAL)                                                                                    \
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM, MULTI, LOCAL>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), \
+                     0, c->stream,                                                                                   \
                      c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,                       \
                      c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,             \
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
                      cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
-  if (tile_modes_now(c) == 12) PL_UPD(12);
-  else PL_UPD(6);
+  if (useL) {
+    if (tile_modes_now(c) == 12) PL_UPD(12, true, true);
+    else PL_UPD(6, true, true);
+  } else if (c->dist.active) {
+    if (tile_modes_now(c) == 12) PL_UPD(12, true, false);
+    else PL_UPD(6, true, false);
+  } else if (tile_modes_now(c) == 12) PL_UPD(12, false, false);
+  else PL_UPD(6, false, false);
 #undef PL_UPD
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below

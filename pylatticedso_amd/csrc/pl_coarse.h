@@ -852,7 +852,10 @@ __global__ __launch_bounds__(kBlock) void k_to_float(int64_t n, const double *__
 // PT = storage type of the search direction p and of Ap, RT = of the iterate x and the residual r (double / float:
 // opts.precision).  Every sum is accumulated in fp64 whatever the storage.
 // TM = modes of the tile level: 6, or 12 (rigid + uniform strains, single-GPU handles: Coarse::tile_modes)
-template <typename PT, typename RT, int TM = 6>
+// MULTI = false (one GPU, no rank-local level): the weights, the shared-node flags and the rank-local aggregates are known
+// to be absent at compile time, and with them go 18 accumulators - the general kernel holds 164 VGPRs (3 waves per SIMD).
+// LOCAL = false: no rank-local dense level (precond = 4 only), six accumulators less on multi-rank handles.
+template <typename PT, typename RT, int TM = 6, bool MULTI = true, bool LOCAL = true>
 __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__restrict__ tile_start,
                                                             const int32_t *__restrict__ agg_of_tile,
                                                             const double *__restrict__ cen,
@@ -872,6 +875,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             int cm = 6 /* modes per aggregate of the dense level */) {
   __shared__ double red[32][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
   __shared__ double sst[16], sv[16];
+  if constexpr (!MULTI) {
+    w = nullptr;
+    shared = nullptr;
+  }
+  if constexpr (!MULTI || !LOCAL) aggL_of_tile = nullptr;
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
   const double pap = scalar_read(scal, S_PAP);
@@ -881,6 +889,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
   // row of B_t^-1 of the lane that will need it at the very end, fetched early.  TM = 12: lanes 0-5 hold the rigid
   // modes, 8-13 the strain modes (6, 7 carry r.r and r.D^-1 r as before)
+  // (parked in LDS, not in registers: 2 TM VGPRs that every wave would carry through the loop cost a wave per SIMD)
+  __shared__ double sbi[16][TM];
   double bi[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) bi[j] = 0.0;
@@ -890,6 +900,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   if (Bt_inv && my_mode >= 0) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) bi[j] = Bt_inv[(size_t)t * (TM * TM) + TM * my_mode + j];
+  }
+  if (threadIdx.x < 16) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) sbi[threadIdx.x][j] = bi[j];
   }
   double accS[6] = {0, 0, 0, 0, 0, 0};   // TM = 12: strain restrictions of the tile
   double accD[6] = {0, 0, 0, 0, 0, 0};   // ... and, on several GPUs with a 12-mode dense level, of the aggregate (weighted,
@@ -1053,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
         sst[threadIdx.x] = st;
         double y = 0.0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) y += bi[j] * sst[j < 6 ? j : j + 2];
+        for (int j = 0; j < 12; ++j) y += sbi[threadIdx.x][j] * sst[j < 6 ? j : j + 2];
         if (my_mode >= 0) yt[12 * (size_t)t + my_mode] = y;
         sv[threadIdx.x] = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
         if (threadIdx.x == 0) {
@@ -1088,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       for (int j = 0; j < 6; ++j) tj[j] = __shfl(st, j, 8);
       double y = 0.0;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) y += bi[j] * tj[j];
+      for (int j = 0; j < 6; ++j) y += sbi[threadIdx.x][j] * tj[j];
       if (threadIdx.x < 6) yt[6 * (size_t)t + threadIdx.x] = y;
       double v = threadIdx.x < 6 ? y * st : (threadIdx.x == 7 ? s : 0.0);
       v += __shfl_xor(v, 1, 8);
