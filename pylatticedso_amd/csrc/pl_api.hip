@@ -798,8 +798,9 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
   }
   pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
                   cs.rc + cs.ncp + pl::kSlots, c->stream);
-#define PL_DIR(TM)                                                                                                       \
-  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT, TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, \
+#define PL_DIR(TM, MULTI, LOCAL)                                                                                         \
+  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT, TM, MULTI, LOCAL>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), \
+                     0, c->stream,                                                                                        \
                      c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,         \
                      cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur, nxt,     \
                      c->hist.p, hist_slot, cs.rc, cs.ncp,                                                                \
@@ -818,8 +819,14 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
   if (!useL && sizeof(PT) == 8) {
     if (tile_modes_now(c) == 12) PL_DIRF(12);
     else PL_DIRF(6);
-  } else if (tile_modes_now(c) == 12) PL_DIR(12);
-  else PL_DIR(6);
+  } else if (useL) {
+    if (tile_modes_now(c) == 12) PL_DIR(12, true, true);
+    else PL_DIR(6, true, true);
+  } else if (c->dist.active) {
+    if (tile_modes_now(c) == 12) PL_DIR(12, true, false);
+    else PL_DIR(6, true, false);
+  } else if (tile_modes_now(c) == 12) PL_DIR(12, false, false);
+  else PL_DIR(6, false, false);
 #undef PL_DIRF
 #undef PL_DIR
   PL_HIP(hipGetLastError());

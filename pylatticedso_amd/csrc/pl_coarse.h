@@ -1287,7 +1287,8 @@ __global__ __launch_bounds__(kBlock) void k_condense_backsubst(int64_t nc, const
 
 // p = D^-1 r + P Z (y_c + y_t) + beta p, plus the end-of-iteration scalar bookkeeping (as k_pcg_direction).
 // One workgroup per tile: aggregate, centre and the two rigid motions are wave-uniform (scalar loads).
-template <typename PT, typename RT, int TM = 6>
+// (MULTI / LOCAL as in k_pcg_update_tile: what a handle cannot have is compiled out, with its registers)
+template <typename PT, typename RT, int TM = 6, bool MULTI = true, bool LOCAL = true>
 __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *__restrict__ tile_start,
                                                                  const RT *__restrict__ r,
                                                                  const float *__restrict__ dinv32,
@@ -1309,6 +1310,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  double *__restrict__ rcL, int ncpL,
                                                                  const uint8_t *__restrict__ zero_rows /* may be null */,
                                                                  int cm = 6) {
+  if constexpr (!MULTI) shared = nullptr;
+  if constexpr (!MULTI || !LOCAL) aggL_of_tile = nullptr;
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   const double pap = scalar_read(scal, S_PAP);
