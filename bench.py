@@ -399,7 +399,7 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
                      "note": "tiles are the bricks of the preconditioner's tile level, nested into the aggregates of its "
                              "dense level (DESIGN.md section 7): 15^3 tiles of 152 nodes at 50^3 Octet cost K*p 3 us "
-                             "against the 13^3 tiles of round 1 (0.93 -> 0.86) and, with the strain modes of both block "
+                             "against the 13^3 tiles of round 1 (0.93 -> 0.86; 0.88 since its index prefetch moved behind the gathers) and, with the strain modes of both block "
                              "levels, save 35 of 155 PCG iterations"},
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
