@@ -330,7 +330,8 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
 
 // Workgroup size of the tile K*p.  Measured on the 50^3 Octet (256-node tiles): 128 / 256 / 384 / 512 / 640 / 768 / 1024
 // threads -> 45.9 / 40.6 / 39.7 / 36.2 / 47.8 / 42.8 / 55.0 us: with 512 a tile's ~1900 strut visits are 3-4 per thread, so a
-// workgroup lives half as long while 4 of them still fit a CU.
+// workgroup lives half as long while 4 of them still fit a CU.  (End of round 2, 152-node tiles of ~1 080 visits:
+// 384 / 448 / 512 / 576 / 640 threads -> 39.4 / 39.2 / 37.9 / 43.7 / 47.0 us.)
 #ifndef PL_TILE_BLOCK
 #define PL_TILE_BLOCK 512
 #endif
