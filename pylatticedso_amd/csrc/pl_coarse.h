@@ -882,8 +882,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
   if constexpr (!MULTI || !LOCAL) aggL_of_tile = nullptr;
   double *rr_slot = rc + ncp + (blockIdx.x & (kSlots - 1)), *rdr_slot = rr_slot + kSlots;   // tail of r_c
   const int t = blockIdx.x;
-  const double pap = scalar_read(scal, S_PAP);
-  const double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
+  double pap, old_rz;
+  scalar_read2(scal, S_PAP, S_RZ_OLD, pap, old_rz);
+  const double alpha = (pap != 0.0) ? old_rz / pap : 0.0;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
@@ -1312,9 +1313,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  int cm = 6) {
   if constexpr (!MULTI) shared = nullptr;
   if constexpr (!MULTI || !LOCAL) aggL_of_tile = nullptr;
-  const double old = scalar_read(scal, S_RZ_OLD);
-  const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
-  const double pap = scalar_read(scal, S_PAP);
+  double old, rz_new, pap;
+  scalar_read3(scal, S_RZ_OLD, S_RZ_NEW, S_PAP, old, rz_new, pap);
+  const double beta = (old != 0.0) ? rz_new / old : 0.0;
   const double alpha = (pap != 0.0) ? old / pap : 0.0;      // the step k_pcg_update_tile took: x += alpha p_old here
   if (blockIdx.x == 1 || gridDim.x == 1)      // r_c was consumed by the coarse solve: clear it for the next restriction
     for (int e = threadIdx.x; e < ncp; e += blockDim.x) rc[e] = 0.0;
@@ -1453,9 +1454,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
                                                                double *__restrict__ rc, int ncp,
                                                                const uint8_t *__restrict__ zero_rows /* may be null */,
                                                                int cm, const uint8_t *__restrict__ shared /* may be null */) {
-  const double old = scalar_read(scal, S_RZ_OLD);
-  const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
-  const double pap = scalar_read(scal, S_PAP);
+  double old, rz_new, pap;
+  scalar_read3(scal, S_RZ_OLD, S_RZ_NEW, S_PAP, old, rz_new, pap);
+  const double beta = (old != 0.0) ? rz_new / old : 0.0;
   const double alpha = (pap != 0.0) ? old / pap : 0.0;
   if (blockIdx.x == 1 || gridDim.x == 1)
     for (int e = threadIdx.x; e < ncp; e += blockDim.x) rc[e] = 0.0;

@@ -68,6 +68,24 @@ __device__ __forceinline__ double scalar_read(const double *scal, int which) {
   return wave_sum(v);
 }
 
+// Two / three scalars at once: their slot values are requested together and reduced afterwards - one memory round trip,
+// where consecutive scalar_read calls wait for each other's load.
+__device__ __forceinline__ void scalar_read2(const double *scal, int a, int b, double &va, double &vb) {
+  static_assert(kSlots == kWave, "one slot per lane");
+  const int lane = threadIdx.x & 63;
+  const double xa = scal[a * kSlots + lane], xb = scal[b * kSlots + lane];
+  va = wave_sum(xa);
+  vb = wave_sum(xb);
+}
+__device__ __forceinline__ void scalar_read3(const double *scal, int a, int b, int c, double &va, double &vb, double &vc) {
+  static_assert(kSlots == kWave, "one slot per lane");
+  const int lane = threadIdx.x & 63;
+  const double xa = scal[a * kSlots + lane], xb = scal[b * kSlots + lane], xc = scal[c * kSlots + lane];
+  va = wave_sum(xa);
+  vb = wave_sum(xb);
+  vc = wave_sum(xc);
+}
+
 // Sum over the block, result valid in thread 0.
 __device__ __forceinline__ double block_sum(double v, double *smem /*[kBlock/kWave]*/) {
   v = wave_sum(v);
