@@ -1,0 +1,227 @@
+// Handle state of libpylattice_hip (struct pl_context) and the helpers every part of the host side uses.
+// Included once, by pl_api.hip (single translation unit; the C ABI itself lives there).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/pylattice_hip.h"
+#include "pl_kernels.h"
+#include "pl_parallel.h"
+#include "pl_tile.h"
+#include "pl_dist.h"
+#include "pl_coarse.h"
+#include "pl_cg1.h"
+#include "pl_palette.h"
+#include "pl_ddm.h"
+#include "pl_lzone.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define PL_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(PL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+  }
+};
+
+inline unsigned grid_for(int64_t n, int block = pl::kBlock) { return (unsigned)((n + block - 1) / block); }
+inline unsigned grid_stream(int64_t n) {
+  // memory-bound grid-stride kernels: cap at 256 CUs x 8 blocks
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + pl::kBlock - 1) / pl::kBlock, 2048));
+}
+
+}  // namespace
+
+struct pl_context {
+  pl_opts_t opt{};
+  pl::Material mat{};
+  int64_t N = 0, B = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pl_assemble overlaps the latency-bound dense factorisation chain (main stream) with the bandwidth-bound fills
+  // (palette, Jacobi diagonal, tile blocks, explicit BSR) on a second stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipStream_t side2 = nullptr;   // tile blocks of the 12-mode dense level beside its strain rows
+  bool assembled = false, have_bc = false, have_bsr = false;
+  int pal_fallback_flags[2] = {1, 0};
+  int *pal_host_flags = pal_fallback_flags;   // pinned once the palette is in use: a D2H copy into pageable memory blocks the host
+  bool want_bsr = false;   // pl_assemble_bsr was called once: pl_assemble keeps the explicit matrix current
+  int bsr_with_bc = 0;
+
+  // caller numbering <-> device numbering (perm[dev] = caller node)
+  std::vector<int32_t> perm, iperm;
+  bool reordered = false;
+  // caller strut order <-> device strut order (bperm[dev] = caller strut); struts are numbered by home tile
+  std::vector<int32_t> bperm;
+
+  // geometry / topology (device numbering)
+  DevBuf<double> xyz, radius, seg_len;
+  DevBuf<int32_t> conn, seg_nsub;
+  DevBuf<pl::Record> rec;
+  DevBuf<double> rec5;   // compact 5-scalar copy of the records for the streaming K*p (tile kernel, no palette)
+  // node -> strut incidence, sliced ELL
+  DevBuf<int64_t> slice_ptr;
+  DevBuf<int2> ent;
+  int64_t n_slices = 0, n_ent = 0;
+  int lpn = pl::kDefaultLPN;   // lanes per node of the gather kernels (1, 2, 4, 8 or 16)
+  // BSR
+  DevBuf<int64_t> bsr_rowptr;
+  DevBuf<int32_t> bsr_col, ent_slot, diag_slot;
+  DevBuf<double> bsr_vals;
+  int64_t nblk = 0;
+  std::vector<int64_t> h_rowptr;
+  std::vector<int32_t> h_col;
+  // boundary data
+  DevBuf<uint8_t> fixed;       // [6N] 0/1
+  DevBuf<uint8_t> fixedbits;   // [N] 6 bits
+  DevBuf<double> ubar, f;
+  // solver state
+  DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
+  DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
+  int hist_cap = 0;
+  // LDS-tile operator
+  pl::TilePlan tile;
+  // DDM operator (pl_ddm.h): opkind = 1 replaces the strut operator by sum_c B^T S B
+  int opkind = 0;
+  int64_t ddm_cells = 0;
+  int ddm_nb = 0;
+  DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
+  DevBuf<double> ddm_St;
+  DevBuf<int64_t> ddm_node_ptr;       // node -> (cell * nb + slot) entries: the atomic-free scatter of k_ddm_node_gather
+  DevBuf<int32_t> ddm_node_ent;
+  DevBuf<double> ddm_stage;           // [cells][6 nb] local products
+  DevBuf<int32_t> ddm_order;          // cells sorted by matrix id (k_ddm_cell_product_lds)
+  // assembled-Schur preconditioner of the DDM operator (opt.precond = 2): optional palette of its own + dense factor
+  DevBuf<int32_t> ddm_cell_P;
+  DevBuf<double> ddm_Pt;
+  bool ddm_have_P = false;
+  DevBuf<double> dd_A, dd_Lf, dd_W, dd_Wt, dd_Dinv, dd_tv;
+  DevBuf<int> dd_info;
+  int dd_n = 0;          // padded order of the dense matrix (0: not allocated)
+  int dd_bw = 0;         // its block bandwidth in the caller's node numbering (from the cells' node spans)
+  bool dd_ready = false;
+  // record palette (pl_palette.h)
+  DevBuf<unsigned long long> pal_keys;
+  DevBuf<int> pal_owner, pal_flags;
+  DevBuf<uint16_t> pal_id;
+  DevBuf<pl::Record> palette;
+  bool pal_ready = false;
+  int pal_entries = 0;
+  // two-level preconditioner (rigid-body coarse space)
+  pl::Coarse coarse;
+  int coarse_info = 0;
+  // precond = 4: a second, rank-LOCAL dense level (aggregates of this handle only, nodes shared with other ranks left
+  // out, never communicated) under the global one, so that the aggregate size can stay fixed under weak scaling
+  // while the all-reduced global level coarsens
+  pl::Coarse coarseL;
+  DevBuf<uint8_t> sharedbits, maskL;
+  // exact elimination of an independent node set inside the PCG (opts.condense, pl_coarse.h)
+  std::vector<uint8_t> h_cand;        // candidates (an independent set of the node graph, chosen at pl_create; device numbering)
+  std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
+  DevBuf<uint8_t> cend;           // strut -> bits: end A / B is a condensed node (pl_tile.h CondSolve)
+  DevBuf<int32_t> cnodes, cbase;  // condensed nodes; node -> offset of its K_cc^-1 block (class table or per node), -1
+  int cbase_state = -1;           // what cbase was built for: -1 stale, 0 per-node blocks, 1 class table
+  DevBuf<double> kcc_inv;
+  DevBuf<uint8_t> maskC, cflag;       // Dirichlet bits | 0x3f on condensed nodes; 1 on condensed nodes
+  // classes of eliminated nodes with the same K_cc^-1 (pl_coarse.h k_cls_*): only with a record palette
+  DevBuf<unsigned long long> cls_key, cls_keys;
+  DevBuf<int> cls_owner, cls_flags;
+  DevBuf<uint16_t> cls_id;
+  DevBuf<double> cls_table;
+  int *cls_host_flag = nullptr;       // pinned
+  bool cls_ready = false;
+  int last_iterations = 0;   // of the previous converged pcg_solve on this handle (hint for the first convergence check)
+  int64_t n_cond = 0;
+  bool cond_ready = false;   // K_cc^-1 valid for the current records and mask
+  bool cond_use = false;     // the running solve eliminates them (fp64 PCG and precision = 1)
+  // multi-GPU
+  pl::Dist dist;
+
+  pl_stats_t last{};
+  double ms_assembly = 0.0;
+
+  ~pl_context() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_chol) (void)hipEventDestroy(ev_chol);
+    if (ev_t0) (void)hipEventDestroy(ev_t0);
+    if (ev_t1) (void)hipEventDestroy(ev_t1);
+    if (side2) (void)hipStreamDestroy(side2);
+    if (side) (void)hipStreamDestroy(side);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------
+// host <-> device vector transfer in caller numbering
+// ----------------------------------------------------------------------------------------------------------
+int upload6(pl_context *c, const double *host, double *dev, std::vector<double> &stage) {
+  const size_t n6 = (size_t)c->N * 6;
+  if (!c->reordered) {
+    PL_HIP(hipMemcpyAsync(dev, host, n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    return PL_OK;
+  }
+  stage.resize(n6);
+  for (int64_t i = 0; i < c->N; ++i) std::memcpy(&stage[6 * i], host + 6 * (size_t)c->perm[i], 6 * sizeof(double));
+  PL_HIP(hipMemcpyAsync(dev, stage.data(), n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  return PL_OK;
+}
+
+int download6(pl_context *c, const double *dev, double *host) {
+  const size_t n6 = (size_t)c->N * 6;
+  if (!c->reordered) {
+    PL_HIP(hipMemcpyAsync(host, dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    return PL_OK;
+  }
+  std::vector<double> stage(n6);
+  PL_HIP(hipMemcpyAsync(stage.data(), dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < c->N; ++i) std::memcpy(host + 6 * (size_t)c->perm[i], &stage[6 * i], 6 * sizeof(double));
+  return PL_OK;
+}
+
+}  // namespace

@@ -1,0 +1,187 @@
+// Operator launches of libpylattice_hip: y = K x in its three kernel variants, the DDM operator, the fp32-stored
+// variant, plus the multi-GPU interface sum behind them (device vectors, device numbering).
+#pragma once
+#include "pl_context.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------
+// operator launches (device vectors, device numbering)
+// ----------------------------------------------------------------------------------------------------------
+// auto: the LDS-tile kernel when the nodes are brick-ordered (its tiles are then compact), else the per-node gather
+int choose_kernel(const pl_context *c) {
+  if (c->opt.spmv_kernel != 0) return c->opt.spmv_kernel;
+  return (c->reordered && c->tile.ready) ? 3 : 2;
+}
+
+template <int LPN>
+void launch_gather_lpn(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+  const unsigned g = grid_for(c->n_slices, pl::kBlock / pl::kWave);   // one wave per ELL slice
+#define PL_G(M, D)                                                                                               \
+  hipLaunchKernelGGL((pl::k_spmv_gather<LPN, M, D>), dim3(g), dim3(pl::kBlock), 0, c->stream, c->N, c->slice_ptr.p, \
+                     c->ent.p, c->rec.p, c->fixedbits.p, x, y, dot_dev)
+  if (masked && dot_dev) PL_G(true, true);
+  else if (masked) PL_G(true, false);
+  else if (dot_dev) PL_G(false, true);
+  else PL_G(false, false);
+#undef PL_G
+}
+
+int dispatch_gather(pl_context *c, const double *x, double *y, bool masked, double *dot_dev) {
+  switch (c->lpn) {
+    case 1: launch_gather_lpn<1>(c, x, y, masked, dot_dev); break;
+    case 2: launch_gather_lpn<2>(c, x, y, masked, dot_dev); break;
+    case 4: launch_gather_lpn<4>(c, x, y, masked, dot_dev); break;
+    case 8: launch_gather_lpn<8>(c, x, y, masked, dot_dev); break;
+    case 16: launch_gather_lpn<16>(c, x, y, masked, dot_dev); break;
+    default: return fail(PL_ERR_ARG, "lanes per node must be 1, 2, 4, 8 or 16");
+  }
+  return PL_OK;
+}
+
+// y = K x (masked -> y = P K x, x assumed zero on fixed dofs); optional dot(x, y) accumulated into *dot_dev.
+// K_cc^-1 for the fused first pass of the condensed operator (kEndsCondensedSolve)
+__global__ __launch_bounds__(pl::kBlock) void k_cond_ends(int64_t B, const int2 *__restrict__ conn2,
+                                                         const uint8_t *__restrict__ cflag, uint8_t *__restrict__ cend) {
+  const int64_t b = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (b >= B) return;
+  const int2 c = conn2[b];
+  cend[b] = (uint8_t)((cflag[c.x] ? 1 : 0) | (cflag[c.y] ? 2 : 0));
+}
+__global__ __launch_bounds__(pl::kBlock) void k_cond_base(int64_t nc, const int32_t *__restrict__ cnodes,
+                                                         const uint16_t *__restrict__ cls /* may be null */,
+                                                         int32_t *__restrict__ base) {
+  const int64_t q = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (q < nc) base[cnodes[q]] = 36 * (cls ? (int32_t)cls[q] : (int32_t)q);
+}
+inline pl::CondSolve cond_solve(pl_context *c, int ends) {
+  pl::CondSolve cs;
+  if (ends != pl::kEndsAll) cs.cend = c->cend.p;
+  if (ends == pl::kEndsCondensedSolve) {
+    const int want = c->cls_ready ? 1 : 0;
+    if (c->cbase_state != want) {   // (after pl_set_bc / when the class table comes or goes: once per assembly at most)
+      (void)hipMemsetAsync(c->cbase.p, 0xFF, (size_t)c->N * sizeof(int32_t), c->stream);
+      hipLaunchKernelGGL(k_cond_base, dim3(grid_for(c->n_cond)), dim3(pl::kBlock), 0, c->stream, c->n_cond, c->cnodes.p,
+                         c->cls_ready ? (const uint16_t *)c->cls_id.p : (const uint16_t *)nullptr, c->cbase.p);
+      c->cbase_state = want;
+    }
+    cs.inv = c->cls_ready ? (const double *)c->cls_table.p : (const double *)c->kcc_inv.p;
+    cs.base = c->cbase.p;
+  }
+  return cs;
+}
+
+int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
+                const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll, bool reduce_dot = true) {
+  const int kind = choose_kernel(c);
+  if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0) {
+    // tile kernel with a caller-chosen row mask and / or only one kind of strut ends (node elimination)
+    const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+    const pl::CondSolve cs = cond_solve(c, ends);
+    if (c->pal_ready)
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,
+                           (const double *)nullptr, ends, cf, cs);
+    else if (c->rec5.p)
+      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
+                           dot_dev, c->stream, c->xyz.p, ends, cf, cs);
+    else
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
+                           (const double *)nullptr, ends, cf, cs);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
+  const int64_t n6 = c->N * 6;
+  if (c->opkind == 1) {
+    const int m = 6 * c->ddm_nb;
+    const size_t lds = ((size_t)m * m + (size_t)(pl::kBlock / pl::kWave) * m) * sizeof(double);
+    const unsigned gw = grid_for((c->ddm_cells + pl::kDdmWaveChunk - 1) / pl::kDdmWaveChunk, pl::kBlock / pl::kWave);
+    if (m <= 48)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<48>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
+                         c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);
+    else if (m <= 64)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<64>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
+                         c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);
+    else if (lds <= 64 * 1024)
+      hipLaunchKernelGGL(pl::k_ddm_cell_product_lds, dim3(grid_for(c->ddm_cells, pl::kDdmChunk)), dim3(pl::kBlock), lds,
+                         c->stream, c->ddm_cells, c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p,
+                         c->ddm_St.p, x, c->ddm_stage.p);
+    else
+      hipLaunchKernelGGL(pl::k_ddm_cell_product, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock),
+                         0, c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x,
+                         c->ddm_stage.p);
+    hipLaunchKernelGGL(pl::k_ddm_node_gather, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y);
+    if (masked || dot_dev)
+      hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
+  if (kind == 1) {
+    PL_HIP(hipMemsetAsync(y, 0, n6 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(pl::k_spmv_atomic, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->conn.p,
+                       c->rec.p, x, y);
+    if (masked || dot_dev)
+      hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
+  } else if (kind == 3 && c->tile.ready) {
+    if (c->pal_ready)
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
+                           dot_dev, c->stream);
+    else if (c->rec5.p)
+      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr,
+                           masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream, c->xyz.p);
+    else
+      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y, dot_dev,
+                           c->stream);
+  } else {
+    int rc = dispatch_gather(c, x, y, masked, dot_dev);
+    if (rc) return rc;
+  }
+  if (c->dist.active) {
+    // Every rank now holds the product of ITS struts.  The Dirichlet mask commutes with the sum over ranks, and
+    // x.(K x) = sum_r x_r.(K_r x_r) with the LOCAL partial products and NO multiplicity weights, so the kernels above
+    // ran exactly as on one GPU; the interface rows and the 32 slots of the partial dot travel in one all-reduce.
+    // (reduce_dot = false: the caller sums the dot slots in a collective of its own - single-reduction PCG)
+    const bool with_dot = dot_dev && reduce_dot;
+    int rc = pl::dist_sum_shared(c->dist, y, c->stream, with_dot ? dot_dev : nullptr, with_dot ? pl::kSlots : 0);
+    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+  }
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// K*p of the fp32 solver modes: tile kernel only, fp32-stored x / y, fp64 arithmetic (pl_tile.h)
+int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double *dot_dev,
+                    const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
+  const uint8_t *mk = maskbits ? maskbits : (masked ? (const uint8_t *)c->fixedbits.p : (const uint8_t *)nullptr);
+  const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+  const pl::CondSolve cs = cond_solve(c, ends);
+  if (c->pal_ready)
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, mk, x, y, dot_dev, c->stream,
+                                (const double *)nullptr, ends, cf, cs);
+  else if (c->rec5.p)
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, mk, x, y,
+                                dot_dev, c->stream, c->xyz.p, ends, cf, cs);
+  else
+    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, mk, x, y, dot_dev, c->stream,
+                                (const double *)nullptr, ends, cf, cs);
+  if (c->dist.active) {
+    int rc = pl::dist_sum_shared<float>(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
+    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
+  }
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// residual history + (reference-CG mode) direction norm, solution norm and step length of every iteration
+int ensure_hist(pl_context *c, int cap) {
+  if (cap <= c->hist_cap) return PL_OK;
+  PL_HIP(c->hist.alloc((size_t)cap * 4));
+  c->hist_cap = cap;
+  return PL_OK;
+}
+// the reference's CG extras are on when the caller asked for any of them (pl_opts_t.mintol / restart_every)
+inline bool ref_cg(const pl_context *c) { return c->opt.mintol > 0.0 || c->opt.restart_every > 0; }
+
+}  // namespace

@@ -1,0 +1,606 @@
+// PCG solvers of libpylattice_hip: ordinary multi-level / Jacobi / reference-CG loop, single-reduction form
+// (Chronopoulos-Gear), fp32 solver modes.
+#pragma once
+#include "pl_assembly.h"
+
+namespace {
+
+// Everything of a two-level PCG iteration after K*p: update + restriction, coarse solve, new direction.
+template <typename PT, typename RT>
+int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
+  pl::Coarse &cs = c->coarse, &cl = c->coarseL;
+  const bool useL = cl.ready;
+#define PL_UPD(TM, MULTI, LOCAL)                                                                                    \
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<PT, RT, TM, MULTI, LOCAL>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), \
+                     0, c->stream,                                                                                   \
+                     c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, Ap, cs.dinv32,                       \
+                     c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr, r, cur,             \
+                     cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
+                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+  if (useL) {
+    if (tile_modes_now(c) == 12) PL_UPD(12, true, true);
+    else PL_UPD(6, true, true);
+  } else if (c->dist.active) {
+    if (tile_modes_now(c) == 12) PL_UPD(12, true, false);
+    else PL_UPD(6, true, false);
+  } else if (tile_modes_now(c) == 12) PL_UPD(12, false, false);
+  else PL_UPD(6, false, false);
+#undef PL_UPD
+  if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
+              // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
+    pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
+                    (const double *)nullptr, c->stream);
+  if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
+    if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
+  }
+  pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
+                  cs.rc + cs.ncp + pl::kSlots, c->stream);
+#define PL_DIR(TM, MULTI, LOCAL)                                                                                         \
+  hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT, TM, MULTI, LOCAL>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), \
+                     0, c->stream,                                                                                        \
+                     c->tile.tile_start.p, (const RT *)r, cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc,         \
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->fixedbits.p, p, x, cur, nxt,     \
+                     c->hist.p, hist_slot, cs.rc, cs.ncp,                                                                \
+                     useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
+                     (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
+                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+#define PL_DIRF(TM)                                                                                                      \
+  hipLaunchKernelGGL((pl::k_pcg_direction_flat<PT, RT, TM>), dim3((unsigned)((3 * c->N + pl::kBlock - 1) / pl::kBlock)),   \
+                     dim3(pl::kBlock), 0, c->stream, c->N, cs.tile_of_node.p, (const RT *)r, cs.dinv32, c->xyz.p,         \
+                     cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
+                     c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
+                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm,                      \
+                     c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr)
+  // flat mapping, contiguous per wave: fp64 p without a rank-local level (measured on one box, 50^3 Octet: 26.2 -> 24.5 us;
+  // fp32 p / fp64 r the same either way, fp32 p / fp32 r 19.0 -> 22.0 us - 8-byte loads per lane are too few in flight)
+  if (!useL && sizeof(PT) == 8) {
+    if (tile_modes_now(c) == 12) PL_DIRF(12);
+    else PL_DIRF(6);
+  } else if (useL) {
+    if (tile_modes_now(c) == 12) PL_DIR(12, true, true);
+    else PL_DIR(6, true, true);
+  } else if (c->dist.active) {
+    if (tile_modes_now(c) == 12) PL_DIR(12, true, false);
+    else PL_DIR(6, true, false);
+  } else if (tile_modes_now(c) == 12) PL_DIR(12, false, false);
+  else PL_DIR(6, false, false);
+#undef PL_DIRF
+#undef PL_DIR
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
+  return pcg_tail_coarse_t<double, double>(c, cur, nxt, hist_slot, c->p.p, (const double *)c->Ap.p, c->x.p, c->r.p);
+}
+
+// One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
+int pcg_iteration(pl_context *c, int k) {
+  const int64_t n6 = c->N * 6;
+  const int set = pl::S_COUNT * pl::kSlots;
+  double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
+  if (c->cond_use) {
+    // S p: the condensed nodes take their equilibrium position under p (first pass, their rows of p are 0 on entry),
+    // then the ordinary product with their rows masked like Dirichlet rows (second pass, with p.Ap)
+    // (first pass fused with the 6 x 6 solves: every tile writes -K_cc^-1 (K p_v)_c into the p rows of its condensed nodes)
+    int rc = launch_spmv(c, c->p.p, c->p.p, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+    if (rc) return rc;
+    rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
+    if (rc) return rc;
+    return pcg_tail_coarse(c, cur, nxt, k);
+  }
+  int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
+  if (rc) return rc;
+  if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
+  // reference-CG mode (conjugate_gradient_solver.py:79-109): every restart_every-th iteration the direction is rebuilt
+  // on the PREVIOUS z (with a preconditioner; kept in tmp) or on the updated residual (without one: z aliases r there)
+  const bool ref = ref_cg(c) && !c->dist.active;
+  const bool restart = ref && c->opt.restart_every > 0 && k > 0 && (k % c->opt.restart_every) == 0;
+  const bool has_M = c->dd_ready || c->opt.precond >= 1;
+  const double *pn = c->p.p, *psrc = nullptr;
+  if (restart) {
+    if (has_M) {
+      PL_HIP(hipMemcpyAsync(c->tmp.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      pn = psrc = c->tmp.p;
+    } else {
+      pn = nullptr;        // ||r_new||
+      psrc = c->z.p;       // = r_new once the update kernel has run (dinv = 1 on free dofs)
+    }
+  }
+  const int hcap = ref ? c->hist_cap : 0;
+  if (c->dd_ready) {   // DDM with the factorised assembled matrix: update leaves z = 0, r.z = 0; then z = G^-1 r
+    if (ref)
+      hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
+    else
+      hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
+    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
+                    cur + pl::S_RZ_NEW * pl::kSlots, (const double *)nullptr, c->stream);
+    hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
+                       c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
+  if (c->dist.active) {
+    pl::launch_pcg_update_weighted(n6, c->p.p, c->Ap.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p, c->z.p, cur,
+                                   c->stream);
+    if (pl::dist_sum_scalars(c->dist, cur + pl::S_RZ_NEW * pl::kSlots, 2 * pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the PCG scalars failed");
+  } else if (ref) {
+    hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
+  } else {
+    hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
+  }
+  hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
+                     c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// Solve P K P x = rhs (device rhs already masked), x0 = 0.  Result in c->x.  Returns iterations through stats.
+int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+              pl_stats_t *st) {
+  const int64_t n6 = c->N * 6;
+  int rc = ensure_hist(c, max_iter + 1);
+  if (rc) return rc;
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
+  if (c->dist.active)
+    pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
+                                 c->z.p, c->p.p, c->scal.p, c->stream);
+  else
+    hipLaunchKernelGGL(pl::k_pcg_init, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active) {
+    if (pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream) ||
+        pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
+  }
+  if (c->dd_ready) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
+    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
+                    c->scal.p + pl::S_RZ_OLD * pl::kSlots, (const double *)nullptr, c->stream);
+    PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (c->cond_ready && c->coarse.ready) {
+    // start from the iterate whose condensed nodes are in equilibrium: x_c = K_cc^-1 r_c, r <- r - K x (rows of the
+    // condensed nodes become exactly 0 and stay 0: every later step keeps them in equilibrium)
+    // t_c = K_cc^-1 b_c (rows of z, zero elsewhere), r_v -= (K t)_v: the load the eliminated nodes pass on.  Their own
+    // rows of r keep b_c, their rows of x stay 0 until the back-substitution after the loop.
+    PL_HIP(hipMemsetAsync(c->z.p, 0, n6 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(pl::k_condense_solve<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, c->z.p, 1.0);
+    rc = launch_spmv(c, c->z.p, c->tmp2.p, true, nullptr, c->maskC.p, pl::kEndsOthers);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pl::k_condense_subtract<double>, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, c->cflag.p,
+                       (const double *)c->tmp2.p, c->r.p);
+    PL_HIP(hipGetLastError());
+  }
+  if (c->coarse.ready) {
+    // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
+    // scalar set 1; its direction kernel leaves p = z0 and rz_old = r0.z0 in set 0, where iteration 0 starts.
+    const int set = pl::S_COUNT * pl::kSlots;
+    PL_HIP(hipMemsetAsync(c->p.p, 0, n6 * sizeof(double), c->stream));
+    PL_HIP(hipMemsetAsync(c->Ap.p, 0, n6 * sizeof(double), c->stream));
+    rc = pcg_tail_coarse(c, c->scal.p + set, c->scal.p, max_iter);
+    if (rc) return rc;
+  }
+  double h_scal[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p + pl::S_BB * pl::kSlots, sizeof(h_scal), hipMemcpyDeviceToHost,
+                        c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  double bb = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) bb += h_scal[k];
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  if (!(bb > 0.0)) {   // zero right-hand side -> zero solution
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  // The host looks at the residual history every `chunk` iterations.  With the default (check_every = 0) the chunk
+  // adapts: 32 while far from the threshold, then what the observed decay rate predicts is still needed - a fixed
+  // chunk overshoots by 16 iterations on average, 8 % of a 200-iteration solve.  (Every rank of a multi-GPU run sees
+  // the same all-reduced history, hence takes the same decisions.)
+  const bool adaptive = c->opt.check_every <= 0;
+  const int chunk = adaptive ? 32 : c->opt.check_every;
+  const bool ref = ref_cg(c) && !c->dist.active && !c->coarse.ready;
+  const int hcap = c->hist_cap;
+  // A design loop solves a slowly changing system over and over: the iteration count of the previous converged solve on
+  // this handle (identical on every rank) is where the first look at the history is worth taking - three iterations
+  // before it - instead of every 32 iterations on the way there (each look drains the stream: 30-50 us).
+  const int first = (adaptive && !ref && c->last_iterations > 40) ? std::min(c->last_iterations - 3, max_iter) : chunk;
+  const int hbuf = std::max(chunk, first);
+  std::vector<double> h_hist(hbuf), h_pp(ref ? hbuf : 0), h_xx(ref ? hbuf : 0), h_al(ref ? hbuf : 0);
+  st->info = 1.0;
+  int k = 0, next = first;
+  double rr_prev = bb;
+  int k_prev = 0;
+  while (k < max_iter) {
+    const int todo = std::min(next, max_iter - k);
+    for (int j = 0; j < todo; ++j) {
+      rc = pcg_iteration(c, k + j);
+      if (rc) return rc;
+    }
+    PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (ref) {
+      PL_HIP(hipMemcpyAsync(h_pp.data(), c->hist.p + hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipMemcpyAsync(h_xx.data(), c->hist.p + 2 * (size_t)hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipMemcpyAsync(h_al.data(), c->hist.p + 3 * (size_t)hcap + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    PL_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < todo; ++j) {
+      const double rr = h_hist[j];
+      if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+      if (!st->converged) st->rel_residual = std::sqrt(rr / bb);
+      if (rr <= thresh && !st->converged) {
+        st->converged = 1;
+        st->iterations = k + j + 1;
+        st->info = 0.0;
+        st->stop_reason = 0.0;
+      }
+      if (ref && !st->converged) {
+        // conjugate_gradient_solver.py:102-109, in its order: the direction-norm stop, then the "tiny step" flag
+        if (c->opt.mintol > 0.0 && std::sqrt(h_pp[j]) < c->opt.mintol * (std::sqrt(h_xx[j]) + 1e-12)) {
+          st->converged = 1;
+          st->iterations = k + j + 1;
+          st->info = 0.0;
+          st->stop_reason = 1.0;
+        } else if (h_al[j] < 1e-6) {
+          st->info = 2.0;
+        }
+      }
+    }
+    k += todo;
+    if (st->converged) break;
+    if (adaptive) {
+      const double rr_end = h_hist[todo - 1];
+      next = chunk;
+      if (rr_end < rr_prev && rr_end > thresh) {
+        const double per_it = std::log(rr_end / rr_prev) / (double)(k - k_prev);      // < 0
+        const double need = std::log(thresh / rr_end) / per_it;
+        if (need < 2.0 * chunk) next = std::max(2, std::min(chunk, (int)std::ceil(0.75 * need)));
+      }
+      rr_prev = rr_end;
+      k_prev = k;
+    }
+  }
+  if (!st->converged) st->iterations = k;
+  c->last_iterations = st->converged ? st->iterations : 0;
+  if (c->cond_use) {   // eliminated nodes: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
+    rc = launch_spmv(c, c->x.p, c->tmp2.p, false, nullptr, nullptr, pl::kEndsCondensed);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pl::k_condense_backsubst<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
+    PL_HIP(hipGetLastError());
+  }
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Single-reduction PCG (opts.cg_form = 1; pl_cg1.h): u -> z, w -> Ap, s -> tmp2.
+// ----------------------------------------------------------------------------------------------------------
+inline bool cg1_applies(const pl_context *c) {
+  return c->opt.cg_form == 1 && c->coarse.ready && !c->coarseL.ready && !c->cond_use && c->opt.precision == 0 &&
+         c->opkind == 0 && c->tile.ready && choose_kernel(c) == 3;
+}
+
+int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+                  pl_stats_t *st) {
+  const int64_t n6 = c->N * 6;
+  pl::Coarse &cs = c->coarse;
+  const int ncp = cs.ncp, bs = pl::cg1_block_size(ncp);
+  int rc = ensure_hist(c, max_iter + 2);
+  if (rc) return rc;
+  const size_t need = 2 * (size_t)bs + 2 * pl::kSlots + 4 + (size_t)ncp;
+  if (!c->cg1.p || c->cg1.n < need) PL_HIP(c->cg1.alloc(need));
+  double *blk[2] = {c->cg1.p, c->cg1.p + bs};
+  double *gc[2] = {c->cg1.p + 2 * bs, c->cg1.p + 2 * bs + pl::kSlots};
+  double *stt[2] = {c->cg1.p + 2 * bs + 2 * pl::kSlots, c->cg1.p + 2 * bs + 2 * pl::kSlots + 2};
+  double *sc = c->cg1.p + 2 * bs + 2 * pl::kSlots + 4;
+  double *u = c->z.p, *w = c->Ap.p, *s = c->tmp2.p;
+  const double *wt = c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr;
+  const uint8_t *shared = c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr;
+  const double *Bt = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
+  const double *yt = cs.tile_level ? (const double *)cs.yt : (const double *)nullptr;
+  const dim3 gt((unsigned)cs.n_tiles), blkdim(cs.vblock);
+
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->cg1.p, 0, need * sizeof(double), c->stream));
+  // r0 = P (f - K ubar), x = 0, ||b||^2 (the z / p the init kernel also writes are overwritten below)
+  if (c->dist.active)
+    pl::launch_pcg_init_weighted(n6, f_dev, Kubar_dev, c->fixed.p, c->dinv.p, c->dist.weight.p, c->x.p, c->r.p,
+                                 c->z.p, c->p.p, c->scal.p, c->stream);
+  else
+    hipLaunchKernelGGL(pl::k_pcg_init, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       c->fixed.p, c->dinv.p, c->x.p, c->r.p, c->z.p, c->p.p, c->scal.p);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
+  PL_HIP(hipMemsetAsync(c->p.p, 0, n6 * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(s, 0, n6 * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(cs.rc, 0, (size_t)ncp * sizeof(double), c->stream));
+
+  // u = M^-1 r, w = K u and the reduction block of iteration k (k = -1: the pass that prepares iteration 0)
+  auto second_half = [&](int k) -> int {
+    const int cur = k & 1, nxt = (k + 1) & 1;
+    pl::dense_apply(cs.W, cs.Wt, ncp, ncp, cs.rc, cs.tv, cs.yc, gc[nxt], (const double *)nullptr, c->stream);
+    hipLaunchKernelGGL(pl::k_cg1_precond, gt, blkdim, 0, c->stream, c->tile.tile_start.p, (const double *)c->r.p,
+                       cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc, yt, c->fixedbits.p, shared, u,
+                       k >= 0 ? blk[cur] : (double *)nullptr, bs, k >= 0 ? gc[cur] : (double *)nullptr);
+    int r2 = launch_spmv(c, u, w, true, blk[nxt] + ncp, nullptr, pl::kEndsAll, false);
+    if (r2) return r2;
+    hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                       c->xyz.p, (const double *)w, wt, blk[nxt]);
+    if (c->dist.active && pl::dist_sum_scalars(c->dist, blk[nxt], bs, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the single-reduction PCG failed");
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  };
+  // Z^T r0 (summed over ranks once), tile level and partial sums of r0 into block 0, then u0, w0
+  hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                     c->xyz.p, (const double *)c->r.p, wt, cs.rc);
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, cs.rc, ncp, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of the initial coarse residual failed");
+  hipLaunchKernelGGL(pl::k_cg1_update<true>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                     c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p, c->r.p,
+                     (const double *)blk[1], (const double *)gc[1], (const double *)stt[1], stt[0], blk[0], Bt, cs.yt,
+                     shared, cs.rc, sc, ncp, c->hist.p, -1);
+  rc = second_half(-1);
+  if (rc) return rc;
+
+  double h_scal[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h_scal, c->scal.p + pl::S_BB * pl::kSlots, sizeof(h_scal), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  double bb = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) bb += h_scal[k];
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  st->info = 1.0;
+  if (!(bb > 0.0)) {
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  const bool adaptive = c->opt.check_every <= 0;
+  const int chunk = adaptive ? 32 : c->opt.check_every;
+  std::vector<double> h_hist(chunk);
+  int k = 0, next = chunk, k_prev = 0;
+  double rr_prev = bb;
+  // hist[k] = ||r_k||^2, the residual BEFORE update k (it is reduced together with that iteration's other sums)
+  while (k < max_iter + 1) {
+    const int todo = std::min(next, max_iter + 1 - k);
+    for (int j = 0; j < todo; ++j) {
+      const int it = k + j, cur = it & 1, nxt = (it + 1) & 1;
+      hipLaunchKernelGGL(pl::k_cg1_update<false>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p,
+                         cs.cen.p, c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p,
+                         c->r.p, (const double *)blk[cur], (const double *)gc[cur], (const double *)stt[cur], stt[nxt],
+                         blk[nxt], Bt, cs.yt, shared, cs.rc, sc, ncp, c->hist.p, it);
+      rc = second_half(it);
+      if (rc) return rc;
+    }
+    PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < todo; ++j) {
+      const double rr = h_hist[j];
+      if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+      if (!st->converged) st->rel_residual = std::sqrt(rr / bb);
+      if (rr <= thresh && !st->converged) {
+        st->converged = 1;
+        st->iterations = k + j;      // updates applied when this residual was reached (x has had a few more since)
+        st->info = 0.0;
+        st->stop_reason = 0.0;
+      }
+    }
+    k += todo;
+    if (st->converged) break;
+    if (adaptive) {
+      const double rr_end = h_hist[todo - 1];
+      next = chunk;
+      if (rr_end < rr_prev && rr_end > thresh) {
+        const double per_it = std::log(rr_end / rr_prev) / (double)(k - k_prev);
+        const double need_it = std::log(thresh / rr_end) / per_it;
+        if (need_it < 2.0 * chunk) next = std::max(2, std::min(chunk, (int)std::ceil(0.75 * need_it) + 1));
+      }
+      rr_prev = rr_end;
+      k_prev = k;
+    }
+  }
+  if (!st->converged) st->iterations = std::min(k, max_iter);
+  return PL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// fp32 solver modes (opts.precision; multi-level PCG on the tile kernel only):
+//   1  inner PCG on fp32-stored x, r, p, Ap; the fp64 solution accumulates the inner corrections and every restart
+//      begins from the TRUE fp64 residual P(f - K(ubar + x)) (classical iterative refinement);
+//   2  only the search direction p and K*p are stored in fp32, x and the residual recurrence stay fp64: no restart
+//      is needed to reach fp64 accuracy, the true residual is verified once the recurrence says "converged" (the
+//      fp32 rounding of K*p lets the two drift apart by ~6e-8 of the accumulated steps).
+// In both modes every product and sum is evaluated in fp64 (pl_tile.h, pl_coarse.h): fp32 only halves the bytes.
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(pl::kBlock) void k_mp_true_residual(int64_t n6, const double *__restrict__ f,
+                                                                const double *__restrict__ Kubar,
+                                                                const double *__restrict__ Kx /* may be null */,
+                                                                const uint8_t *__restrict__ fixed,
+                                                                const double *__restrict__ w /* may be null */,
+                                                                double *__restrict__ r, double *__restrict__ rr_slots) {
+  __shared__ double red[pl::kBlock / pl::kWave];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock) {
+    const double v = fixed[i] ? 0.0 : f[i] - Kubar[i] - (Kx ? Kx[i] : 0.0);
+    r[i] = v;
+    acc += (w ? w[i] : 1.0) * v * v;
+  }
+  const double t = pl::block_sum(acc, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(rr_slots + (blockIdx.x & (pl::kSlots - 1)), t);
+}
+// start of an fp32 inner solve: r32 = r, x32 = 0
+__global__ __launch_bounds__(pl::kBlock) void k_mp_restart(int64_t n6, const double *__restrict__ r,
+                                                          float *__restrict__ r32, float *__restrict__ x32) {
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock) {
+    r32[i] = (float)r[i];
+    x32[i] = 0.f;
+  }
+}
+__global__ __launch_bounds__(pl::kBlock) void k_mp_accumulate(int64_t n6, const float *__restrict__ x32,
+                                                             double *__restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; i < n6; i += (int64_t)gridDim.x * pl::kBlock)
+    x[i] += (double)x32[i];
+}
+
+int read_slots(pl_context *c, const double *dev, double *sum) {
+  double h[pl::kSlots];
+  PL_HIP(hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  *sum = 0.0;
+  for (int k = 0; k < pl::kSlots; ++k) *sum += h[k];
+  return PL_OK;
+}
+
+template <typename RT>
+int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
+                   pl_stats_t *st) {
+  constexpr bool kAll32 = sizeof(RT) == 4;
+  const int64_t n6 = c->N * 6;
+  const int set = pl::S_COUNT * pl::kSlots;
+  int rc = ensure_hist(c, max_iter + 2);
+  if (rc) return rc;
+  float *p32 = reinterpret_cast<float *>(c->p.p), *Ap32 = reinterpret_cast<float *>(c->Ap.p);
+  // mode 1: the inner iterate / residual live in the (otherwise unused) z buffer
+  RT *xi = kAll32 ? reinterpret_cast<RT *>(c->z.p) : reinterpret_cast<RT *>(c->x.p);
+  RT *ri = kAll32 ? reinterpret_cast<RT *>(c->z.p) + n6 : reinterpret_cast<RT *>(c->r.p);
+  const double *w = c->dist.active ? (const double *)c->dist.weight.p : (const double *)nullptr;
+  double *aux = c->scal.p + pl::S_AUX * pl::kSlots;   // slots outside the two per-parity sets' live entries
+  PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * set * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->x.p, 0, n6 * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_mp_true_residual, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                     (const double *)nullptr, c->fixed.p, w, c->r.p, aux);
+  PL_HIP(hipGetLastError());
+  if (c->dist.active && pl::dist_sum_scalars(c->dist, aux, pl::kSlots, c->stream))
+    return fail(PL_ERR_HIP, "RCCL all-reduce of ||b||^2 failed");
+  double bb = 0.0;
+  rc = read_slots(c, aux, &bb);
+  if (rc) return rc;
+  st->b_norm = std::sqrt(bb);
+  st->iterations = 0;
+  st->converged = 0;
+  st->rel_residual = 0.0;
+  if (!(bb > 0.0)) {
+    st->converged = 1;
+    return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
+  }
+  const double thresh = rtol * rtol * bb;
+  // an fp32 residual recurrence is trustworthy over ~4 decades: restart from the true residual after that
+  const double inner_drop = kAll32 ? 1e-8 : 0.0;      // on ||r||^2
+  double rr_true = bb;
+  int k = 0;                      // iterations over all inner solves
+  std::vector<double> h_hist(32);
+  for (int outer = 0; outer < 40 && k < max_iter; ++outer) {
+    // ---- (re)start: p = M^-1 r through the tail of an iteration "-1" (alpha = 0) on scalar set 1
+    PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * set * sizeof(double), c->stream));
+    if (kAll32)
+      hipLaunchKernelGGL(k_mp_restart, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, c->r.p,
+                         reinterpret_cast<float *>(ri), reinterpret_cast<float *>(xi));
+    PL_HIP(hipMemsetAsync(p32, 0, n6 * sizeof(float), c->stream));
+    if (kAll32 && c->cond_use) {
+      // node elimination inside the inner solve (as in pcg_solve): t_c = K_cc^-1 b_c in the rows of p32, r_v -= (K t)_v
+      float *r32 = reinterpret_cast<float *>(ri);
+      hipLaunchKernelGGL(pl::k_condense_solve<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                         c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)r32, p32, 1.0);
+      rc = launch_spmv_f32(c, p32, Ap32, true, nullptr, c->maskC.p, pl::kEndsOthers);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pl::k_condense_subtract<float>, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                         c->cflag.p, (const float *)Ap32, r32);
+      PL_HIP(hipMemsetAsync(p32, 0, n6 * sizeof(float), c->stream));
+    }
+    PL_HIP(hipMemsetAsync(Ap32, 0, n6 * sizeof(float), c->stream));
+    rc = pcg_tail_coarse_t<float, RT>(c, c->scal.p + set, c->scal.p, max_iter + 1, p32, (const float *)Ap32, xi, ri);
+    if (rc) return rc;
+    const double stop = std::max(thresh, inner_drop * rr_true);
+    bool inner_done = false;
+    int j = 0, next = 32;
+    double rr_prev = rr_true;
+    int j_prev = 0;
+    while (!inner_done && k < max_iter) {
+      const int todo = std::min(next, max_iter - k);
+      for (int q = 0; q < todo; ++q) {
+        double *cur = c->scal.p + ((j + q) & 1) * set, *nxt = c->scal.p + ((j + q + 1) & 1) * set;
+        if (kAll32 && c->cond_use) {
+          rc = launch_spmv_f32(c, p32, p32, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+          if (rc) return rc;
+          rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots, c->maskC.p, pl::kEndsOthers);
+        } else {
+          rc = launch_spmv_f32(c, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        }
+        if (rc) return rc;
+        rc = pcg_tail_coarse_t<float, RT>(c, cur, nxt, k + q, p32, (const float *)Ap32, xi, ri);
+        if (rc) return rc;
+      }
+      PL_HIP(hipMemcpyAsync(h_hist.data(), c->hist.p + k, todo * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipStreamSynchronize(c->stream));
+      int used = todo;
+      for (int q = 0; q < todo; ++q) {
+        const double rr = h_hist[q];
+        if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+        if (rr <= stop) { inner_done = true; used = q + 1; break; }
+      }
+      // (the device has run the whole chunk: x holds the iterate after `todo` iterations, which is what is kept)
+      const double rr_end = h_hist[todo - 1];
+      j += todo;
+      k += todo;
+      (void)used;
+      if (!inner_done) {
+        next = 32;
+        if (rr_end < rr_prev && rr_end > stop) {
+          const double per_it = std::log(rr_end / rr_prev) / (double)(j - j_prev);
+          const double need = std::log(stop / rr_end) / per_it;
+          if (need < 64.0) next = std::max(2, std::min(32, (int)std::ceil(0.75 * need)));
+        }
+        rr_prev = rr_end;
+        j_prev = j;
+      }
+    }
+    // ---- true residual of the accumulated solution
+    if (kAll32 && c->cond_use) {   // the eliminated nodes of this inner solve: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
+      float *x32 = reinterpret_cast<float *>(xi), *r32 = reinterpret_cast<float *>(ri);
+      rc = launch_spmv_f32(c, x32, Ap32, false, nullptr, nullptr, pl::kEndsCondensed);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pl::k_condense_backsubst<float>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
+                         c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const float *)r32, (const float *)Ap32, x32);
+    }
+    if (kAll32)
+      hipLaunchKernelGGL(k_mp_accumulate, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
+                         reinterpret_cast<const float *>(xi), c->x.p);
+    rc = launch_spmv(c, c->x.p, c->tmp2.p, true, nullptr);
+    if (rc) return rc;
+    PL_HIP(hipMemsetAsync(aux, 0, pl::kSlots * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_mp_true_residual, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       (const double *)c->tmp2.p, c->fixed.p, w, c->r.p, aux);
+    PL_HIP(hipGetLastError());
+    if (c->dist.active && pl::dist_sum_scalars(c->dist, aux, pl::kSlots, c->stream))
+      return fail(PL_ERR_HIP, "RCCL all-reduce of the true residual failed");
+    rc = read_slots(c, aux, &rr_true);
+    if (rc) return rc;
+    if (std::isnan(rr_true) || std::isinf(rr_true)) return fail(PL_ERR_NAN, "NaN/Inf in the true residual");
+    st->rel_residual = std::sqrt(rr_true / bb);
+    st->restarts = (double)(outer + 1);     // restarts (inner solves) taken
+    if (rr_true <= thresh * 1.0000001) {
+      st->converged = 1;
+      break;
+    }
+  }
+  st->iterations = k;
+  return PL_OK;
+}
+
+}  // namespace
