@@ -50,7 +50,17 @@ typedef struct {
   const int32_t *seg_nsub;    /* [3*n_beams] number of equal P1 sub-elements per segment (>=1 where len>0) */
 } pl_mesh_t;
 
+/* ABI handshake.  pl_opts_t and pl_stats_t grow from release to release; a caller compiled (or a ctypes binding written)
+ * against another header must fail with PL_ERR_ARG instead of having memory overrun.  Both structs therefore START with
+ * the size the CALLER believes they have: pl_default_opts(&o, sizeof o) refuses any other size than the library's and
+ * stamps struct_size / abi_version, pl_create / pl_create_ddm check the stamp, and pl_solve checks stats->struct_size,
+ * which the caller sets (= sizeof(pl_stats_t)) before the call.  pl_opts_size() / pl_stats_size() / pl_abi_version()
+ * let a binding assert its layout when it loads the library. */
+#define PL_ABI_VERSION 3u
+
 typedef struct {
+  uint32_t struct_size;  /* sizeof(pl_opts_t) as the caller sees it; written by pl_default_opts, checked by pl_create */
+  uint32_t abi_version;  /* PL_ABI_VERSION, written by pl_default_opts */
   double young;          /* E   (materials/<name>.json Young_modulus) */
   double poisson;        /* nu */
   double kappa;          /* shear correction, 0.9 in material_definition.py:45 */
@@ -116,8 +126,10 @@ typedef struct {
 } pl_opts_t;
 
 typedef struct {
+  uint32_t struct_size;    /* IN: sizeof(pl_stats_t) as the caller sees it (pl_solve returns PL_ERR_ARG on any other value) */
   int32_t iterations;
   int32_t converged;       /* 1 if ||r|| <= rtol*||b|| */
+  int32_t reserved_i;
   double rel_residual;     /* ||r||/||b|| of the recurrence at exit */
   double b_norm;
   double ms_assembly;      /* last pl_assemble (+ pl_assemble_bsr) on the device, HIP events */
@@ -135,7 +147,12 @@ typedef struct {
   double reserved[1];
 } pl_stats_t;
 
-void pl_default_opts(pl_opts_t *o);
+/* Fills *o with the defaults.  struct_size = sizeof(pl_opts_t) of the caller's header; PL_ERR_ARG (and *o untouched)
+ * when it differs from the library's. */
+int pl_default_opts(pl_opts_t *o, uint32_t struct_size);
+uint32_t pl_opts_size(void);
+uint32_t pl_stats_size(void);
+uint32_t pl_abi_version(void);
 const char *pl_last_error(void);
 const char *pl_version(void);
 

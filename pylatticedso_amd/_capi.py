@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("PYLATTICE_HIP_LIB") or os.path.join(_HERE, "libpylatt
 PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
-EXPORTS = ["pl_default_opts", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
+EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
            "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
@@ -34,7 +34,8 @@ class PlMesh(C.Structure):
 
 
 class PlOpts(C.Structure):
-    _fields_ = [("young", C.c_double), ("poisson", C.c_double), ("kappa", C.c_double), ("pen_coef", C.c_double),
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+                ("young", C.c_double), ("poisson", C.c_double), ("kappa", C.c_double), ("pen_coef", C.c_double),
                 ("device", C.c_int32), ("spmv_kernel", C.c_int32), ("precond", C.c_int32), ("reorder", C.c_int32),
                 ("check_every", C.c_int32), ("lanes_per_node", C.c_int32),
                 ("tile_nodes", C.c_int32), ("coarse_max_dofs", C.c_int32), ("palette", C.c_int32),
@@ -46,7 +47,8 @@ class PlOpts(C.Structure):
 
 
 class PlStats(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
+    _fields_ = [("struct_size", C.c_uint32), ("iterations", C.c_int32), ("converged", C.c_int32),
+                ("reserved_i", C.c_int32), ("rel_residual", C.c_double),
                 ("b_norm", C.c_double), ("ms_assembly", C.c_double), ("ms_solve", C.c_double),
                 ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("restarts", C.c_double),
                 ("precision_used", C.c_double), ("info", C.c_double), ("stop_reason", C.c_double),
@@ -76,10 +78,11 @@ def load_library(path: str | None = None):
     lib.pl_last_error.restype = C.c_char_p
     lib.pl_version.restype = C.c_char_p
     lib.pl_destroy.restype = None
-    lib.pl_default_opts.restype = None
+    for name in ("pl_opts_size", "pl_stats_size", "pl_abi_version"):
+        getattr(lib, name).restype = C.c_uint32
     lib.pl_lattice_free.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
-    sig = {"pl_default_opts": [V], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
+    sig = {"pl_default_opts": [V, C.c_uint32], "pl_opts_size": [], "pl_stats_size": [], "pl_abi_version": [], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
            "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
            "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
@@ -92,8 +95,21 @@ def load_library(path: str | None = None):
            "pl_lattice_free": [V], "pl_penalize": [I64, V, V, V, D, V, V, V]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
+    # ABI handshake (include/pylattice_hip.h): this binding's struct layouts must be the library's
+    if lib.pl_opts_size() != C.sizeof(PlOpts) or lib.pl_stats_size() != C.sizeof(PlStats):
+        raise ImportError(f"{p}: pl_opts_t / pl_stats_t are {lib.pl_opts_size()} / {lib.pl_stats_size()} bytes in the "
+                          f"library, {C.sizeof(PlOpts)} / {C.sizeof(PlStats)} in this binding (ABI version "
+                          f"{lib.pl_abi_version()}): rebuild libpylattice_hip.so")
     _lib = lib
     return lib
+
+
+def default_opts(lib=None) -> "PlOpts":
+    """A pl_opts_t stamped by pl_default_opts (struct size + ABI version checked by the library)."""
+    lib = lib or load_library()
+    opts = PlOpts()
+    _check(lib, lib.pl_default_opts(C.byref(opts), C.sizeof(PlOpts)))
+    return opts
 
 
 def _ptr(a):
@@ -205,8 +221,7 @@ class HipLattice:
         self._seg_nsub = np.ascontiguousarray(seg_nsub, dtype=np.int32).reshape(-1)
         mesh = PlMesh(self.n_nodes, self.n_beams, _ptr(self.node_xyz), _ptr(self.beam_conn), _ptr(self._radius),
                       _ptr(self._seg_len), _ptr(self._seg_nsub))
-        opts = PlOpts()
-        self._lib.pl_default_opts(C.byref(opts))
+        opts = default_opts(self._lib)
         opts.young, opts.poisson, opts.kappa, opts.pen_coef = young, poisson, kappa, pen_coef
         opts.device, opts.spmv_kernel, opts.reorder, opts.check_every = device, spmv_kernel, reorder, check_every
         opts.lanes_per_node = lanes_per_node
@@ -244,8 +259,7 @@ class HipLattice:
             Sm = Sm[None]
         cs = np.ascontiguousarray(cell_S, dtype=np.int32)
         self.n_nodes, self.n_beams = int(n_nodes), 0
-        opts = PlOpts()
-        self._lib.pl_default_opts(C.byref(opts))
+        opts = default_opts(self._lib)
         opts.device, opts.alpha_max, opts.check_every = device, alpha_max, check_every
         opts.precond = precond
         opts.mintol, opts.restart_every = float(mintol), int(restart_every)   # conjugate_gradient_solver.py:96-109
@@ -271,8 +285,15 @@ class HipLattice:
         _check(self._lib, self._lib.pl_ddm_set_preconditioner(self._h, Sm.shape[0], _ptr(Sm), _ptr(cs)))
 
     # -- lifetime ---------------------------------------------------------------------------------------
+    def _changing(self, why):
+        cb = getattr(self, "_before_change", None)
+        if cb is not None:
+            self._before_change = None
+            cb(why)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self._changing("handle closed")
             self._lib.pl_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -299,10 +320,12 @@ class HipLattice:
         _check(self._lib, self._lib.pl_set_bc(self._h, _ptr(fx), _ptr(ub), _ptr(ff)))
 
     def update_radii(self, radius):
+        self._changing("update_radii")
         self._radius = _f64(radius, self.n_beams)
         _check(self._lib, self._lib.pl_update_radii(self._h, _ptr(self._radius)))
 
     def update_segments(self, seg_len, seg_nsub):
+        self._changing("update_segments")
         self._seg_len = _f64(seg_len, 3 * self.n_beams)
         self._seg_nsub = np.ascontiguousarray(seg_nsub, dtype=np.int32).reshape(-1)
         _check(self._lib, self._lib.pl_update_segments(self._h, _ptr(self._seg_len), _ptr(self._seg_nsub)))
@@ -351,8 +374,9 @@ class HipLattice:
         """PCG solve; returns (u[N,6], stats).  download=False leaves u on the device and returns stats only."""
         u = np.empty(6 * self.n_nodes, np.float64) if download else None
         st = PlStats()
+        st.struct_size = C.sizeof(PlStats)
         rc = self._lib.pl_solve(self._h, float(rtol), int(max_iter), _ptr(u), C.byref(st))
-        self.last_stats = {k: getattr(st, k) for k, _ in PlStats._fields_ if k != "reserved"}
+        self.last_stats = {k: getattr(st, k) for k, _ in PlStats._fields_ if k not in ("reserved", "reserved_i", "struct_size")}
         _timing.device("pl_solve: PCG (HIP events)", st.ms_solve)
         if st.ms_assembly > 0.0:
             _timing.device("pl_assemble of this solve (HIP events)", st.ms_assembly)

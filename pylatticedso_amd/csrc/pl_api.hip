@@ -68,9 +68,19 @@ extern "C" {
 const char *pl_last_error(void) { return g_err.c_str(); }
 const char *pl_version(void) { return "pylattice_hip 0.1 (gfx950)"; }
 
-void pl_default_opts(pl_opts_t *o) {
-  if (!o) return;
+uint32_t pl_opts_size(void) { return (uint32_t)sizeof(pl_opts_t); }
+uint32_t pl_stats_size(void) { return (uint32_t)sizeof(pl_stats_t); }
+uint32_t pl_abi_version(void) { return PL_ABI_VERSION; }
+
+int pl_default_opts(pl_opts_t *o, uint32_t struct_size) {
+  if (!o) return fail(PL_ERR_ARG, "pl_default_opts: null argument");
+  if (struct_size != sizeof(pl_opts_t))
+    return fail(PL_ERR_ARG, "pl_default_opts: the caller's pl_opts_t has " + std::to_string(struct_size) +
+                                " bytes, this library's " + std::to_string(sizeof(pl_opts_t)) +
+                                " (ABI version " + std::to_string(PL_ABI_VERSION) + "): rebuild the binding against include/pylattice_hip.h");
   std::memset(o, 0, sizeof(*o));
+  o->struct_size = (uint32_t)sizeof(pl_opts_t);
+  o->abi_version = PL_ABI_VERSION;
   o->young = 1013.0;   // VeroClear
   o->poisson = 0.3;
   o->kappa = 0.9;
@@ -80,9 +90,18 @@ void pl_default_opts(pl_opts_t *o) {
   o->precond = 1;
   o->reorder = 1;
   o->check_every = 0;   // adaptive
+  return PL_OK;
 }
 
 namespace {
+// pl_opts_t must carry the stamp of pl_default_opts of THIS library (include/pylattice_hip.h, "ABI handshake")
+int check_opts_abi(const pl_opts_t *o, const char *who) {
+  if (o->struct_size != sizeof(pl_opts_t) || o->abi_version != PL_ABI_VERSION)
+    return fail(PL_ERR_ARG, std::string(who) + ": pl_opts_t was not initialised by pl_default_opts of this library (struct_size " +
+                                std::to_string(o->struct_size) + " / abi " + std::to_string(o->abi_version) + ", expected " +
+                                std::to_string(sizeof(pl_opts_t)) + " / " + std::to_string(PL_ABI_VERSION) + ")");
+  return PL_OK;
+}
 inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
 // modes per aggregate of the dense level: 12 (rigid + strains) needs the 12-mode tile level, i.e. a single-GPU handle in
 // the ordinary CG form with precond = 3
@@ -113,6 +132,7 @@ inline int coarse_budget(const pl_opts_t *o, int64_t N) {
 
 int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (!m || !o || !out) return fail(PL_ERR_ARG, "pl_create: null argument");
+  if (int rc_abi = check_opts_abi(o, "pl_create")) return rc_abi;
   StageTimer stage("pl_create");
   if (m->n_nodes <= 0 || m->n_beams <= 0) return fail(PL_ERR_ARG, "pl_create: empty mesh");
   if (m->n_nodes >= (1LL << 31) - 64 || m->n_beams >= (1LL << 31) - 64)
@@ -381,6 +401,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S,
                   const double *S, const int32_t *cell_S, const pl_opts_t *o, pl_handle *out) {
   if (!cell_nodes || !S || !cell_S || !o || !out) return fail(PL_ERR_ARG, "pl_create_ddm: null argument");
+  if (int rc_abi = check_opts_abi(o, "pl_create_ddm")) return rc_abi;
   if (n_nodes <= 0 || n_cells <= 0 || nb <= 0 || n_S <= 0) return fail(PL_ERR_ARG, "pl_create_ddm: empty problem");
   if (6 * nb > pl::kDdmMaxM) return fail(PL_ERR_ARG, "pl_create_ddm: more than 27 boundary nodes per cell");
   int ndev = 0;
@@ -867,17 +888,20 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_solve: call pl_assemble first");
   if (!h->have_bc) return fail(PL_ERR_STATE, "pl_solve: call pl_set_bc first");
   if (!(rtol > 0.0) || max_iter <= 0) return fail(PL_ERR_ARG, "pl_solve: rtol and max_iter must be positive");
+  if (stats && stats->struct_size != sizeof(pl_stats_t))
+    return fail(PL_ERR_ARG, "pl_solve: stats->struct_size is " + std::to_string(stats->struct_size) + ", this library's pl_stats_t has " +
+                                std::to_string(sizeof(pl_stats_t)) + " bytes (set it to sizeof(pl_stats_t) before the call)");
   PL_HIP(hipSetDevice(h->opt.device));
   const int64_t n6 = h->N * 6;
   pl_stats_t st{};
+  st.struct_size = (uint32_t)sizeof(pl_stats_t);
   PL_HIP(hipEventRecord(h->ev0, h->stream));
   // lifting: tmp = K ubar (ubar is zero on free dofs)
   int rc = launch_spmv(h, h->ubar.p, h->tmp.p, false, nullptr);
   if (rc) return rc;
   // fp32 solver modes need the multi-level preconditioner on the tile kernel; anything else runs the fp64 PCG
-  const bool mp = h->opt.precision != 0 && h->opkind == 0 && h->coarse.ready && choose_kernel(h) == 3 && h->tile.ready;
-  h->cond_use = h->cond_ready && h->coarse.ready && h->opkind == 0 && choose_kernel(h) == 3 && h->tile.ready &&
-                (!mp || h->opt.precision == 1) && h->opt.cg_form != 1;
+  const bool mp = mp_applies(h);
+  solver_plan(h);
   const bool cg1 = !mp && cg1_applies(h);
   st.cg_form_used = cg1 ? 1.0 : 0.0;
   if (cg1) rc = pcg_solve_cg1(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
@@ -998,6 +1022,7 @@ int pl_schur(pl_handle h, const int32_t *boundary_nodes, int32_t nb, double rtol
     int rc = pl_set_bc(h, fixed.data(), ubar.data(), nullptr);
     if (rc) return rc;
     pl_stats_t st;
+    st.struct_size = (uint32_t)sizeof(pl_stats_t);
     rc = pl_solve(h, rtol, max_iter, u.data(), &st);
     if (rc) return rc;
     rc = pl_reactions(h, u.data(), R.data());
@@ -1037,6 +1062,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   const int64_t n6 = h->N * 6;
   int rc = ensure_hist(h, reps + 1);
   if (rc) return rc;
+  solver_plan(h);   // which == 3 times the iteration the next pl_solve would run, whatever was called before
   // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (which >= 7 && which <= 9) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp

@@ -23,6 +23,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/pylattice_hip.h"
@@ -53,12 +55,10 @@ struct pl_lattice {
   std::vector<int64_t> cell_beam_ptr, cell_beam_idx, cell_node_ptr, cell_node_idx;
 };
 
-extern "C" {
-
-int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double *cell_size, const double *cell_radii,
-                        int32_t n_geom, int32_t n_tmpl, const double *tmpl, const int32_t *tmpl_type,
-                        pl_lattice **out, pl_lattice_info_t *info) {
-  if (!out || !info || n_cells <= 0 || n_tmpl <= 0 || n_geom <= 0 || !cell_coord || !cell_size || !cell_radii ||
+static int generate_impl(int64_t n_cells, const double *cell_coord, const double *cell_size, const double *cell_radii,
+                         int32_t n_geom, int32_t n_tmpl, const double *tmpl, const int32_t *tmpl_type,
+                         std::unique_ptr<pl_lattice> &L_out, pl_lattice_info_t *info) {
+  if (!info || !info || n_cells <= 0 || n_tmpl <= 0 || n_geom <= 0 || !cell_coord || !cell_size || !cell_radii ||
       !tmpl || !tmpl_type)
     return PL_ERR_ARG;
   Gen g;
@@ -96,7 +96,11 @@ int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double 
     u.erase(std::unique(u.begin(), u.end()), u.end());
   }
   const int64_t S0 = (int64_t)U[0].size(), S1 = (int64_t)U[1].size(), S2 = (int64_t)U[2].size();
-  if ((double)S0 * (double)S1 * (double)S2 > 3.0e9) return PL_ERR_STATE;   // table too large: caller takes the numpy path
+  // The direct-address table costs 4 + 4 bytes per slot (creator + node id).  It pays while the lattice fills a fair share
+  // of it: a regular lattice occupies ~1/20 of its slots at worst (Octet: 4 nodes per cell in a 2x2x2-per-cell grid of
+  // distinct coordinates; graded cell sizes multiply the distinct coordinates).  Beyond 64 slots per created strut end
+  // (or 3e9 slots) the table would be mostly empty - tens of GB for an irregular lattice: the caller takes the numpy path.
+  if ((double)S0 * (double)S1 * (double)S2 > std::min(3.0e9, 64.0 * 2.0 * (double)n_created + 1.0e6)) return PL_ERR_STATE;
   const int64_t T = S0 * S1 * S2;
   auto rank_of = [&](int ax, double v) -> int64_t {
     const auto &u = U[ax];
@@ -135,7 +139,8 @@ int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double 
   for (unsigned w = 0; w < W; ++w) part[w + 1] += part[w];
   const int64_t N = part[W];
   if (N >= (1LL << 31) - 64) return PL_ERR_ARG;
-  pl_lattice *L = new pl_lattice();
+  L_out.reset(new pl_lattice());
+  pl_lattice *L = L_out.get();
   L->node_xyz.resize((size_t)N * 3);
   std::vector<int32_t> node_of_slot((size_t)T);
   parallel_for(W, [&](int64_t wb, int64_t we, unsigned) {
@@ -255,7 +260,26 @@ int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double 
   info->n_cell_beam = (int64_t)L->cell_beam_idx.size();
   info->n_cell_node = (int64_t)L->cell_node_idx.size();
   info->n_created = n_created;
-  *out = L;
+  return PL_OK;
+}
+
+extern "C" {
+
+int pl_generate_lattice(int64_t n_cells, const double *cell_coord, const double *cell_size, const double *cell_radii,
+                        int32_t n_geom, int32_t n_tmpl, const double *tmpl, const int32_t *tmpl_type,
+                        pl_lattice **out, pl_lattice_info_t *info) {
+  if (!out) return PL_ERR_ARG;
+  *out = nullptr;
+  std::unique_ptr<pl_lattice> L;
+  try {   // no C++ exception may cross the C ABI: out of host memory = "declined", the caller falls back to numpy
+    const int rc = generate_impl(n_cells, cell_coord, cell_size, cell_radii, n_geom, n_tmpl, tmpl, tmpl_type, L, info);
+    if (rc != PL_OK) return rc;
+  } catch (const std::bad_alloc &) {
+    return PL_ERR_STATE;
+  } catch (...) {
+    return PL_ERR_STATE;
+  }
+  *out = L.release();
   return PL_OK;
 }
 

@@ -167,7 +167,7 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                     c->scal.p + pl::S_RZ_OLD * pl::kSlots, (const double *)nullptr, c->stream);
     PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
-  if (c->cond_ready && c->coarse.ready) {
+  if (c->cond_use) {   // (decided by solver_plan: never with a K*p kernel that ignores the elimination masks)
     // start from the iterate whose condensed nodes are in equilibrium: x_c = K_cc^-1 r_c, r <- r - K x (rows of the
     // condensed nodes become exactly 0 and stay 0: every later step keeps them in equilibrium)
     // t_c = K_cc^-1 b_c (rows of z, zero elsewhere), r_v -= (K t)_v: the load the eliminated nodes pass on.  Their own
@@ -287,6 +287,17 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
 // ----------------------------------------------------------------------------------------------------------
 // Single-reduction PCG (opts.cg_form = 1; pl_cg1.h): u -> z, w -> Ap, s -> tmp2.
 // ----------------------------------------------------------------------------------------------------------
+// Which solver the next pl_solve runs, decided in ONE place (pl_solve and pl_time_kernel both ask): the fp32 modes and
+// the node elimination need the multi-level preconditioner on the LDS-tile kernel; the elimination is off in the
+// single-reduction form and in precision = 2.  Sets c->cond_use.
+inline bool mp_applies(const pl_context *c) {
+  return c->opt.precision != 0 && c->opkind == 0 && c->coarse.ready && choose_kernel(c) == 3 && c->tile.ready;
+}
+inline void solver_plan(pl_context *c) {
+  const bool mp = mp_applies(c);
+  c->cond_use = c->cond_ready && c->coarse.ready && c->opkind == 0 && choose_kernel(c) == 3 && c->tile.ready &&
+                (!mp || c->opt.precision == 1) && c->opt.cg_form != 1;
+}
 inline bool cg1_applies(const pl_context *c) {
   return c->opt.cg_form == 1 && c->coarse.ready && !c->coarseL.ready && !c->cond_use && c->opt.precision == 0 &&
          c->opkind == 0 && c->tile.ready && choose_kernel(c) == 3;

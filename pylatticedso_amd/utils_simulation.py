@@ -56,8 +56,17 @@ class FullScaleLatticeSimulation:
         closed form on the device (pl_node_mod) the first time one of them is looked at."""
         self.lattice.displacement_vector[:] = self.u
         if self.lattice.is_penalized:
-            dev, u = self.device, self._u_solver
-            self.lattice._node_mod_pending = lambda: dev.node_mod(u)
+            dev, u, lat = self.device, self._u_solver, self.lattice
+            lat._node_mod_pending = lambda: dev.node_mod(u)
+            lat._node_mod_stale = False
+
+            def _device_changes(why, lat=lat):
+                # the back-substitution reads the device's CURRENT records: once radii / segments change or the handle
+                # closes, a pending evaluation would combine the old u with new records (round-2 advisor finding)
+                if getattr(lat, "_node_mod_pending", None) is not None:
+                    lat._node_mod_pending = None
+                    lat._node_mod_stale = why
+            dev._before_change = _device_changes
 
     @property
     def domain(self):

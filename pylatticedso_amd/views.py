@@ -477,13 +477,24 @@ class LatticeViews:
             store = {"tables": t, "displacement_vector": np.zeros((P, 6)), "reaction_force_vector": np.zeros((P, 6)),
                      "applied_force": np.zeros((P, 6)), "fixed_DOF": np.zeros((P, 6), bool)}
             self._node_mod_store = store
+            if getattr(self, "_node_mod_pending", None) is None:
+                self._node_mod_stale = False        # a regenerated lattice has no results yet: zeros, as after __init__
         pending = getattr(self, "_node_mod_pending", None)
+        if pending is None and name == "displacement_vector" and getattr(self, "_node_mod_stale", False):
+            raise RuntimeError("displacements of the penalisation points (node_mod) of the last solve were not fetched before "
+                               f"the device state changed ({self._node_mod_stale}); look at one of them (or call "
+                               "lattice.fetch_node_mod()) right after the solve, or solve again")
         if pending is not None and name == "displacement_vector":
             # first look at a penalisation point after a solve: back-substitute on the device now (B x 12 doubles
             # come back over PCIe - not something every solve should pay for)
             self._node_mod_pending = None
             store[name][:] = pending()[t.pen_strut, t.pen_end]
         return store[name]
+
+    def fetch_node_mod(self):
+        """Evaluate the pending back-substitution of the penalisation points now (optimisation loops that change the
+        radii afterwards and still want the node_mod displacements of this solve)."""
+        return self._node_mod_rows("displacement_vector")
 
     def set_node_mod_displacement(self, per_strut):
         """Store (B, 2, 6) penalisation-point displacements (``HipLattice.node_mod``) in node order."""

@@ -659,6 +659,28 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
     assert its[1] <= its[-1] + 2          # (a few dozen iterations on these small lattices: +-1 is noise)
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_node_elimination_is_off_with_kernels_that_ignore_its_masks(golden_dir, kernel):
+    """Round-2 advisor finding: with an explicit spmv_kernel = 1 / 2 the K*p kernels ignore the elimination masks, so the
+    solve must not run the elimination prologue either (it rewrote r_v -= K_vc K_cc^-1 b_c and never back-substituted:
+    silently wrong whenever an eliminated node carried load).  condense = 1 and a body load on every interior node."""
+    _, L = _sim(golden_dir, "bcc_4x4x4")
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    inside = np.all((lat.node_xyz > 0.0) & (lat.node_xyz < 4.0), axis=1)
+    f[inside, :3] += [1e-3, -2e-3, 5e-4]                 # the cell centres (what gets eliminated on BCC) carry load
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    uref = O.solve_dirichlet(K, L.fixed_DOF, 0.0 * f, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    with _device(L, spmv_kernel=kernel, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=1) as dev:
+        dev.set_bc(L.fixed_DOF, None, f)
+        dev.assemble()
+        assert dev.time_kernel(3, 2) > 0.0               # (the timed iteration is the one the solve runs: no elimination)
+        u, st = dev.solve(rtol=1e-11, max_iter=20000)
+        assert st["converged"] == 1 and st["condensed_nodes"] == 0
+        assert _rel(u, uref) < 1e-8
+
+
 @pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "octet_3x2x2_size",
                                   "bcchybrid1hybrid4_3x2x1_size"])
 def test_single_reduction_pcg_matches_oracle(golden_dir, name):
