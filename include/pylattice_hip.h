@@ -279,6 +279,15 @@ int pl_debug_spd_solve(int device, int32_t n, const double *A, const double *b, 
 /* Size of the opaque RCCL unique id the ranks must share (rank 0 fills it with pl_dist_unique_id). */
 int pl_dist_unique_id_bytes(void);
 int pl_dist_unique_id(void *id_out);
+/* Loopback transport: an id (same size as the RCCL one) that makes pl_dist_init attach the handle to an IN-PROCESS group
+ * instead of an RCCL communicator - `world` handles of one process on one device, every collective of the multi-GPU path
+ * (interface rows, scalar blocks, coarse operator band) summed through device buffers.  Each rank must then be driven by
+ * its own host thread (collective calls meet at a host barrier: pl_dist_init, pl_set_bc on an assembled handle,
+ * pl_assemble, pl_solve, pl_spmv*, pl_reactions, pl_time_kernel), exactly as each rank of an RCCL run is driven by its
+ * own process.  This is how the whole multi-rank solver path runs with world = 2 ... 16 on a one-GPU box (tests/
+ * test_gpu_loopback.py); it also serves to run several sub-domains on one GPU.  A rank that never arrives at a
+ * collective makes the others fail with PL_ERR_HIP after 120 s instead of hanging. */
+int pl_dist_loopback_id(void *id_out);
 /* Attach this handle (one per rank/GPU) to a communicator.  shared_nodes lists, for each node of THIS rank's
  * sub-lattice that also exists on other ranks, its local index and a global id (dense 0..n_shared_global-1);
  * partial forces on those nodes are summed across ranks after every local K*x. */

@@ -1180,6 +1180,11 @@ int pl_dist_unique_id(void *id_out) {
   if (!id_out) return fail(PL_ERR_ARG, "pl_dist_unique_id: null argument");
   return pl::dist_unique_id(id_out) ? fail(PL_ERR_HIP, "ncclGetUniqueId failed") : PL_OK;
 }
+int pl_dist_loopback_id(void *id_out) {
+  if (!id_out) return fail(PL_ERR_ARG, "pl_dist_loopback_id: null argument");
+  pl::dist_loopback_id(id_out);
+  return PL_OK;
+}
 int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const int32_t *shared_local,
                  const int32_t *shared_global, int32_t n_shared, int32_t n_shared_global) {
   if (!valid(h) || !unique_id || world < 1 || rank < 0 || rank >= world || n_shared < 0)
@@ -1194,7 +1199,10 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   }
   int rc = pl::dist_init(h->dist, rank, world, unique_id, loc.data(), shared_global, n_shared, n_shared_global, h->N,
                          h->stream);
-  if (rc) return fail(PL_ERR_HIP, "pl_dist_init: RCCL communicator setup failed (" + std::to_string(rc) + ")");
+  if (rc == 6)
+    return fail(PL_ERR_ARG, "pl_dist_init: loopback group mismatch (all ranks of a loopback id must share one device and one "
+                            "world size <= " + std::to_string(pl::kLoopMaxWorld) + ", each rank attaches once)");
+  if (rc) return fail(PL_ERR_HIP, "pl_dist_init: communicator setup failed (" + std::to_string(rc) + ")");
   if (h->coarse.enabled) {   // the tile level and the rank-local dense level leave shared nodes out
     std::vector<uint8_t> sh((size_t)h->N, 0);
     for (int i = 0; i < n_shared; ++i) sh[loc[i]] = 1;

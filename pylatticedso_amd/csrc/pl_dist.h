@@ -9,13 +9,83 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
 #include "pl_kernels.h"
 
 namespace pl {
+
+// ---- loopback transport -----------------------------------------------------------------------------------------
+// R handles of ONE process on ONE device form a communicator without RCCL: every collective of pl_dist.h has a second
+// implementation in which the ranks' contributions meet in device buffers.  The solver code above it is the same -
+// pack kernels, weights, coarse band, single-reduction form, node elimination - so the whole multi-rank path runs (and is
+// tested) with world = 2, 4, 8 on a one-GPU box, each rank driven by its own host thread exactly as each rank of an
+// RCCL run is driven by its own process.  (It is also a way to run several sub-domains on one GPU.)
+//
+// One collective, seen from rank r (n = this rank's count of collectives so far, p = n & 1):
+//   wait (stream) for done[p][q] of every rank q      - buffers of parity p were last read in collective n - 2
+//   publish: write own contribution into own buffer of parity p, record ready[p][r]
+//   HOST barrier of the R threads                     - every ready[p][q] of THIS collective is now recorded
+//   wait (stream) for ready[p][q] of every q, combine (sum in rank order: the same bits on every rank), record done[p][r]
+// Parity double-buffering makes one barrier per collective enough: a rank can only be one collective ahead of the
+// slowest one, so an event or buffer of parity p is never re-used before everybody has queued its reads of it.
+constexpr int kLoopMaxWorld = 16;
+struct LoopPtrs {
+  const double *p[kLoopMaxWorld];
+};
+__global__ void k_loop_sum(int world, LoopPtrs src, int64_t n, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc = src.p[0][i];
+  for (int q = 1; q < world; ++q) acc += src.p[q][i];
+  out[i] = acc;
+}
+
+struct LoopGroup {
+  int world = 0, device = -1, attached = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool broken = false;
+  hipEvent_t ready[2][kLoopMaxWorld] = {}, done[2][kLoopMaxWorld] = {};
+  const double *stage[2][kLoopMaxWorld] = {};                  // published all-reduce contributions
+  const double *send[2][kLoopMaxWorld][kLoopMaxWorld] = {};    // published neighbour messages [parity][from][to]
+  // all ranks arrive or the group is declared broken (a rank that failed elsewhere never arrives: no hang, an error)
+  bool barrier(double timeout_s = 120.0) {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || broken; });
+    if (!ok || broken) {
+      broken = true;
+      cv.notify_all();
+      return false;
+    }
+    return true;
+  }
+};
+inline std::mutex &loop_registry_mutex() {
+  static std::mutex m;
+  return m;
+}
+inline std::map<uint64_t, LoopGroup *> &loop_registry() {
+  static std::map<uint64_t, LoopGroup *> r;
+  return r;
+}
+constexpr char kLoopMagic[8] = {'P', 'L', 'L', 'O', 'O', 'P', 'v', '1'};
 
 template <typename T>
 struct DBuf {
@@ -35,12 +105,20 @@ struct Peer {
   int32_t n = 0;
   DBuf<int32_t> loc;
   DBuf<double> send, recv;
+  DBuf<double> send2;      // loopback transport: the message buffer of odd collectives
 };
 
 struct Dist {
   bool active = false;
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
+  // loopback transport (see above): non-null instead of comm
+  LoopGroup *loop = nullptr;
+  uint64_t loop_key = 0;
+  uint64_t loop_ops = 0;                   // collectives this rank has queued (all ranks count alike)
+  double *loop_stage[2] = {nullptr, nullptr};
+  size_t loop_cap[2] = {0, 0};
+  std::vector<double *> loop_garbage;      // outgrown staging buffers: other ranks may still read them, freed at the end
   // interface rows by grouped ncclSend / ncclRecv with the (at most two) neighbouring slabs instead of an all-reduce
   // over ALL interface planes (pl_dist_set_peers): at N ranks the all-reduce carries N - 1 planes to everyone, each
   // rank needs two
@@ -100,6 +178,65 @@ inline int dist_unique_id(void *out) {
   return 0;
 }
 
+// A loopback "unique id": magic + serial number; pl_dist_init recognises it and attaches the handle to the in-process
+// group of that number instead of an RCCL communicator.
+inline void dist_loopback_id(void *out) {
+  static uint64_t serial = 0;
+  std::memset(out, 0, sizeof(ncclUniqueId));
+  std::memcpy(out, kLoopMagic, 8);
+  uint64_t key;
+  {
+    std::lock_guard<std::mutex> lk(loop_registry_mutex());
+    key = ++serial;
+  }
+  std::memcpy(static_cast<char *>(out) + 8, &key, sizeof(key));
+}
+inline bool dist_is_loopback_id(const void *uid) { return std::memcmp(uid, kLoopMagic, 8) == 0; }
+
+// ---- loopback collectives ------------------------------------------------------------------------------------------
+// begin: the stream waits until every rank has finished reading the parity-p buffers of two collectives ago
+inline int loop_begin(Dist &d, hipStream_t s, int &p) {
+  LoopGroup &g = *d.loop;
+  p = (int)(d.loop_ops & 1);
+  if (d.loop_ops >= 2)
+    for (int q = 0; q < g.world; ++q)
+      if (hipStreamWaitEvent(s, g.done[p][q], 0) != hipSuccess) return 1;
+  return 0;
+}
+// middle: own contribution is queued -> ready; meet the other ranks; wait for theirs
+inline int loop_meet(Dist &d, hipStream_t s, int p) {
+  LoopGroup &g = *d.loop;
+  if (hipEventRecord(g.ready[p][d.rank], s) != hipSuccess) return 1;
+  if (!g.barrier()) return 3;
+  for (int q = 0; q < g.world; ++q)
+    if (q != d.rank && hipStreamWaitEvent(s, g.ready[p][q], 0) != hipSuccess) return 1;
+  return 0;
+}
+inline int loop_end(Dist &d, hipStream_t s, int p) {
+  if (hipEventRecord(d.loop->done[p][d.rank], s) != hipSuccess) return 1;
+  ++d.loop_ops;
+  return 0;
+}
+inline int loop_allreduce(Dist &d, double *buf, size_t count, hipStream_t s) {
+  LoopGroup &g = *d.loop;
+  int p = 0;
+  if (loop_begin(d, s, p)) return 1;
+  if (d.loop_cap[p] < count) {   // grow-only; the old buffer may still be read by a slower rank: keep it until the end
+    if (d.loop_stage[p]) d.loop_garbage.push_back(d.loop_stage[p]);
+    d.loop_stage[p] = nullptr;
+    const size_t cap = std::max<size_t>(count + count / 4, 1024);
+    if (hipMalloc(reinterpret_cast<void **>(&d.loop_stage[p]), cap * sizeof(double)) != hipSuccess) return 2;
+    d.loop_cap[p] = cap;
+  }
+  if (hipMemcpyAsync(d.loop_stage[p], buf, count * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+  g.stage[p][d.rank] = d.loop_stage[p];      // (published under the barrier's mutex ordering)
+  if (int rc = loop_meet(d, s, p)) return rc;
+  LoopPtrs src;
+  for (int q = 0; q < g.world; ++q) src.p[q] = g.stage[p][q];
+  hipLaunchKernelGGL(k_loop_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, g.world, src, (int64_t)count, buf);
+  return loop_end(d, s, p);
+}
+
 template <typename VT>
 __global__ void k_pack_rows(int32_t n, const int32_t *__restrict__ loc, const VT *__restrict__ y,
                             double *__restrict__ out) {
@@ -120,6 +257,23 @@ __global__ void k_add_rows(int32_t n, const int32_t *__restrict__ loc, const dou
 // what it receives.  All sends and receives of one call form ONE RCCL group (they progress concurrently).
 template <typename VT>
 inline int dist_exchange_p2p(Dist &d, VT *y, hipStream_t s) {
+  if (d.loop) {   // loopback: pack into this collective's message buffers, meet, add straight from the neighbours' buffers
+    LoopGroup &g = *d.loop;
+    int p = 0;
+    if (loop_begin(d, s, p)) return 2;
+    for (Peer *q : d.peers) {
+      double *msg = p ? q->send2.p : q->send.p;
+      if (q->n > 0)
+        hipLaunchKernelGGL(k_pack_rows<VT>, dim3((unsigned)((q->n * 6 + 255) / 256)), dim3(256), 0, s, q->n, q->loc.p, y, msg);
+      g.send[p][d.rank][q->rank] = msg;
+    }
+    if (loop_meet(d, s, p)) return 2;
+    for (Peer *q : d.peers)
+      if (q->n > 0)
+        hipLaunchKernelGGL(k_add_rows<VT>, dim3((unsigned)((q->n * 6 + 255) / 256)), dim3(256), 0, s, q->n, q->loc.p,
+                           g.send[p][q->rank][d.rank], y);
+    return loop_end(d, s, p) ? 2 : 0;
+  }
   for (Peer *q : d.peers)
     if (q->n > 0)
       hipLaunchKernelGGL(k_pack_rows<VT>, dim3((unsigned)((q->n * 6 + 255) / 256)), dim3(256), 0, s, q->n, q->loc.p, y,
@@ -138,6 +292,13 @@ inline int dist_exchange_p2p(Dist &d, VT *y, hipStream_t s) {
   return 0;
 }
 
+// in-place sum over ranks of `count` device doubles: RCCL all-reduce, or the loopback transport
+inline int dist_allreduce(Dist &d, double *buf, size_t count, hipStream_t s) {
+  if (count == 0) return 0;
+  if (d.loop) return loop_allreduce(d, buf, count, s);
+  return ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, d.comm, s) == ncclSuccess ? 0 : 1;
+}
+
 // y[shared] <- sum over ranks of y[shared]; optionally `nscal` device scalars (e.g. the 32 slots of a LOCAL partial
 // dot product) ride in the tail of the same message and are summed over ranks too: ONE collective, one kernel
 // before it and one after.
@@ -147,8 +308,7 @@ inline int dist_sum_shared(Dist &d, VT *y, hipStream_t s, double *scal = nullptr
   if (!d.active) return 0;
   if (d.p2p) {   // rows with the neighbours; the scalar tail needs a (tiny) all-reduce of its own
     if (dist_exchange_p2p<VT>(d, y, s)) return 2;
-    if (scal && nscal > 0 && ncclAllReduce(scal, scal, (size_t)nscal, ncclDouble, ncclSum, d.comm, s) != ncclSuccess)
-      return 2;
+    if (scal && nscal > 0 && dist_allreduce(d, scal, (size_t)nscal, s)) return 2;
     return 0;
   }
   const int64_t nrow = (int64_t)d.n_shared_global * 6;
@@ -157,7 +317,7 @@ inline int dist_sum_shared(Dist &d, VT *y, hipStream_t s, double *scal = nullptr
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_pack_message<VT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nrow, d.slot2loc.p, y, scal,
                      nscal, d.pack.p);
-  if (ncclAllReduce(d.pack.p, d.pack.p, (size_t)n, ncclDouble, ncclSum, d.comm, s) != ncclSuccess) return 2;
+  if (dist_allreduce(d, d.pack.p, (size_t)n, s)) return 2;
   const int64_t m = (int64_t)d.n_shared * 6 + nscal;
   if (m > 0)
     hipLaunchKernelGGL(k_unpack_message<VT>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d.n_shared,
@@ -167,14 +327,39 @@ inline int dist_sum_shared(Dist &d, VT *y, hipStream_t s, double *scal = nullptr
 
 inline int dist_sum_scalars(Dist &d, double *dev, int count, hipStream_t s) {
   if (!d.active) return 0;
-  return ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, d.comm, s) == ncclSuccess ? 0 : 1;
+  return dist_allreduce(d, dev, (size_t)count, s);
 }
 
 inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_t *loc, const int32_t *glob,
                      int32_t n_shared, int32_t n_shared_global, int64_t N, hipStream_t s) {
-  ncclUniqueId id;
-  std::memcpy(&id, uid, sizeof(id));
-  if (ncclCommInitRank(&d.comm, world, id, rank) != ncclSuccess) return 1;
+  if (dist_is_loopback_id(uid)) {
+    if (world > kLoopMaxWorld) return 6;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    uint64_t key = 0;
+    std::memcpy(&key, static_cast<const char *>(uid) + 8, sizeof(key));
+    std::lock_guard<std::mutex> lk(loop_registry_mutex());
+    LoopGroup *&g = loop_registry()[key];
+    if (!g) {
+      g = new LoopGroup();
+      g->world = world;
+      g->device = dev;
+      for (int p = 0; p < 2; ++p)
+        for (int q = 0; q < world; ++q)
+          if (hipEventCreateWithFlags(&g->ready[p][q], hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&g->done[p][q], hipEventDisableTiming) != hipSuccess)
+            return 1;
+    }
+    if (g->world != world || g->device != dev || g->attached >= world) return 6;   // one device, world ranks, once each
+    ++g->attached;
+    d.loop = g;
+    d.loop_key = key;
+    d.loop_ops = 0;
+  } else {
+    ncclUniqueId id;
+    std::memcpy(&id, uid, sizeof(id));
+    if (ncclCommInitRank(&d.comm, world, id, rank) != ncclSuccess) return 1;
+  }
   d.rank = rank;
   d.world = world;
   d.n_shared = n_shared;
@@ -229,6 +414,7 @@ inline int dist_set_peers(Dist &d, const int32_t *peer) {
     if (q->loc.alloc(std::max<size_t>(1, loc.size())) != hipSuccess) return 3;
     if (q->send.alloc(std::max<size_t>(1, loc.size() * 6)) != hipSuccess) return 3;
     if (q->recv.alloc(std::max<size_t>(1, loc.size() * 6)) != hipSuccess) return 3;
+    if (d.loop && q->send2.alloc(std::max<size_t>(1, loc.size() * 6)) != hipSuccess) return 3;
     if (!loc.empty() &&
         hipMemcpy(q->loc.p, loc.data(), loc.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
       return 3;
@@ -240,6 +426,35 @@ inline int dist_set_peers(Dist &d, const int32_t *peer) {
 inline void dist_destroy(Dist &d) {
   if (d.comm) (void)ncclCommDestroy(d.comm);
   d.comm = nullptr;
+  if (d.loop) {
+    // the caller has drained this rank's stream; other ranks may still be reading our buffers in kernels they have
+    // queued: wait for the device before freeing anything they could touch
+    (void)hipDeviceSynchronize();
+    for (double *b : d.loop_garbage) (void)hipFree(b);
+    d.loop_garbage.clear();
+    for (int p = 0; p < 2; ++p) {
+      if (d.loop_stage[p]) (void)hipFree(d.loop_stage[p]);
+      d.loop_stage[p] = nullptr;
+      d.loop_cap[p] = 0;
+    }
+    std::lock_guard<std::mutex> lk(loop_registry_mutex());
+    LoopGroup *g = d.loop;
+    {
+      std::lock_guard<std::mutex> lg(g->m);
+      g->broken = true;             // a group that lost a rank cannot run another collective
+      g->cv.notify_all();
+    }
+    if (--g->attached == 0) {
+      for (int p = 0; p < 2; ++p)
+        for (int q = 0; q < g->world; ++q) {
+          if (g->ready[p][q]) (void)hipEventDestroy(g->ready[p][q]);
+          if (g->done[p][q]) (void)hipEventDestroy(g->done[p][q]);
+        }
+      loop_registry().erase(d.loop_key);
+      delete g;
+    }
+    d.loop = nullptr;
+  }
   d.active = false;
 }
 

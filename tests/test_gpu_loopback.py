@@ -1,0 +1,138 @@
+"""The multi-rank solver path of libpylattice_hip with world = 2 / 4 / 8 on ONE GPU (loopback transport,
+pylatticedso_amd/loopback.py): the same pack / exchange / weight / coarse-band / single-reduction / node-elimination
+device code an RCCL run executes, one host thread per rank, contributions summed through device buffers.  Every case is
+held to the single-handle solve of the un-partitioned lattice (which tests/test_gpu_parity.py holds to the oracle):
+1e-8 relative L2 on displacements, written at each assert."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from pylatticedso_amd import _capi                      # noqa: E402
+from pylatticedso_amd.loopback import LoopbackGroup, whole_lattice   # noqa: E402
+
+E, NU = 1013.0, 0.3
+LATTICES = {"octet16": ((16, 16, 16), ["Octet"], [0.03]), "bcc12": ((12, 12, 12), ["BCC"], [0.05])}
+SMALL = dict(tile_nodes=32, coarse_max_dofs=600)
+_cache = {}
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _reference(name):
+    """Single-handle solve of the whole lattice (cantilever of bench.py), once per lattice."""
+    if name not in _cache:
+        cells, geom, radii = LATTICES[name]
+        lat, pen = whole_lattice((1, 1, 1), cells, geom, radii)
+        fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+        fixed[lat.node_xyz[:, 0] == 0.0] = 1
+        tgt = lat.node_xyz[:, 0] == float(cells[0])
+        f = np.zeros((lat.n_nodes, 6))
+        f[tgt, 2] = -0.1 / tgt.sum()
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, condense=-1, **SMALL) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            x = np.random.default_rng(7).standard_normal((lat.n_nodes, 6))
+            y = dev.spmv_free(x)
+        assert st["converged"] == 1
+        _cache[name] = (lat, u, st["iterations"], x, y)
+    return _cache[name]
+
+
+def _group(name, world, axis, **kw):
+    cells, geom, radii = LATTICES[name]
+    opts = dict(SMALL)
+    opts.update(kw)
+    return LoopbackGroup((1, 1, 1), cells, geom, radii, world, axis=axis, young=E, poisson=NU, **opts)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name", ["octet16", "bcc12"])
+@pytest.mark.parametrize("p2p", [True, False])
+def test_partitioned_operator_equals_the_whole(name, world, p2p):
+    """P K P x on R slabs (interface rows by neighbour exchange or by the all-planes all-reduce) = the single handle's."""
+    lat, _, _, x, y = _reference(name)
+    with _group(name, world, axis=0, precond=1, condense=-1, p2p=p2p) as g:
+        fixed, f = g.cantilever(float(g.num_cells[0]))
+        g.set_bc(fixed, None, f)
+        g.assemble()
+        yr = g.spmv_free(g.scatter(lat.node_xyz, x))
+        assert _rel(g.gather(lat.node_xyz, yr), y) < 1e-13
+
+
+CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dict(precond=1),
+         "cg_form1": dict(precond=3, cg_form=1), "precision1": dict(precond=3, precision=1),
+         "precond4_precision1": dict(precond=4, precision=1), "precision2": dict(precond=3, precision=2)}
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name", ["octet16", "bcc12"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_partitioned_solve_equals_single_handle(name, world, case):
+    lat, u0, it0, _, _ = _reference(name)
+    with _group(name, world, axis=0, condense=-1, **CASES[case]) as g:
+        fixed, f = g.cantilever(float(g.num_cells[0]))
+        g.set_bc(fixed, None, f)
+        g.assemble()
+        res = g.solve(rtol=1e-11, max_iter=20000)
+        stats = [st for _, st in res]
+        assert all(st["converged"] == 1 for st in stats)
+        # every rank sees the same all-reduced history: same decisions, same counts
+        assert len({st["iterations"] for st in stats}) == 1 and len({st["rel_residual"] for st in stats}) == 1
+        u = g.gather(lat.node_xyz, [u for u, _ in res])        # (also checks that copies of shared nodes agree)
+        assert _rel(u, u0) < 1e-8
+        if case == "cg_form1":
+            assert all(int(st["cg_form_used"]) == 1 for st in stats)
+        if case.startswith("precision") or case.endswith("precision1"):
+            assert all(int(st["precision_used"]) == CASES[case]["precision"] for st in stats)
+        if case != "jacobi":
+            # the multi-level preconditioner survives the partition: the levels leave out shared nodes and the dense level
+            # coarsens, which costs iterations - but nowhere near the Jacobi count
+            assert stats[0]["iterations"] < 2.5 * it0
+        # a second solve on the same handles (new right-hand side: pl_set_bc on assembled handles is collective too)
+        g.set_bc(fixed, None, [2.0 * ff for ff in f])
+        res2 = g.solve(rtol=1e-11, max_iter=20000)
+        assert _rel(g.gather(lat.node_xyz, [u for u, _ in res2]), 2.0 * u0) < 1e-8
+
+
+@pytest.mark.parametrize("axis", [1, 2])
+def test_partition_axis(axis):
+    """Slabs along y and z (bench.py's weak-scaling layout is along y)."""
+    lat, u0, _, _, _ = _reference("octet16")
+    with _group("octet16", 4, axis=axis, precond=3, condense=-1) as g:
+        fixed, f = g.cantilever(16.0)
+        g.set_bc(fixed, None, f)
+        g.assemble()
+        res = g.solve(rtol=1e-11, max_iter=20000)
+        assert _rel(g.gather(lat.node_xyz, [u for u, _ in res]), u0) < 1e-8
+
+
+def test_missing_rank_is_an_error_not_a_hang():
+    """A collective that one rank never joins: the group is broken when that rank's handle goes away and the others
+    return PL_ERR_HIP instead of waiting for ever."""
+    import threading
+    g = _group("bcc12", 2, axis=0, precond=1, condense=-1)
+    try:
+        fixed, f = g.cantilever(12.0)
+        g.set_bc(fixed, None, f)
+        err = []
+
+        def lonely():
+            try:
+                g.devs[0].assemble()          # collective: rank 1 never calls it
+            except _capi.PlError as e:
+                err.append(e)
+        t = threading.Thread(target=lonely)
+        t.start()
+        import time
+        time.sleep(1.0)
+        g.devs[1].close()                     # breaks the group: rank 0's barrier returns
+        g.devs[1] = None
+        t.join(timeout=30.0)
+        assert not t.is_alive() and len(err) == 1 and err[0].code == _capi.PL_ERR_HIP
+    finally:
+        g.close()
