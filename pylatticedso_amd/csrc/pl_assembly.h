@@ -272,9 +272,11 @@ inline const uint16_t *ccls(const pl_context *c) { return c->cls_ready ? c->cls_
 int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   c->cond_ready = false;
   c->n_cond = 0;
-  // (single-GPU handles only for now: the two passes of the condensed operator would each need the interface exchange)
+  c->cond_agree = -1;
+  // (several GPUs: nodes shared with another rank stay unknowns - an eliminated node then has all its struts on this
+  // rank, its 6 x 6 block and the first pass of the condensed operator are complete locally, pl_ops.h)
   const bool wanted = c->opt.condense >= 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision != 2 &&
-                      !c->h_cand.empty() && !c->dist.active;
+                      !c->h_cand.empty();
   if (!wanted) return PL_OK;
   const int64_t N = c->N;
   std::vector<int32_t> picked;
@@ -305,10 +307,30 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   c->n_cond = (int64_t)picked.size();
   return PL_OK;
 }
+// Several GPUs: a solve with node elimination has one exchange more (its prologue) than a solve without, so either every
+// rank eliminates or none does.  One 1-double all-reduce after a pl_set_bc (main stream; collective - every rank of a
+// handle with these options calls it at the same point of pl_assemble / pl_set_bc).
+int agree_condensed(pl_context *c) {
+  if (!c->dist.active || c->cond_agree != -1) return PL_OK;
+  const bool asked = c->opt.condense >= 0 && c->opkind == 0 && c->coarse.enabled && c->opt.precision != 2;
+  if (!asked) {   // (options are the same on every rank: nobody has candidates, nobody calls the collective)
+    c->cond_agree = 0;
+    return PL_OK;
+  }
+  double *slot = c->scal.p + pl::S_AUX * pl::kSlots;
+  double v = c->n_cond > 0 ? 0.0 : 1.0;
+  PL_HIP(hipMemcpyAsync(slot, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (pl::dist_sum_scalars(c->dist, slot, 1, c->stream)) return fail(PL_ERR_HIP, "all-reduce of the node-elimination vote failed");
+  PL_HIP(hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  c->cond_agree = (v == 0.0) ? 1 : 0;
+  return PL_OK;
+}
 // K_cc^-1 of the condensed nodes from the current records (after launch_records, same stream)
 int launch_condensed_blocks(pl_context *c, hipStream_t st) {
   c->cond_ready = false;
   if (c->n_cond <= 0 || !c->have_bc) return PL_OK;
+  if (c->dist.active && c->cond_agree != 1) return PL_OK;
   hipLaunchKernelGGL(pl::k_node_block_inverse, dim3(grid_for(c->n_cond)), dim3(pl::kBlock), 0, st, c->n_cond,
                      c->cnodes.p, pl::kWave / c->lpn, c->slice_ptr.p, c->ent.p, c->rec.p, c->kcc_inv.p);
   PL_HIP(hipGetLastError());

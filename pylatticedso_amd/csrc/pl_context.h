@@ -171,6 +171,8 @@ struct pl_context {
   int64_t n_cond = 0;
   bool cond_ready = false;   // K_cc^-1 valid for the current records and mask
   bool cond_use = false;     // the running solve eliminates them (fp64 PCG and precision = 1)
+  int cond_agree = -1;       // several GPUs: every rank has nodes to eliminate (1) / some rank has none, so nobody does (0) /
+                             // not yet agreed since the last pl_set_bc (-1): the solver's collectives must match on all ranks
   // multi-GPU
   pl::Dist dist;
 

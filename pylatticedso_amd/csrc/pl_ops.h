@@ -71,6 +71,19 @@ inline pl::CondSolve cond_solve(pl_context *c, int ends) {
   return cs;
 }
 
+// Several GPUs: every rank holds the product of ITS struts.  The Dirichlet mask commutes with the sum over ranks, and
+// x.(K x) = sum_r x_r.(K_r x_r) with the LOCAL partial products and NO multiplicity weights, so the K*x kernels run
+// exactly as on one GPU; the interface rows and the slots of the partial dot then travel in one exchange.
+// (reduce_dot = false: the caller sums the dot slots in a collective of its own - single-reduction PCG)
+template <typename VT>
+int spmv_interface_sum(pl_context *c, VT *y, double *dot_dev, bool reduce_dot = true) {
+  if (!c->dist.active) return PL_OK;
+  const bool with_dot = dot_dev && reduce_dot;
+  int rc = pl::dist_sum_shared<VT>(c->dist, y, c->stream, with_dot ? dot_dev : nullptr, with_dot ? pl::kSlots : 0);
+  if (rc) return fail(PL_ERR_HIP, "exchange of the interface forces failed (" + std::to_string(rc) + ")");
+  return PL_OK;
+}
+
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
                 const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll, bool reduce_dot = true) {
   const int kind = choose_kernel(c);
@@ -88,6 +101,10 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
       pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
                            (const double *)nullptr, ends, cf, cs);
     PL_HIP(hipGetLastError());
+    // Several GPUs: an eliminated node is never shared with another rank, so all its struts are this rank's and the passes
+    // that accumulate ONLY the strut ends at eliminated nodes (kEndsCondensed / kEndsCondensedSolve) are complete locally;
+    // the pass over the other ends is an ordinary partial product and takes the interface exchange.
+    if (ends == pl::kEndsAll || ends == pl::kEndsOthers) return spmv_interface_sum(c, y, dot_dev, reduce_dot);
     return PL_OK;
   }
   const int64_t n6 = c->N * 6;
@@ -138,17 +155,8 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     int rc = dispatch_gather(c, x, y, masked, dot_dev);
     if (rc) return rc;
   }
-  if (c->dist.active) {
-    // Every rank now holds the product of ITS struts.  The Dirichlet mask commutes with the sum over ranks, and
-    // x.(K x) = sum_r x_r.(K_r x_r) with the LOCAL partial products and NO multiplicity weights, so the kernels above
-    // ran exactly as on one GPU; the interface rows and the 32 slots of the partial dot travel in one all-reduce.
-    // (reduce_dot = false: the caller sums the dot slots in a collective of its own - single-reduction PCG)
-    const bool with_dot = dot_dev && reduce_dot;
-    int rc = pl::dist_sum_shared(c->dist, y, c->stream, with_dot ? dot_dev : nullptr, with_dot ? pl::kSlots : 0);
-    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
-  }
   PL_HIP(hipGetLastError());
-  return PL_OK;
+  return spmv_interface_sum(c, y, dot_dev, reduce_dot);
 }
 
 // K*p of the fp32 solver modes: tile kernel only, fp32-stored x / y, fp64 arithmetic (pl_tile.h)
@@ -166,11 +174,8 @@ int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double
   else
     pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, mk, x, y, dot_dev, c->stream,
                                 (const double *)nullptr, ends, cf, cs);
-  if (c->dist.active) {
-    int rc = pl::dist_sum_shared<float>(c->dist, y, c->stream, dot_dev, dot_dev ? pl::kSlots : 0);
-    if (rc) return fail(PL_ERR_HIP, "RCCL all-reduce of interface forces failed");
-  }
   PL_HIP(hipGetLastError());
+  if (ends == pl::kEndsAll || ends == pl::kEndsOthers) return spmv_interface_sum<float>(c, y, dot_dev);
   return PL_OK;
 }
 

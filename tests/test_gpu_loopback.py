@@ -43,6 +43,28 @@ def _reference(name):
     return _cache[name]
 
 
+def _body_load_reference(name):
+    """The cantilever plus a small load on every node that carries none (single handle, no elimination)."""
+    key = name + ":body"
+    if key not in _cache:
+        cells, geom, radii = LATTICES[name]
+        lat, pen = whole_lattice((1, 1, 1), cells, geom, radii)
+        fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+        fixed[lat.node_xyz[:, 0] == 0.0] = 1
+        tgt = lat.node_xyz[:, 0] == float(cells[0])
+        f = np.zeros((lat.n_nodes, 6))
+        f[tgt, 2] = -0.1 / tgt.sum()
+        f = f + np.array([1e-5, -2e-5, 5e-6, 0, 0, 0]) * (f[:, 2:3] == 0.0)
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, condense=-1, **SMALL) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+        assert st["converged"] == 1
+        _cache[key] = u
+    return _cache[key]
+
+
 def _group(name, world, axis, **kw):
     cells, geom, radii = LATTICES[name]
     opts = dict(SMALL)
@@ -66,7 +88,10 @@ def test_partitioned_operator_equals_the_whole(name, world, p2p):
 
 CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dict(precond=1),
          "cg_form1": dict(precond=3, cg_form=1), "precision1": dict(precond=3, precision=1),
-         "precond4_precision1": dict(precond=4, precision=1), "precision2": dict(precond=3, precision=2)}
+         "precond4_precision1": dict(precond=4, precision=1), "precision2": dict(precond=3, precision=2),
+         # node elimination on multi-rank handles (nodes shared with another rank stay unknowns)
+         "condense": dict(precond=3, condense=1), "condense_precision1": dict(precond=3, condense=1, precision=1),
+         "condense_precond4": dict(precond=4, condense=1)}
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -74,8 +99,12 @@ CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dic
 @pytest.mark.parametrize("case", list(CASES))
 def test_partitioned_solve_equals_single_handle(name, world, case):
     lat, u0, it0, _, _ = _reference(name)
-    with _group(name, world, axis=0, condense=-1, **CASES[case]) as g:
+    opts = dict(condense=-1)
+    opts.update(CASES[case])
+    with _group(name, world, axis=0, **opts) as g:
         fixed, f = g.cantilever(float(g.num_cells[0]))
+        if case.startswith("condense"):        # a body load, so that eliminated nodes carry load as well
+            f = [ff + np.array([1e-5, -2e-5, 5e-6, 0, 0, 0]) * (ff[:, 2:3] == 0.0) for ff in f]
         g.set_bc(fixed, None, f)
         g.assemble()
         res = g.solve(rtol=1e-11, max_iter=20000)
@@ -84,6 +113,9 @@ def test_partitioned_solve_equals_single_handle(name, world, case):
         # every rank sees the same all-reduced history: same decisions, same counts
         assert len({st["iterations"] for st in stats}) == 1 and len({st["rel_residual"] for st in stats}) == 1
         u = g.gather(lat.node_xyz, [u for u, _ in res])        # (also checks that copies of shared nodes agree)
+        if case.startswith("condense"):
+            u0 = _body_load_reference(name)
+            assert all(st["condensed_nodes"] > 0 for st in stats)
         assert _rel(u, u0) < 1e-8
         if case == "cg_form1":
             assert all(int(st["cg_form_used"]) == 1 for st in stats)
@@ -97,6 +129,8 @@ def test_partitioned_solve_equals_single_handle(name, world, case):
         g.set_bc(fixed, None, [2.0 * ff for ff in f])
         res2 = g.solve(rtol=1e-11, max_iter=20000)
         assert _rel(g.gather(lat.node_xyz, [u for u, _ in res2]), 2.0 * u0) < 1e-8
+        if case.startswith("condense"):
+            assert all(st["condensed_nodes"] > 0 for _, st in res2)
 
 
 @pytest.mark.parametrize("axis", [1, 2])
