@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — beams/s of "assembly + PCG solve" on synthetic periodic lattices (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                                  (the driver's N = 1 line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config 2 --loopback 8          (a partitioned configuration rehearsed on ONE GPU, see below)
 
-Workload (BASELINE.json configs[1]): 50x50x50 Octet, r = 0.03, cell size 1, VeroClear,
-joint penalisation on, cantilever (all 6 dofs clamped on Xmin, total force -0.1 in Z on Xmax), fp64.
-For N > 1 GPUs the lattice is 50 x (50 N) x 50 cut into N y-slabs of 50 layers (weak scaling: 3.03 M struts per
-GPU; growing along y keeps the cantilever's aspect ratio, hence its conditioning, fixed); interface forces and
-PCG dot products are all-reduced with RCCL inside libpylattice_hip.
+Workloads (BASELINE.json `configs`; cell size 1, VeroClear, joint penalisation on, cantilever: all
+6 dofs clamped on Xmin, total force -0.1 in Z on Xmax):
+  --config 1 (default)  configs[1]: 50x50x50 Octet, r = 0.03, fp64.  N > 1 GPUs: 50 x (50 N) x 50 cut into N y-slabs
+                        (weak scaling: 3.03 M struts per GPU; growing along y keeps the cantilever's aspect ratio).
+  --config 2            configs[2]: 100x100x100 BCC, r = 0.05, fp64, N x-slabs of the SAME lattice (strong scaling).
+  --config 3            configs[3]: graded-radius 24^3 BCC, 50 objective + adjoint-gradient evaluations, one GPU.
+  --config 4            configs[4]: 200x200x50 BCC + Octet, r = [0.04, 0.03], fp32 inner PCG with fp64 refinement
+                        (opts.precision = 1), N x-slabs (strong scaling).
+Ranks: one process per GPU under torchrun (RCCL inside libpylattice_hip), or --loopback R: R slab handles of THIS process
+on ONE GPU joined by the library's loopback transport (the same multi-rank device code; iteration counts and per-rank
+kernel times of an R-GPU run, on a one-GPU box - the value is then a one-GPU number and says so).
 
-One "step" = per-strut stiffness build (condensed records + Jacobi diagonal + coarse operator of the two-level
+One "step" = per-strut stiffness build (condensed records + Jacobi diagonal + coarse operator of the multi-level
 preconditioner and its dense factorisation) + explicit BSR(6x6) global-K assembly + matrix-free PCG solve to
-||r|| <= rtol ||b|| — all on data already resident in HBM.
-value = struts of the whole job * steps / time.  The roofline object prices the dominant kernel (K*p) with the
-algorithmic bytes of SURVEY.md 8(d) and a HIP-event timing taken on the library's own stream; cpu_baseline is the
-plain-C oracle (oracle/beam_pcg.c) on all host cores, plus the reference-faithful sub-meshed + sparse-LU leg, on
-bounded samples of the same workload; end_to_end_s is the wall clock of the drop-in call site (LatticeSim +
-solve_FEM_FenicsX) for the same lattice.
+||r|| <= rtol ||b|| - all on data already resident in HBM.  value = struts of the whole job * steps / time.  The
+roofline object prices the dominant kernel (K*p) with the algorithmic bytes of SURVEY.md 8(d) and a HIP-event timing
+taken on the library's own stream; cpu_baseline is the plain-C oracle (oracle/beam_pcg.c) on the host cores this job
+may use, plus the reference-faithful sub-meshed + sparse-LU leg, on bounded samples of the same workload; end_to_end_s
+is the wall clock of the drop-in call site (LatticeSim + solve_FEM_FenicsX) for the same lattice.
 """
 import argparse
 import json
@@ -32,6 +38,15 @@ sys.path.insert(0, ROOT)
 
 E, NU = 1013.0, 0.3
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+CONFIGS = {
+    1: dict(cells=(50, 50, 50), geom=["Octet"], radii=[0.03], axis=1, scaling="weak", precision=0, tile_modes=0,
+            name="BASELINE.json configs[1]"),
+    2: dict(cells=(100, 100, 100), geom=["BCC"], radii=[0.05], axis=0, scaling="strong", precision=0, tile_modes=0,
+            name="BASELINE.json configs[2]"),
+    4: dict(cells=(200, 200, 50), geom=["BCC", "Octet"], radii=[0.04, 0.03], axis=0, scaling="strong", precision=1,
+            tile_modes=6, name="BASELINE.json configs[4]"),
+}
 
 
 def log(*a):
@@ -57,9 +72,10 @@ def dev_kernel_name(kernel, reorder):
 
 def cpu_baseline(cells, radius, rtol, splu_cells):
     """CPU legs on the host cores of this box, on bounded samples of the same workload (same lattice type / BCs, fewer
-    cells).  (ii) of SURVEY 8(d): the plain-C oracle - condensed struts, matrix-free Jacobi-PCG - on ALL cores (OpenMP,
-    thread count reported) and on one; (i): the reference-faithful discretisation - every penalised segment sub-meshed
-    like gmsh does, scipy CSR assembly + SuperLU (stand-in for PETSc preonly/lu) - on a size it can finish."""
+    cells).  (ii) of SURVEY 8(d): the plain-C oracle - condensation of every strut + matrix-free Jacobi-PCG - on the
+    CPUs this job may use (OpenMP; affinity mask capped by the cgroup quota) and on one; (i): the reference-faithful
+    discretisation - every penalised segment sub-meshed like gmsh does, scipy CSR assembly + SuperLU (stand-in for PETSc
+    preonly/lu) - on a size it can finish."""
     from oracle import c_oracle, timoshenko_oracle as O
     from pylatticedso_amd import lattice_arrays as LA
     lat = LA.generate((1, 1, 1), (cells,) * 3, ["Octet"], [radius])
@@ -67,20 +83,29 @@ def cpu_baseline(cells, radius, rtol, splu_cells):
     fixed, f, _ = cantilever_bc(lat.node_xyz, float(cells))
     legs = {}
     u = None
+    cpus = c_oracle.available_cpus()
     for name, mt in (("all_cores", True), ("one_core", False)):
+        c_oracle.set_threads(cpus if mt else 1)
         t0 = time.perf_counter()
-        sc = c_oracle.condense_unique(lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU)
+        sc = c_oracle.condense_all(lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU)      # "assembly"
+        t1 = time.perf_counter()
         u, it, rel = c_oracle.pcg(lat.node_xyz, lat.beam_conn, sc, fixed, np.zeros_like(f), f, rtol=rtol, maxit=100000,
                                   all_cores=mt)
-        legs[name] = (lat.n_beams / (time.perf_counter() - t0), time.perf_counter() - t0, abs(it))
-    threads = c_oracle.num_threads()
-    out = {"value": legs["all_cores"][0], "unit": "beams/s", "cores": threads, "kind": "port",
-           "sample": f"{cells}^3 Octet r={radius} cantilever, {lat.n_beams} struts, {legs['all_cores'][2]} Jacobi-PCG "
-                     f"iterations to rtol {rtol:g} in {legs['all_cores'][1]:.1f} s (oracle/beam_pcg.c oracle_pcg_mt, gcc -O2 "
-                     f"-fopenmp, {threads} threads of {os.cpu_count()} host CPUs; the GPU runs a multi-level PCG with "
-                     f"4x fewer iterations - a different preconditioner, see config.preconditioner)",
-           "one_core": {"value": legs["one_core"][0], "unit": "beams/s", "cores": 1,
-                        "sample": f"same sample, oracle_pcg (scatter form), {legs['one_core'][1]:.1f} s"}}
+        t2 = time.perf_counter()
+        legs[name] = dict(rate=lat.n_beams / (t2 - t0), total=t2 - t0, assembly=t1 - t0, its=abs(it))
+    a, o = legs["all_cores"], legs["one_core"]
+    out = {"value": a["rate"], "unit": "beams/s", "cores": cpus, "kind": "port",
+           "sample": f"{cells}^3 Octet r={radius} cantilever, {lat.n_beams} struts: condensation of every strut "
+                     f"{a['assembly']:.2f} s + {a['its']} Jacobi-PCG iterations to rtol {rtol:g} = {a['total']:.1f} s "
+                     f"(oracle/beam_pcg.c oracle_condense_all + oracle_pcg_mt, gcc -O2 -fopenmp, {cpus} threads = the CPUs "
+                     f"this job may use of {os.cpu_count()} on the host; per-node gather form, parallel first touch)",
+           "speedup_over_one_core": a["rate"] / o["rate"],
+           "per_iteration": {"all_cores_beams_per_s": lat.n_beams * a["its"] / (a["total"] - a["assembly"]),
+                             "note": "struts x iterations / solve time: the rate to compare across preconditioners - the "
+                                     "GPU's multi-level PCG needs ~5 x fewer iterations than this Jacobi-PCG "
+                                     "(config.pcg_iterations at 50^3 against its count at this sample size)"},
+           "one_core": {"value": o["rate"], "unit": "beams/s", "cores": 1,
+                        "sample": f"same sample, oracle_pcg (scatter form), {o['total']:.1f} s"}}
     if splu_cells > 0:
         sl = LA.generate((1, 1, 1), (splu_cells,) * 3, ["Octet"], [radius])
         sp_ = LA.penalize(sl, LA.compute_lzone(sl))
@@ -122,13 +147,14 @@ def penalised_segments(lat, pen):
     return xyz, conn, rad
 
 
-def end_to_end(cells, geom, radius, rtol):
+def end_to_end(cells, geom, radii, rtol):
     """What a user of the drop-in call site waits for: LatticeSim(preset) (host lattice build, penalisation, BCs) +
     solve_FEM_FenicsX (pl_create, upload, assembly, solve, reactions, write-back), wall clock, once."""
     from pylatticedso_amd.lattice_sim import LatticeSim
     from pylatticedso_amd.utils_simulation import solve_FEM_FenicsX
-    preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": cells, "y": cells, "z": cells},
-                           "radii": [radius], "geom_types": [geom]},
+    preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1},
+                           "number_of_cells": {"x": cells[0], "y": cells[1], "z": cells[2]},
+                           "radii": list(radii), "geom_types": list(geom)},
               "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False},
               "boundary_conditions": {
                   "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"],
@@ -145,14 +171,70 @@ def end_to_end(cells, geom, radius, rtol):
                     "(includes pl_create, topology upload, reactions, write-back)"}
 
 
+def design_loop(args, local_rank):
+    """configs[3]: graded-radius 24^3 BCC ("gyroid-like" radius field of SURVEY 8d item 4), unit_cell parameterisation,
+    50 evaluations of compliance + its adjoint gradient (self-adjoint: one solve + the per-strut sensitivity pass) with a
+    projected-gradient update of the radii in between - pl_update_radii, pl_assemble, pl_solve, pl_sens per iteration."""
+    from pylatticedso_amd import _capi, lattice_arrays as LA
+    n = args.cells[0] if args.cells else 24
+    iters = 50
+    i3 = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), axis=-1).reshape(-1, 3) + 0.5
+    x, y, z = (2 * np.pi * i3[:, k] / 8 for k in range(3))
+    rc = np.clip(0.05 + 0.03 * (np.sin(x) * np.cos(y) + np.sin(y) * np.cos(z) + np.sin(z) * np.cos(x)) / 1.5, 0.01, 0.1)
+    lat = LA.generate((1, 1, 1), (n, n, n), ["BCC"], [0.05], cell_radii_override=rc.reshape(-1, 1))
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius))
+    fixed, f, _ = cantilever_bc(lat.node_xyz, float(n))
+    cell_of = lat.beam_cell0
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                          device=local_rank, precond=3, palette=1) as dev:
+        dev.set_bc(fixed, None, f)
+        r = rc.copy()
+        its = []
+
+        def evaluate(r):
+            dev.update_radii(r[cell_of])
+            dev.assemble()
+            u, st = dev.solve(rtol=args.rtol, max_iter=args.max_iter)
+            C = float((f * u).sum())
+            g = -np.bincount(cell_of, weights=dev.sens(u), minlength=len(r))     # dC/dr_cell = -u^T dK/dr u
+            its.append(st["iterations"])
+            return C, g
+        for _ in range(args.warmup):
+            evaluate(r)
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        C0 = None
+        for _ in range(iters):
+            C, g = evaluate(r)
+            C0 = C if C0 is None else C0
+            r = np.clip(r - 0.002 * g / max(np.abs(g).max(), 1e-300), 0.01, 0.1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"metric": "beams/s assembly+PCG-solve", "value": lat.n_beams * iters / dt, "unit": "beams/s", "n_gpus": 1,
+            "steps": iters, "warmup": args.warmup, "ms_per_step": dt / iters * 1e3, "higher_is_better": True,
+            "scaling": None, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n}^3 BCC, graded radius per cell ({len(rc)} design variables, unit_cell "
+                                   f"parameterisation), {iters} x (pl_update_radii + assembly + PCG solve + adjoint "
+                                   f"sensitivity pl_sens + projected-gradient step) (BASELINE.json configs[3])",
+                       "struts": lat.n_beams, "pcg_iterations_first_last": [its[args.warmup], its[-1]],
+                       "compliance_first_last": [C0, C], "rtol": args.rtol}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", type=int, default=50, help="cells per edge (per GPU along y)")
-    ap.add_argument("--geom", default="Octet")
-    ap.add_argument("--radius", type=float, default=0.03)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configuration (1 = configs[1], the headline; see the module docstring)")
+    ap.add_argument("--loopback", type=int, default=0,
+                    help="R > 1: run the configuration as R slab handles on ONE GPU through the library's loopback "
+                         "transport (rehearsal of an R-GPU run: same device code, same iteration counts)")
+    ap.add_argument("--cells", type=int, nargs="+", default=None,
+                    help="override the configuration's cells: one number (cube) or three")
+    ap.add_argument("--geom", default=None, help="override the configuration's geometry (comma-separated for hybrids)")
+    ap.add_argument("--radius", type=float, nargs="+", default=None)
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--kernel", type=int, default=0, help="spmv_kernel option of the library (0 = auto)")
@@ -163,24 +245,32 @@ def main():
                     help="1 = Jacobi, 2 = Jacobi + rigid-body coarse space (dense), 3 = 2 + tile level, 4 = 3 + "
                          "rank-local dense level; 0 = 3")
     ap.add_argument("--coarse-max-dofs", type=int, default=0,
-                    help="upper bound on the dofs of the dense coarse level (0 = library default, 3072)")
+                    help="upper bound on the dofs of the dense coarse level (0 = library default)")
     ap.add_argument("--palette", type=int, default=1, help="1 = K*p reads palette ids when the records repeat")
     ap.add_argument("--condense", type=int, default=0,
                     help="exact elimination of an independent node set inside the PCG: 0 = automatic (bipartite node "
                          "graphs such as BCC), 1 = whenever possible, -1 = never (see pylattice_hip.h)")
-    ap.add_argument("--tile-modes", type=int, default=0,
-                    help="modes per block of the preconditioner's tile level: 0 / 12 = rigid + uniform strains, 6 = rigid")
+    ap.add_argument("--tile-modes", type=int, default=-1,
+                    help="modes per block of the preconditioner's tile level: 0 / 12 = rigid + uniform strains, 6 = rigid "
+                         "(-1 = the configuration's default)")
     ap.add_argument("--coarse-modes", type=int, default=0,
-                    help="modes per aggregate of the dense level: 0 / 6 = rigid, 12 = rigid + uniform strains")
+                    help="modes per aggregate of the dense level: 0 = automatic, 6 = rigid, 12 = rigid + uniform strains")
     ap.add_argument("--cg-form", type=int, default=0,
                     help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
                          "vectors); 0 = ordinary form")
-    ap.add_argument("--precision", type=int, default=0,
-                    help="0 = fp64 (headline), 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only")
+    ap.add_argument("--precision", type=int, default=-1,
+                    help="0 = fp64, 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only (-1 = the "
+                         "configuration's: fp64, configs[4] precision 1)")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="multi-rank K*p: 1 = interface tiles first, exchange under the interior tiles; 0 = one launch "
+                         "then the exchange (-1 = library default)")
     ap.add_argument("--cpu-cells", type=int, default=36,
                     help="edge of the CPU-baseline sample (0 = skip); 36 = 1.1 M struts, ~10-15 s on one core")
     ap.add_argument("--splu-cells", type=int, default=5,
                     help="edge of the reference-faithful (sub-meshed + sparse LU) CPU sample (0 = skip); 5 = ~15 s")
+    ap.add_argument("--large-cells", type=int, default=100,
+                    help="edge of the Octet cube for roofline_large (K*p on a working set far beyond the 256 MiB "
+                         "Infinity Cache; 0 = skip)")
     ap.add_argument("--no-streaming", action="store_true", help="skip the palette-off / graded-lattice K*p measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing through solve_FEM_FenicsX")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
@@ -207,6 +297,32 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    from pylatticedso_amd import _capi, lattice_arrays as LA, partition as PT
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+
+    if args.config == 3:
+        out = design_loop(args, local_rank)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
+
+    cfg = dict(CONFIGS[args.config])
+    if args.cells:
+        cfg["cells"] = tuple(args.cells * 3) if len(args.cells) == 1 else tuple(args.cells)
+    if args.geom:
+        cfg["geom"] = args.geom.split(",")
+    if args.radius:
+        cfg["radii"] = list(args.radius)
+    if len(cfg["radii"]) != len(cfg["geom"]):
+        cfg["radii"] = [cfg["radii"][0]] * len(cfg["geom"])
+    if args.precision < 0:
+        args.precision = cfg["precision"]
+    if args.tile_modes < 0:
+        args.tile_modes = cfg["tile_modes"]
+    loop = args.loopback if args.loopback > 1 else 0
+    if loop and world > 1:
+        raise SystemExit("--loopback is a single-process mode")
     multi = world > 1 or args.force_dist
     if args.precond == 0:
         # 4 (rank-local dense level) was measured on the single-GPU rehearsal of the multi-rank path: +11 us per
@@ -221,58 +337,80 @@ def main():
         # whichever came first exactly once).
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from pylatticedso_amd import _capi, lattice_arrays as LA, partition as PT
-    if not os.path.exists(_capi.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
+    nranks = loop if loop else world
+    axis = cfg["axis"]
+    ncell = list(cfg["cells"])
+    if cfg["scaling"] == "weak":
+        ncell[axis] *= nranks            # per-rank work fixed
+    ncell = tuple(ncell)
+    x_max = float(ncell[0])
+    if nranks > ncell[axis]:
+        raise SystemExit("more ranks than cell layers along the partition axis")
+    opts = dict(spmv_kernel=args.kernel, reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond,
+                palette=args.palette, tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs,
+                precision=args.precision, condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes,
+                coarse_modes=args.coarse_modes)
+    if args.overlap >= 0:
+        opts["overlap"] = args.overlap
 
-    n = args.cells
-    ncell = (n, n * world, n)
     t0 = time.perf_counter()
-    if not multi:
-        lat = LA.generate((1, 1, 1), ncell, [args.geom], [args.radius])
-        pen = LA.penalize(lat, LA.compute_lzone(lat))
+    group = dev = slab = None
+    if loop:
+        from pylatticedso_amd.loopback import LoopbackGroup
+        group = LoopbackGroup((1, 1, 1), ncell, cfg["geom"], cfg["radii"], loop, axis=axis, young=E, poisson=NU,
+                              device=local_rank, p2p=not args.interface_allreduce, **opts)
+        n_beams_total = group.n_beams
+        per_rank = (max(len(s.beam_conn) for s in group.slabs), max(len(s.node_xyz) for s in group.slabs))
+        fixed, f = group.cantilever(x_max)
+        group.set_bc(fixed, None, f)
+        log(f"[loopback x{loop}] host slab build + pl_create {time.perf_counter() - t0:.1f} s: {n_beams_total} struts")
+    elif not multi:
+        lat = LA.generate((1, 1, 1), ncell, cfg["geom"], cfg["radii"])
+        pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius, device=local_rank)
+                          if lat.n_beams > 4_000_000 else LA.compute_lzone(lat))
         xyz, conn, rad, seg_len, seg_nsub = lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub
         n_tgt = None
     else:
-        slab = PT.build_slab((1, 1, 1), ncell, [args.geom], [args.radius], rank, world, axis=1)
+        slab = PT.build_slab((1, 1, 1), ncell, cfg["geom"], cfg["radii"], rank, world, axis=axis)
         xyz, conn, rad, seg_len, seg_nsub = slab.node_xyz, slab.beam_conn, slab.beam_radius, slab.seg_len, slab.seg_nsub
-    log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
-
-    grid = None
-    if multi:
-        # every rank must cut the same brick / aggregate grid: hand over the box and node count of the whole lattice
-        nn = torch.tensor([float(len(xyz))], dtype=torch.float64)
-        dist.all_reduce(nn)
-        grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
-    dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
-                           reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond, grid=grid, palette=args.palette,
-                           tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs, precision=args.precision,
-                           condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes,
-                           coarse_modes=args.coarse_modes)
-    n_beams_total = len(conn)
-    if multi:
-        keys = [None] * world
-        dist.all_gather_object(keys, slab.iface_key)
-        ok, gid, nsg = PT.global_interface_ids(keys, rank)
-        uid = [_capi.HipLattice.dist_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        # interface rows: neighbour exchange (grouped ncclSend/ncclRecv with the two adjacent slabs) unless the
-        # all-planes all-reduce is asked for; a single-rank rehearsal has no neighbours
-        peers = None if (args.interface_allreduce or world == 1) else slab.iface_peer[ok]
-        dev.dist_init(rank, world, uid[0], slab.iface_local[ok], gid, nsg, shared_peer=peers)
-        # global number of loaded nodes / struts (shared nodes counted once: they belong to the lower slab)
-        lower_plane = np.zeros(len(xyz), bool)
-        if rank > 0:
-            lower_plane[slab.iface_local[ok][slab.iface_key[ok][:, 0] == slab.layers[0]]] = True
-        cnt = torch.tensor([float(((xyz[:, 0] == float(n)) & ~lower_plane).sum()), float(len(conn))],
-                           dtype=torch.float64)
-        dist.all_reduce(cnt)
-        n_tgt, n_beams_total = int(cnt[0].item()), int(cnt[1].item())
-    fixed, f, _ = cantilever_bc(xyz, float(n), n_tgt)
-    dev.set_bc(fixed, None, f)
+    if not loop:
+        log(f"[rank {rank}] host lattice build {time.perf_counter() - t0:.1f} s: {len(conn)} struts, {len(xyz)} nodes")
+        grid = None
+        if multi:
+            # every rank must cut the same brick / aggregate grid: hand over the box and node count of the whole lattice
+            nn = torch.tensor([float(len(xyz))], dtype=torch.float64)
+            dist.all_reduce(nn)
+            grid = ((0.0, 0.0, 0.0), tuple(float(v) for v in ncell), int(nn.item()))
+        dev = _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, grid=grid, **opts)
+        n_beams_total = len(conn)
+        per_rank = (len(conn), len(xyz))
+        if multi:
+            keys = [None] * world
+            dist.all_gather_object(keys, slab.iface_key)
+            ok, gid, nsg = PT.global_interface_ids(keys, rank)
+            uid = [_capi.HipLattice.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            # interface rows: neighbour exchange (grouped ncclSend/ncclRecv with the two adjacent slabs) unless the
+            # all-planes all-reduce is asked for; a single-rank rehearsal has no neighbours
+            peers = None if (args.interface_allreduce or world == 1) else slab.iface_peer[ok]
+            dev.dist_init(rank, world, uid[0], slab.iface_local[ok], gid, nsg, shared_peer=peers)
+            # global number of loaded nodes / struts (shared nodes counted once: they belong to the lower slab)
+            lower_plane = np.zeros(len(xyz), bool)
+            if rank > 0:
+                lower_plane[slab.iface_local[ok][slab.iface_key[ok][:, 0] == slab.layers[0]]] = True
+            cnt = torch.tensor([float(((xyz[:, 0] == x_max) & ~lower_plane).sum()), float(len(conn))],
+                               dtype=torch.float64)
+            dist.all_reduce(cnt)
+            n_tgt, n_beams_total = int(cnt[0].item()), int(cnt[1].item())
+        fixed, f, _ = cantilever_bc(xyz, x_max, n_tgt)
+        dev.set_bc(fixed, None, f)
 
     def step():
+        if loop:
+            group.assemble()
+            if not args.no_bsr:
+                group.each(lambda r: group.devs[r].assemble_bsr(False))
+            return group.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)[0]
         dev.assemble()
         if not args.no_bsr:
             dev.assemble_bsr(False)
@@ -283,6 +421,9 @@ def main():
         if multi:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def tk(which, reps):             # HIP-event time of one kernel / iteration on the library's stream (rank 0's clock)
+        return group.time_kernel(which, reps)[0] if loop else dev.time_kernel(which, reps)
 
     for _ in range(args.warmup):
         st = step()
@@ -298,37 +439,43 @@ def main():
         dt = float(t.item())
 
     # dominant kernel: K*p.  HIP events on the library's stream (torch events only see torch's stream).
-    ms_spmv = dev.time_kernel(0, 50)
-    ms_iter = dev.time_kernel(3, 50)
-    ms_rec = dev.time_kernel(1, 20)
-    ms_bsr = dev.time_kernel(2, 10) if not args.no_bsr else None
+    ms_spmv = tk(0, 50)
+    ms_iter = tk(3, 50)
+    ms_rec = tk(1, 20)
+    ms_bsr = tk(2, 10) if not args.no_bsr else None
     ms_f32 = None
     if args.precond >= 2 and args.kernel in (0, 3) and args.reorder:
-        ms_f32 = {"spmv_f32_storage": dev.time_kernel(7, 50), "pcg_iteration_precision1": dev.time_kernel(8, 50),
-                  "pcg_iteration_precision2": dev.time_kernel(9, 50)}
+        ms_f32 = {"spmv_f32_storage": tk(7, 50), "pcg_iteration_precision1": tk(8, 50),
+                  "pcg_iteration_precision2": tk(9, 50)}
     # the two collectives of an iteration, alone (every rank makes the same calls; rank 0's clock is reported)
-    ms_coll = {"interface_allreduce": dev.time_kernel(5, 50), "coarse_allreduce": dev.time_kernel(6, 50)} if multi else None
-    ab = dev.algorithmic_bytes()
+    ms_coll = {"interface_exchange": tk(5, 50), "coarse_allreduce": tk(6, 50)} if (multi or loop) else None
+    d0 = group.devs[0] if loop else dev
+    ab = d0.algorithmic_bytes()
     achieved = ab["spmv"] / (ms_spmv * 1e-3) / 1e9
+    headline = args.config == 1 and world == 1 and not loop and not args.cells and not args.geom and not args.radius
     # HBM bytes per K*p launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
     # gfx950: FETCH_SIZE counts half of 16-B/lane streaming reads - see profiles/README.md).  Valid for the default
-    # single-GPU workload only.
-    traffic = traffic_src = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
-    if world == 1 and n == 50 and args.geom == "Octet" and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        if pmc.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder) and \
-                pmc.get("record_palette", 0) == args.palette:
-            traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
-            traffic_src = {"file": "profiles/pmc_spmv_latest.json", "measured_on": pmc.get("build", "unknown build"),
-                           "note": "PMC counters cannot be read inside this run (rocprofv3 --pmc is a separate "
-                                   "pass); this is the committed pass for this workload / kernel / palette setting"}
+    # single-GPU workload only, and only for the kernel / palette setting the pass was taken with.
+    def committed_pmc(name, **must):
+        path = os.path.join(ROOT, "profiles", name)
+        if not (headline and os.path.exists(path)):
+            return None, None
+        pmc = json.load(open(path))
+        if any(pmc.get(k) != v for k, v in must.items()):
+            return None, None
+        return (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0, \
+            {"file": "profiles/" + name, "measured_on": pmc.get("build", "unknown build"),
+             "note": "PMC counters cannot be read inside this run (rocprofv3 --pmc is a separate pass); this is the "
+                     "committed pass for this workload / kernel / palette setting"}
+    traffic, traffic_src = committed_pmc("pmc_spmv_latest.json", spmv_kernel=dev_kernel_name(args.kernel, args.reorder),
+                                         record_palette=args.palette)
 
     # The same kernel on lattices whose records do NOT repeat (graded / optimised radii: what every pl_update_radii loop
     # runs): K*p then streams one 40-byte record per strut instead of 2-byte palette ids.  Measured on this lattice with
     # the palette switched off, and on a graded copy (own radius per cell, > 10^5 distinct records) incl. a whole step.
     streaming = None
-    if world == 1 and not args.no_streaming and args.kernel in (0, 3) and args.reorder:
+    if headline and not args.no_streaming and args.kernel in (0, 3) and args.reorder:
+        n = ncell[0]
         streaming = {}
         with _capi.HipLattice(xyz, conn, rad, seg_len, seg_nsub, E, NU, device=local_rank, spmv_kernel=args.kernel,
                               reorder=args.reorder, precond=args.precond, palette=0, tile_nodes=args.tile_nodes,
@@ -339,8 +486,8 @@ def main():
             streaming["palette_off"] = {"ms": ms, "achieved": ab["spmv"] / (ms * 1e-3) / 1e9,
                                         "frac": ab["spmv"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         i3 = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), axis=-1).reshape(-1, 3)
-        rad_cell = (args.radius * (0.8 + 0.4 * (0.5 + 0.5 * np.sin(0.113 * i3[:, 0] + 0.271 * i3[:, 1] + 0.419 * i3[:, 2]))))
-        glat = LA.generate((1, 1, 1), ncell, [args.geom], [args.radius], cell_radii_override=rad_cell.reshape(-1, 1))
+        rad_cell = (cfg["radii"][0] * (0.8 + 0.4 * (0.5 + 0.5 * np.sin(0.113 * i3[:, 0] + 0.271 * i3[:, 1] + 0.419 * i3[:, 2]))))
+        glat = LA.generate((1, 1, 1), ncell, cfg["geom"], cfg["radii"], cell_radii_override=rad_cell.reshape(-1, 1))
         gpen = LA.penalize(glat, _capi.lzone(glat.node_xyz, glat.beam_conn, glat.beam_radius))
         with _capi.HipLattice(glat.node_xyz, glat.beam_conn, glat.beam_radius, gpen.seg_len, gpen.seg_nsub, E, NU,
                               device=local_rank, spmv_kernel=args.kernel, reorder=args.reorder, precond=args.precond,
@@ -363,26 +510,56 @@ def main():
                                    "beams_per_s": glat.n_beams / dtg, "ms_per_step": dtg * 1e3,
                                    "pcg_iterations": gst["iterations"],
                                    "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
+        s_traffic, s_src = committed_pmc("pmc_spmv_streaming_latest.json", spmv_kernel=dev_kernel_name(args.kernel, args.reorder))
         streaming.update({"bound": "hbm", "kernel": "K*p: k_spmv_tile<.., kRecCompact>", "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "algorithmic_bytes": ab["spmv"],
-                          "traffic": (2.0 * 126177.28125 + 24322.515625) * 1024.0,
-                          "traffic_source": "profiles/r02_cj_pmc_streaming_p0.json / _gr.json (separate rocprofv3 --pmc FETCH_SIZE and "
-                                            "WRITE_SIZE passes of tools/prof_stream.sh: 2 x 129.2 MB fetched + 24.9 MB "
-                                            "written per launch, 1.06 x the algorithmic bytes)"})
+                          "unit": "GB/s", "algorithmic_bytes": ab["spmv"], "traffic": s_traffic, "traffic_source": s_src})
+        if s_traffic:
+            streaming["real_frac"] = s_traffic / (streaming["palette_off"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
 
+    # K*p on a working set far beyond the 256 MiB Infinity Cache (at 50^3 the iteration's vectors + connectivity, 155 MB,
+    # fit it - MI355X_MICROARCH.md counts Infinity-Cache hits in FETCH_SIZE): a 100^3 Octet cube, 24.2 M struts, 2.1 GB of
+    # algorithmic bytes per launch, palette on (as the headline) and off (streaming records).
+    large = None
+    if headline and args.large_cells > 0 and args.kernel in (0, 3) and args.reorder:
+        m = args.large_cells
+        llat = LA.generate((1, 1, 1), (m, m, m), cfg["geom"], cfg["radii"])
+        lpen = LA.penalize(llat, _capi.lzone(llat.node_xyz, llat.beam_conn, llat.beam_radius, device=local_rank))
+        lfixed, lf, _ = cantilever_bc(llat.node_xyz, float(m))
+        large = {"workload": f"{m}^3 Octet r={cfg['radii'][0]} (one GPU)", "struts": llat.n_beams, "nodes": llat.n_nodes,
+                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        for tag, pal in (("palette", 1), ("streaming", 0)):
+            with _capi.HipLattice(llat.node_xyz, llat.beam_conn, llat.beam_radius, lpen.seg_len, lpen.seg_nsub, E, NU,
+                                  device=local_rank, precond=args.precond, palette=pal) as dl:
+                dl.set_bc(lfixed, None, lf)
+                dl.assemble()
+                lab = dl.algorithmic_bytes()
+                ms = dl.time_kernel(0, 20)
+                t_l, src_l = committed_pmc(f"pmc_spmv_large_{tag}_latest.json")
+                large[tag] = {"ms": ms, "achieved": lab["spmv"] / (ms * 1e-3) / 1e9,
+                              "frac": lab["spmv"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t_l, "traffic_source": src_l,
+                              "real_frac": (t_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_l else None,
+                              "pcg_iteration_ms": dl.time_kernel(3, 20)}
+                large["algorithmic_bytes"] = lab["spmv"]
+        del llat, lpen
+
+    part = "single GPU"
+    if loop:
+        part = (f"{loop} {'xyz'[axis]}-slabs as {loop} handles on ONE GPU (loopback transport: the multi-rank device path without "
+                f"RCCL; value is a one-GPU number)")
+    elif world > 1 or multi:
+        part = (f"{world} {'xyz'[axis]}-slabs, RCCL " + ("interface all-reduce" if args.interface_allreduce else
+                                                         "neighbour exchange of interface rows (ncclSend/ncclRecv)") +
+                " + fused scalar all-reduces")
     out = {
         "metric": "beams/s assembly+PCG-solve", "value": n_beams_total * args.steps / dt, "unit": "beams/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": (cfg["scaling"] if (world > 1 or loop) else None), "vs_baseline": None,
         "dtype": {0: "f64", 1: "f32 storage + f64 refinement (f64 arithmetic)", 2: "f32 p/Kp storage, f64 x/r"}[args.precision],
         "data": "synthetic",
-        "config": {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {args.geom} r={args.radius} cantilever "
-                               f"(BASELINE.json configs[1] per GPU)",
-                   "struts": n_beams_total, "struts_per_gpu": len(conn), "nodes_per_gpu": len(xyz),
-                   "partition": "single GPU" if world == 1 else
-                   f"{world} y-slabs, RCCL " + ("interface all-reduce" if args.interface_allreduce else
-                                                "neighbour exchange of interface rows (ncclSend/ncclRecv)") +
-                   " + fused scalar all-reduces",
+        "config": {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {'+'.join(cfg['geom'])} r={cfg['radii']} cantilever "
+                               f"({cfg['name']}{' per GPU' if cfg['scaling'] == 'weak' else ''})",
+                   "struts": n_beams_total, "struts_per_gpu": per_rank[0], "nodes_per_gpu": per_rank[1],
+                   "partition": part, "ranks": nranks,
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"], "precision": args.precision,
                    "inner_solves": st.get("restarts", 0.0), "condensed_nodes": int(st.get("condensed_nodes", 0)),
@@ -393,34 +570,53 @@ def main():
                                          "dense rigid-body coarse space)"}[args.precond],
                    "step": "records + Jacobi diag" + (" + coarse operator/factorisation" if args.precond >= 2 else "")
                            + ("" if args.no_bsr else " + BSR(6x6) K") + " + matrix-free PCG",
-                   "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette},
+                   "spmv_kernel": args.kernel, "reorder": args.reorder, "record_palette": args.palette,
+                   "convergence_checks": "the host reads the residual history every 32 iterations, then as the observed "
+                                         "decay predicts; from the second solve of a handle on, the FIRST look is taken 3 "
+                                         "iterations before the previous solve's count (pl_solver.h) - in this loop of "
+                                         "identical solves that removes the intermediate stream drains (~5 x 40 us per "
+                                         "solve); the iteration count is the first one whose residual meets rtol either way",
+                   "octet_bc_note": "Octet faces: the reference also constrains / loads the penalisation points that lie in "
+                                    "a loaded face (its per-cell strut copies, DESIGN.md section 2 defect 1); here only "
+                                    "lattice nodes carry boundary data - an un-pinned divergence from the reference on "
+                                    "this geometry (BCC / hybrid presets match bit-exactly)" if "Octet" in cfg["geom"] else None},
         "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
-                     "note": "tiles are the bricks of the preconditioner's tile level, nested into the aggregates of its "
-                             "dense level (DESIGN.md section 7): 15^3 tiles of 152 nodes at 50^3 Octet cost K*p 3 us "
-                             "against the 13^3 tiles of round 1 (0.93 -> 0.86; 0.88 since its index prefetch moved behind the gathers) and, with the strain modes of both block "
-                             "levels, save 35 of 155 PCG iterations"},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "real_frac": (traffic / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
+                     "note": "frac prices the ALGORITHMIC bytes of SURVEY 8(d) (64-byte record per strut); on this "
+                             "single-radius lattice the record palette replaces them by 2-byte ids, so the bytes that really "
+                             "move (traffic, PMC) are ~0.4 x and real_frac = traffic / time / peak is the honest HBM figure "
+                             "of this launch - and at 50^3 the working set fits the 256 MiB Infinity Cache, whose hits "
+                             "FETCH_SIZE counts: see roofline_large (far beyond that cache) and roofline_streaming (lattices "
+                             "with per-strut records, what every pl_update_radii loop runs)"},
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
     }
     if streaming is not None:
         out["roofline_streaming"] = streaming
+    if large is not None:
+        out["roofline_large"] = large
     if ms_coll is not None:
         out["collectives_ms"] = ms_coll
-        # one RCCL per process: torch's bundled librccl.so and /opt/rocm's share the soname, the loader maps the first
-        with open("/proc/self/maps") as fh:
-            out["rccl_libraries_mapped"] = sorted({ln.split()[-1] for ln in fh if "librccl" in ln})
-        out["process_group_backend"] = "gloo (host bootstrap only); data path: RCCL communicator inside libpylattice_hip"
-    dev.close()
-    if rank == 0 and world == 1 and args.cpu_cells > 0:
-        cb, _ = cpu_baseline(args.cpu_cells, args.radius, args.rtol, args.splu_cells)
+        if not loop:
+            # one RCCL per process: torch's bundled librccl.so and /opt/rocm's share the soname, the loader maps the first
+            with open("/proc/self/maps") as fh:
+                out["rccl_libraries_mapped"] = sorted({ln.split()[-1] for ln in fh if "librccl" in ln})
+            out["process_group_backend"] = "gloo (host bootstrap only); data path: RCCL communicator inside libpylattice_hip"
+    if loop:
+        group.close()
+    else:
+        dev.close()
+    if rank == 0 and headline and args.cpu_cells > 0:
+        cb, _ = cpu_baseline(args.cpu_cells, cfg["radii"][0], args.rtol, args.splu_cells)
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0 and world == 1 and not args.no_e2e and not args.force_dist:
-        out["end_to_end_s"] = end_to_end(n, args.geom, args.radius, args.rtol)
+    if rank == 0 and world == 1 and not loop and not args.no_e2e and not args.force_dist and n_beams_total < 8_000_000:
+        out["end_to_end_s"] = end_to_end(ncell, cfg["geom"], cfg["radii"], args.rtol)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:

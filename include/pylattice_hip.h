@@ -105,7 +105,8 @@ typedef struct {
   int32_t compact_records; /* LDS-tile K*p without a palette (graded / optimised lattices): 0 or 1 = stream 40-byte records
                               (the 5 stiffness scalars; the strut vector is recomputed from the node coordinates),
                               -1 = stream the 64-byte records */
-  int32_t condense;      /* multi-level PCG (precond >= 2, fp64, one GPU): exact elimination of an independent set of nodes (no
+  int32_t condense;      /* multi-level PCG (precond >= 2; fp64 and precision = 1; one or several GPUs - nodes shared with another
+                            rank are never eliminated, and either every rank eliminates or none does): exact elimination of an independent set of nodes (no
                             two share a strut, none carries a Dirichlet dof; chosen at pl_create, interior nodes first)
                             inside the solver - CG runs on the Schur complement of the other nodes, the vector kernels skip
                             the eliminated rows, every iteration pays a second K*p, x still receives every node.
@@ -123,6 +124,10 @@ typedef struct {
   int32_t coarse_modes;  /* dense level of the multi-level PCG: 0 = automatic (12 from 250 k nodes of the whole lattice), 12 =
                           * rigid-body + uniform-strain modes per aggregate (needs tile_modes = 12; fewer, larger aggregates),
                           * 6 = rigid-body modes */
+  int32_t overlap;       /* multi-GPU handles with the neighbour exchange (pl_dist_set_peers), LDS-tile K*p: 0 / 1 = the tiles
+                          * that own interface rows run first and their rows travel (pack, send / recv, add) on a second
+                          * stream while the interior tiles run, -1 = one launch, then the exchange */
+  int32_t reserved_o;
 } pl_opts_t;
 
 typedef struct {

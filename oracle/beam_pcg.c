@@ -168,7 +168,21 @@ int oracle_pcg(int64_t N, int64_t B, const double *xyz, const int32_t *conn, con
 }
 
 
+/* the condensation of every strut ("assembly" of the matrix-free operator) on all cores */
+void oracle_condense_all(int64_t B, const double *radius, const double *seg_len, const int32_t *seg_nsub, double E, double nu,
+                         double kappa, double pen, double *out5) {
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < B; ++b) oracle_condense(radius[b], seg_len + 3 * b, seg_nsub + 3 * b, E, nu, kappa, pen, out5 + 5 * b);
+}
+
 /* ---- all-cores variant ------------------------------------------------------------------------------------ */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -226,17 +240,40 @@ int oracle_pcg_mt(int64_t N, int64_t B, const double *xyz, const int32_t *conn, 
                   const uint8_t *fixed, const double *ubar, const double *f, double rtol, int maxit, double *u,
                   double *relres_out) {
   const int64_t n = 6 * N;
-  double *buf = (double *)calloc((size_t)n * 7, sizeof(double));
+  /* malloc + parallel first touch: with calloc the master thread would place every page on its own NUMA node and the
+   * 128 threads of the GPU box's host would all pull from one memory controller (round 2: 1.5 x over one thread) */
+  double *buf = (double *)malloc((size_t)n * 7 * sizeof(double));
   int64_t *ptr = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
   int64_t *inc = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)B);
   int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
   if (!buf || !ptr || !inc || !fill) return -1000000;
+  double *x = buf, *r = buf + n, *z = buf + 2 * n, *p = buf + 3 * n, *Ap = buf + 4 * n, *dinv = buf + 5 * n,
+         *ub = buf + 6 * n;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) x[i] = r[i] = z[i] = p[i] = Ap[i] = dinv[i] = ub[i] = 0.0;
   for (int64_t b = 0; b < B; ++b) { ptr[conn[2 * b] + 1]++; ptr[conn[2 * b + 1] + 1]++; }
   for (int64_t i = 0; i < N; ++i) { ptr[i + 1] += ptr[i]; fill[i] = ptr[i]; }
   for (int64_t b = 0; b < B; ++b) { inc[fill[conn[2 * b]]++] = b << 1; inc[fill[conn[2 * b + 1]]++] = (b << 1) | 1; }
-  double *x = buf, *r = buf + n, *z = buf + 2 * n, *p = buf + 3 * n, *Ap = buf + 4 * n, *dinv = buf + 5 * n,
-         *ub = buf + 6 * n;
-  oracle_diag(N, B, xyz, conn, sc, dinv);
+  /* Jacobi diagonal by rows (same numbers as oracle_diag, summed per node instead of scattered per strut) */
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    double dg[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t q = ptr[i]; q < ptr[i + 1]; ++q) {
+      const int64_t b = inc[q] >> 1;
+      const int tip = (int)(inc[q] & 1);
+      const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
+      const double ka = sc[5 * b], kt = sc[5 * b + 1], a = sc[5 * b + 2], bb2 = sc[5 * b + 3], c = sc[5 * b + 4];
+      const double d[3] = {xyz[3 * ib] - xyz[3 * ia], xyz[3 * ib + 1] - xyz[3 * ia + 1], xyz[3 * ib + 2] - xyz[3 * ia + 2]};
+      const double L2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], L = sqrt(L2);
+      const double cA = c + a * L2 - 2.0 * bb2 * L;
+      for (int k = 0; k < 3; ++k) {
+        const double t2 = d[k] * d[k] / L2;
+        dg[k] += ka * t2 + a * (1.0 - t2);
+        dg[3 + k] += kt * t2 + (tip ? c : cA) * (1.0 - t2);
+      }
+    }
+    for (int k = 0; k < 6; ++k) dinv[6 * i + k] = dg[k];
+  }
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     dinv[i] = (fixed[i] || dinv[i] == 0.0) ? 0.0 : 1.0 / dinv[i];

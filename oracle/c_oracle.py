@@ -37,6 +37,19 @@ def condense(radius, seg_len, seg_nsub, E, nu, kappa=0.9, pen=1.5):
     return out
 
 
+def condense_all(radius, seg_len, seg_nsub, E, nu, kappa=0.9, pen=1.5):
+    """Every strut's condensation in C on all cores (oracle_condense_all): the assembly half of the all-cores CPU leg."""
+    lib = _lib()
+    lib.oracle_condense_all.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_void_p]
+    radius = np.ascontiguousarray(radius, dtype=np.float64)
+    seg_len = np.ascontiguousarray(seg_len, dtype=np.float64).reshape(-1, 3)
+    seg_nsub = np.ascontiguousarray(seg_nsub, dtype=np.int32).reshape(-1, 3)
+    out = np.empty((len(radius), 5))
+    lib.oracle_condense_all(len(radius), _p(radius), _p(seg_len), _p(seg_nsub), E, nu, kappa, pen, _p(out))
+    return out
+
+
 def condense_unique(radius, seg_len, seg_nsub, E, nu, kappa=0.9, pen=1.5):
     """Same as condense() but evaluates each distinct (r, lengths, n) once (big lattices)."""
     key = np.c_[np.asarray(radius, float), np.asarray(seg_len, float).reshape(-1, 3),
@@ -56,6 +69,33 @@ def spmv(xyz, conn, scalars, x):
     y = np.zeros_like(x)
     lib.oracle_spmv_add(len(conn), _p(xyz), _p(conn), _p(sc), _p(x), _p(y))
     return y.reshape(-1, 6)
+
+
+def available_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a one-GPU
+    job 16 of its 256 hardware threads - OpenMP's default of one thread per hardware thread oversubscribes 8 x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def set_threads(n):
+    lib = _lib()
+    lib.oracle_set_threads.argtypes = [C.c_int]
+    lib.oracle_set_threads(int(n))
 
 
 def num_threads():

@@ -346,6 +346,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
+  c->h_tile_start = tile_start;
   stage.mark("tile plan");
   if (o->precond >= 2 && o->precond <= 4) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
@@ -580,6 +581,7 @@ void pl_destroy(pl_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   pl::dist_destroy(h->dist);
   if (h->pal_host_flags != h->pal_fallback_flags) (void)hipHostFree(h->pal_host_flags);
   if (h->cls_host_flag) (void)hipHostFree(h->cls_host_flag);
@@ -1207,13 +1209,14 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
     return fail(PL_ERR_ARG, "pl_dist_init: loopback group mismatch (all ranks of a loopback id must share one device and one "
                             "world size <= " + std::to_string(pl::kLoopMaxWorld) + ", each rank attaches once)");
   if (rc) return fail(PL_ERR_HIP, "pl_dist_init: communicator setup failed (" + std::to_string(rc) + ")");
+  h->h_shared.assign((size_t)h->N, 0);
+  for (int i = 0; i < n_shared; ++i) h->h_shared[loc[i]] = 1;
+  h->ov_ready = false;
   if (h->coarse.enabled) {   // the tile level and the rank-local dense level leave shared nodes out
-    std::vector<uint8_t> sh((size_t)h->N, 0);
-    for (int i = 0; i < n_shared; ++i) sh[loc[i]] = 1;
-    h->h_shared = sh;
     h->cond_ready = false;   // (re-selected at the next pl_set_bc; until then nothing is condensed)
     h->n_cond = 0;
-    PL_HIP(hipMemcpy(h->sharedbits.p, sh.data(), sh.size(), hipMemcpyHostToDevice));
+    h->cond_agree = -1;
+    PL_HIP(hipMemcpy(h->sharedbits.p, h->h_shared.data(), h->h_shared.size(), hipMemcpyHostToDevice));
     h->coarseL.n_fix = -1;
   }
   h->assembled = false;
@@ -1227,6 +1230,33 @@ int pl_dist_set_peers(pl_handle h, const int32_t *shared_peer) {
   int rc = pl::dist_set_peers(h->dist, shared_peer);
   if (rc) return fail(rc == 2 ? PL_ERR_ARG : PL_ERR_HIP, "pl_dist_set_peers: setup failed (" + std::to_string(rc) + ")");
   h->assembled = false;
+  // exchange / compute overlap of the tile K*p: which tiles own interface rows
+  h->ov_ready = false;
+  if (h->opt.overlap >= 0 && h->tile.ready && h->opkind == 0 && !h->h_tile_start.empty()) {
+    const int64_t T = (int64_t)h->h_tile_start.size() - 1;
+    std::vector<int32_t> iface, inner;
+    for (int64_t t = 0; t < T; ++t) {
+      bool has = false;
+      for (int32_t i = h->h_tile_start[t]; i < h->h_tile_start[t + 1] && !has; ++i) has = h->h_shared[i] != 0;
+      (has ? iface : inner).push_back((int32_t)t);
+    }
+    if (!iface.empty() && !inner.empty()) {
+      PL_HIP(h->ov_iface.alloc(iface.size()));
+      PL_HIP(h->ov_inner.alloc(inner.size()));
+      PL_HIP(hipMemcpy(h->ov_iface.p, iface.data(), iface.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      PL_HIP(hipMemcpy(h->ov_inner.p, inner.data(), inner.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      h->n_ov_iface = (int64_t)iface.size();
+      h->n_ov_inner = (int64_t)inner.size();
+      if (!h->comm_stream) {
+        int prio_low = 0, prio_high = 0;
+        PL_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        PL_HIP(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_high));
+        PL_HIP(hipEventCreateWithFlags(&h->ev_ov_a, hipEventDisableTiming));
+        PL_HIP(hipEventCreateWithFlags(&h->ev_ov_x, hipEventDisableTiming));
+      }
+      h->ov_ready = true;
+    }
+  }
   return PL_OK;
 }
 

@@ -175,6 +175,14 @@ struct pl_context {
                              // not yet agreed since the last pl_set_bc (-1): the solver's collectives must match on all ranks
   // multi-GPU
   pl::Dist dist;
+  // exchange / compute overlap of K*p: the tiles that own interface rows run first, their rows travel on the
+  // communication stream while the interior tiles run on the main one
+  std::vector<int32_t> h_tile_start;
+  DevBuf<int32_t> ov_iface, ov_inner;      // ascending tile lists
+  int64_t n_ov_iface = 0, n_ov_inner = 0;
+  bool ov_ready = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ov_a = nullptr, ev_ov_x = nullptr;
 
   pl_stats_t last{};
   double ms_assembly = 0.0;
@@ -187,6 +195,9 @@ struct pl_context {
     if (ev_chol) (void)hipEventDestroy(ev_chol);
     if (ev_t0) (void)hipEventDestroy(ev_t0);
     if (ev_t1) (void)hipEventDestroy(ev_t1);
+    if (ev_ov_a) (void)hipEventDestroy(ev_ov_a);
+    if (ev_ov_x) (void)hipEventDestroy(ev_ov_x);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (side2) (void)hipStreamDestroy(side2);
     if (side) (void)hipStreamDestroy(side);
     if (stream) (void)hipStreamDestroy(stream);

@@ -84,29 +84,58 @@ int spmv_interface_sum(pl_context *c, VT *y, double *dot_dev, bool reduce_dot = 
   return PL_OK;
 }
 
+// The LDS-tile K*x from whichever record source the handle has (palette ids / compact records / 64-byte records), over
+// all tiles or over a list of them.
+template <typename VT>
+void tile_launch(pl_context *c, const uint8_t *maskbits, const VT *x, VT *y, double *dot_dev, int ends, const uint8_t *cf,
+                 const pl::CondSolve &cs, const int32_t *list = nullptr, int64_t n_list = 0) {
+  if (c->pal_ready)
+    pl::launch_tile_spmv<VT>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,
+                             (const double *)nullptr, ends, cf, cs, list, n_list);
+  else if (c->rec5.p)
+    pl::launch_tile_spmv<VT>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
+                             dot_dev, c->stream, c->xyz.p, ends, cf, cs, list, n_list);
+  else
+    pl::launch_tile_spmv<VT>(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
+                             (const double *)nullptr, ends, cf, cs, list, n_list);
+}
+
+// Tile K*x of a handle, with the interface sum of a multi-GPU handle behind it.
+// Several GPUs: an eliminated node is never shared with another rank, so all its struts are this rank's and the passes that
+// accumulate ONLY the strut ends at eliminated nodes (kEndsCondensed / kEndsCondensedSolve) are complete locally; the pass
+// over the other ends is an ordinary partial product and takes the interface exchange.
+// Overlap (neighbour exchange only): the tiles that own interface rows run first; their rows are packed, exchanged and
+// added on the communication stream while the interior tiles run on the main stream; the scalar slots of the fused dot
+// product (to which both launches add) take their small all-reduce afterwards.
+template <typename VT>
+int tile_spmv(pl_context *c, const uint8_t *maskbits, const VT *x, VT *y, double *dot_dev, int ends, bool reduce_dot) {
+  const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+  const pl::CondSolve cs = cond_solve(c, ends);
+  const bool exchange = c->dist.active && (ends == pl::kEndsAll || ends == pl::kEndsOthers);
+  if (!(exchange && c->ov_ready && c->dist.p2p)) {
+    tile_launch<VT>(c, maskbits, x, y, dot_dev, ends, cf, cs);
+    PL_HIP(hipGetLastError());
+    return exchange ? spmv_interface_sum<VT>(c, y, dot_dev, reduce_dot) : PL_OK;
+  }
+  tile_launch<VT>(c, maskbits, x, y, dot_dev, ends, cf, cs, c->ov_iface.p, c->n_ov_iface);
+  PL_HIP(hipEventRecord(c->ev_ov_a, c->stream));
+  PL_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_ov_a, 0));
+  if (pl::dist_exchange_p2p<VT>(c->dist, y, c->comm_stream)) return fail(PL_ERR_HIP, "exchange of the interface forces failed");
+  PL_HIP(hipEventRecord(c->ev_ov_x, c->comm_stream));
+  tile_launch<VT>(c, maskbits, x, y, dot_dev, ends, cf, cs, c->ov_inner.p, c->n_ov_inner);
+  PL_HIP(hipStreamWaitEvent(c->stream, c->ev_ov_x, 0));
+  PL_HIP(hipGetLastError());
+  if (dot_dev && reduce_dot && pl::dist_sum_scalars(c->dist, dot_dev, pl::kSlots, c->stream))
+    return fail(PL_ERR_HIP, "all-reduce of the K*p dot-product slots failed");
+  return PL_OK;
+}
+
 int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *dot_dev,
                 const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll, bool reduce_dot = true) {
   const int kind = choose_kernel(c);
-  if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0) {
+  if ((maskbits || ends != pl::kEndsAll) && kind == 3 && c->tile.ready && c->opkind == 0)
     // tile kernel with a caller-chosen row mask and / or only one kind of strut ends (node elimination)
-    const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
-    const pl::CondSolve cs = cond_solve(c, ends);
-    if (c->pal_ready)
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,
-                           (const double *)nullptr, ends, cf, cs);
-    else if (c->rec5.p)
-      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, maskbits, x, y,
-                           dot_dev, c->stream, c->xyz.p, ends, cf, cs);
-    else
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, maskbits, x, y, dot_dev, c->stream,
-                           (const double *)nullptr, ends, cf, cs);
-    PL_HIP(hipGetLastError());
-    // Several GPUs: an eliminated node is never shared with another rank, so all its struts are this rank's and the passes
-    // that accumulate ONLY the strut ends at eliminated nodes (kEndsCondensed / kEndsCondensedSolve) are complete locally;
-    // the pass over the other ends is an ordinary partial product and takes the interface exchange.
-    if (ends == pl::kEndsAll || ends == pl::kEndsOthers) return spmv_interface_sum(c, y, dot_dev, reduce_dot);
-    return PL_OK;
-  }
+    return tile_spmv<double>(c, maskbits, x, y, dot_dev, ends, reduce_dot);
   const int64_t n6 = c->N * 6;
   if (c->opkind == 1) {
     const int m = 6 * c->ddm_nb;
@@ -142,15 +171,8 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
       hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
                          masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
   } else if (kind == 3 && c->tile.ready) {
-    if (c->pal_ready)
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->palette.p, c->pal_id.p, masked ? c->fixedbits.p : nullptr, x, y,
-                           dot_dev, c->stream);
-    else if (c->rec5.p)
-      pl::launch_tile_spmv(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr,
-                           masked ? c->fixedbits.p : nullptr, x, y, dot_dev, c->stream, c->xyz.p);
-    else
-      pl::launch_tile_spmv(c->tile, c->conn.p, c->rec.p, nullptr, masked ? c->fixedbits.p : nullptr, x, y, dot_dev,
-                           c->stream);
+    return tile_spmv<double>(c, masked ? (const uint8_t *)c->fixedbits.p : (const uint8_t *)nullptr, x, y, dot_dev,
+                             pl::kEndsAll, reduce_dot);
   } else {
     int rc = dispatch_gather(c, x, y, masked, dot_dev);
     if (rc) return rc;
@@ -163,20 +185,7 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
 int launch_spmv_f32(pl_context *c, const float *x, float *y, bool masked, double *dot_dev,
                     const uint8_t *maskbits = nullptr, int ends = pl::kEndsAll) {
   const uint8_t *mk = maskbits ? maskbits : (masked ? (const uint8_t *)c->fixedbits.p : (const uint8_t *)nullptr);
-  const uint8_t *cf = ends != pl::kEndsAll ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
-  const pl::CondSolve cs = cond_solve(c, ends);
-  if (c->pal_ready)
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, mk, x, y, dot_dev, c->stream,
-                                (const double *)nullptr, ends, cf, cs);
-  else if (c->rec5.p)
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, reinterpret_cast<const pl::Record *>(c->rec5.p), nullptr, mk, x, y,
-                                dot_dev, c->stream, c->xyz.p, ends, cf, cs);
-  else
-    pl::launch_tile_spmv<float>(c->tile, c->conn.p, c->rec.p, nullptr, mk, x, y, dot_dev, c->stream,
-                                (const double *)nullptr, ends, cf, cs);
-  PL_HIP(hipGetLastError());
-  if (ends == pl::kEndsAll || ends == pl::kEndsOthers) return spmv_interface_sum<float>(c, y, dot_dev);
-  return PL_OK;
+  return tile_spmv<float>(c, mk, x, y, dot_dev, ends, true);
 }
 
 // residual history + (reference-CG mode) direction norm, solution norm and step length of every iteration

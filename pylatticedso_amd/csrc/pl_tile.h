@@ -351,11 +351,15 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
                                                       const VT *__restrict__ x, VT *__restrict__ y,
                                                       double *__restrict__ dot_out, int stride,
                                                       const uint8_t *__restrict__ cflag = nullptr,
-                                                      CondSolve cs = CondSolve()) {
+                                                      CondSolve cs = CondSolve(),
+                                                      const int32_t *__restrict__ tile_list = nullptr) {
   extern __shared__ double ys[];             // [6][stride], stride >= nodes of the largest tile (launch_tile_spmv)
   __shared__ double red[kTileBlock / kWave];
   __shared__ int32_t sbase[ENDS == kEndsCondensedSolve ? kTileMaxNodes : 1];
-  const unsigned t = xcd_block(blockIdx.x, gridDim.x);
+  // tile_list: a launch over a subset of the tiles (multi-GPU overlap: the tiles that own interface rows first, the
+  // exchange under the others) - ascending tile numbers, so the XCD mapping keeps its contiguous eighths
+  unsigned t = xcd_block(blockIdx.x, gridDim.x);
+  if (tile_list) t = (unsigned)tile_list[t];
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int nn = n1 - n0;
   for (int i = threadIdx.x; i < 6 * stride; i += kTileBlock) ys[i] = 0.0;
@@ -457,14 +461,16 @@ template <typename VT>
 inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Record *rec, const uint16_t *pal,
                              const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev, hipStream_t s,
                              const double *xyz = nullptr, int ends = kEndsAll, const uint8_t *cflag = nullptr,
-                             CondSolve cs = CondSolve()) {
-  const dim3 g((unsigned)plan.n_tiles), blk(kTileBlock);
+                             CondSolve cs = CondSolve(), const int32_t *tile_list = nullptr, int64_t n_list = 0) {
+  if (tile_list && n_list <= 0) return;
+  const dim3 g((unsigned)(tile_list ? n_list : plan.n_tiles)), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
 #define PL_T(M, D, P, E)                                                                                          \
   hipLaunchKernelGGL((k_spmv_tile<M, D, P, VT, E>), g, blk, lds, s, plan.tile_start.p, plan.home_ptr.p,           \
-                     plan.foreign_ptr.p, plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride, cflag, cs)
+                     plan.foreign_ptr.p, plan.foreign_idx.p, conn2, rec, pal, xyz, fixedbits, x, y, dot_dev, stride, cflag, cs, \
+                     tile_list)
 #define PL_TT(P, E)                                           \
   do {                                                        \
     if (fixedbits && dot_dev) PL_T(true, true, P, E);         \

@@ -91,7 +91,9 @@ CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dic
          "precond4_precision1": dict(precond=4, precision=1), "precision2": dict(precond=3, precision=2),
          # node elimination on multi-rank handles (nodes shared with another rank stay unknowns)
          "condense": dict(precond=3, condense=1), "condense_precision1": dict(precond=3, condense=1, precision=1),
-         "condense_precond4": dict(precond=4, condense=1)}
+         "condense_precond4": dict(precond=4, condense=1),
+         # the default K*p of a multi-rank handle overlaps the neighbour exchange with the interior tiles; -1 = one launch
+         "no_overlap": dict(precond=3, overlap=-1), "condense_no_overlap": dict(precond=3, condense=1, overlap=-1)}
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
