@@ -57,7 +57,8 @@ def _hybrid4():
 
 
 def _bccz():
-    return _bcc() + [(x, y, 0.0, x, y, 1.0) for x in (0.0, 1.0) for y in (0.0, 1.0)]
+    # BCC plus a strut along z through the cell centre, split there (bottom face centre - centre - top face centre)
+    return _bcc() + [(0.5, 0.5, 0.0, *_C), (*_C, 0.5, 0.5, 1.0)]
 
 
 def _fcc():
@@ -67,8 +68,121 @@ def _fcc():
     return rows
 
 
+def _octant_of(c):
+    """The point a quarter of the body diagonal inside the cube from corner c."""
+    return tuple(0.25 if v == 0.0 else 0.75 for v in c)
+
+
+def _diamond():
+    # diamond cubic: every corner to its octant point, the octant point to the centres of the three faces that meet
+    # at that corner
+    rows = []
+    for c in _CORNERS:
+        o = _octant_of(c)
+        rows += [(*c, *o), (*o, 0.5, 0.5, c[2]), (*o, c[0], 0.5, 0.5), (*o, 0.5, c[1], 0.5)]
+    return rows
+
+
+def _original():
+    # like the diamond cell, but the octant points reach the mid-points of the three EDGES that meet at the corner
+    rows = []
+    for c in _CORNERS:
+        o = _octant_of(c)
+        rows += [(*c, *o), (*o, 0.5, c[1], c[2]), (*o, c[0], c[1], 0.5), (*o, c[0], 0.5, c[2])]
+    return rows
+
+
+def _hybrid2():
+    return [(*e, *_C) for e in _EDGE_MIDS]                    # the twelve edge mid-points to the cell centre
+
+
+def _hybrid3():
+    # every octant point to the centres of its three nearest faces (Hybrid4 without the face-centre -> centre struts)
+    return [(*o, *f) for o in _OCTANTS for f in _FACE_CENTRES if abs(_dist2(o, f) - 3 * 0.0625) < 1e-12]
+
+
+def _hybrid5():
+    # six points half-way between the cell centre and the face centres: each to the centre and to the four corners of
+    # its face
+    rows = []
+    for f in _FACE_CENTRES:
+        p = tuple(0.5 * (a + b) for a, b in zip(f, _C))
+        rows.append((*p, *_C))
+        rows += [(*p, *c) for c in _CORNERS if abs(_dist2(c, f) - 0.5) < 1e-12]
+    return rows
+
+
+def _kelvin():
+    # truncated octahedron: on every face a square of four points a quarter edge from the face centre, plus the struts
+    # between squares of adjacent faces (nearest points, 1/8 apart in squared distance)
+    pts, rows = [], []
+    for ax in range(3):
+        a, b = [k for k in range(3) if k != ax]
+        for side in (0.0, 1.0):
+            sq = []
+            for k, off in ((a, 0.25), (a, 0.75), (b, 0.25), (b, 0.75)):
+                q = [0.5, 0.5, 0.5]
+                q[ax] = side
+                q[k] = off
+                sq.append(tuple(q))
+            rows += [(*sq[i], *sq[j]) for i in (0, 1) for j in (2, 3)]
+            pts += [(q, (ax, side)) for q in sq]
+    for (p, fp), (q, fq) in itertools.combinations(pts, 2):
+        if fp != fq and abs(_dist2(p, q) - 0.125) < 1e-12:
+            rows.append((*p, *q))
+    return rows
+
+
+def _octahedron():
+    return [(*p, *q) for p, q in itertools.combinations(_FACE_CENTRES, 2) if abs(_dist2(p, q) - 0.5) < 1e-12]
+
+
+def _octahedron_z():
+    return _octahedron() + [(0.5, 0.5, 0.0, 0.5, 0.5, 1.0)]          # one strut through the cell along z
+
+
+def _octahedron_yz():
+    return _octahedron() + [(*f, *_C) for f in _FACE_CENTRES]           # (all six face centres to the cell centre)
+
+
+def _original2():
+    # BCC diagonals plus, on every face, the four corners and the four edge mid-points to the face centre
+    rows = _bcc()
+    for f in _FACE_CENTRES:
+        ax = [k for k in range(3) if f[k] != 0.5][0]
+        ring = [p for p in itertools.product((0.0, 0.5, 1.0), repeat=3) if p[ax] == f[ax] and p != f]
+        rows += [(*p, *f) for p in ring]
+    return rows
+
+
+def _auxetic(hgeom=0.35, angle_deg=20.0):
+    # re-entrant ("bow-tie") honeycomb on the four vertical faces of the cell; h = height of the re-entrant node above the
+    # face's bottom edge, v = height where the inclined struts leave the vertical edges (parametric in the reference:
+    # hgeom = 0.35, angleGeom = 20 degrees, valGeom = hgeom - tan(angleGeom) / 2)
+    h = hgeom
+    v = _eval_expr("hgeom - tan(angleGeom * pi / 180) / 2", {"hgeom": hgeom, "angleGeom": angle_deg})
+    rows = []
+
+    def face(point, upper_from_node):            # point(s, z) -> xyz of the face's in-plane coordinates
+        lower = [(point(0.5, 0.0), point(0.5, h)), (point(0.0, v), point(0.5, h)), (point(1.0, v), point(0.5, h))]
+        upper = [(point(0.5, 1.0), point(0.5, 1.0 - h)), (point(0.0, 1.0 - v), point(0.5, 1.0 - h)),
+                 (point(1.0, 1.0 - v), point(0.5, 1.0 - h))]
+        if upper_from_node:     # (strut direction decides from which end the penalisation points are laid off: with these
+            upper = [(b, a) for a, b in upper]      # irrational coordinates that is visible in the last bit)
+        return [(*a, *b) for a, b in lower + upper]
+    for y in (0.0, 1.0):
+        rows += face(lambda s, z, y=y: (s, y, z), False)
+        rows += [(x, y, v, x, y, 1.0 - v) for x in (0.0, 1.0)]          # the four vertical edges, once
+    for x in (1.0, 0.0):
+        rows += face(lambda s, z, x=x: (x, s, z), True)
+    return rows
+
+
 _BUILTIN = {"BCC": _bcc, "Cubic": _cubic, "Octet": _octet, "Hybrid1": _hybrid1, "Hybrid4": _hybrid4,
-            "BCCZ": _bccz, "FCC": _fcc}
+            "BCCZ": _bccz, "FCC": _fcc, "OctetExt": _fcc, "Diamond": _diamond, "Original": _original,
+            "Original2": _original2, "Hybrid2": _hybrid2, "Hybrid3": _hybrid3, "Hybrid5": _hybrid5, "Kelvin": _kelvin,
+            "Octahedron": _octahedron, "OctahedronZ": _octahedron_z, "OctahedronYZ": _octahedron_yz,
+            "Auxetic": _auxetic}
 _REGISTERED: dict[str, list] = {}
 
 _OPS = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
@@ -77,9 +191,26 @@ _FUNCS = {"tan": math.tan, "sin": math.sin, "cos": math.cos, "sqrt": math.sqrt, 
 
 
 def _eval_expr(expr, names):
-    """Arithmetic-only evaluator for parametric geometry files (the reference uses sympy.sympify)."""
+    """Evaluator for parametric geometry files.  The reference evaluates these expressions with
+    sympy.sympify(expr, locals).evalf() (geometries_utils.py:20-38), parameters entering as Python floats: pi and tan()
+    stay symbolic until the end while float coefficients fold at double precision - the result is neither plain double
+    arithmetic nor the correctly rounded value (the Auxetic cell's valGeom differs from both by one ulp), and node
+    coordinates must match bit for bit.  So sympy - which the reference requires anyway - is used when it is importable;
+    without it an arithmetic-only evaluator in double precision serves (parametric cells are then good to 1 ulp)."""
     if isinstance(expr, (int, float)):
         return float(expr)
+    try:
+        import sympy
+    except ImportError:                                    # pragma: no cover - sympy is a dependency of the reference
+        sympy = None
+    if sympy is not None:
+        ctx = {k: getattr(sympy, k) for k in ("sin", "cos", "tan", "asin", "acos", "atan", "exp", "log", "sqrt", "pi")}
+        ctx.update({k: float(v) for k, v in names.items()})
+        try:
+            res = sympy.sympify(str(expr), locals=ctx)
+            return float(res.evalf()) if hasattr(res, "evalf") else float(res)
+        except Exception as e:      # noqa: BLE001 - same message as the reference
+            raise ValueError(f"Failed to evaluate expression '{expr}': {e}") from e
 
     def ev(n):
         if isinstance(n, ast.Expression):

@@ -343,10 +343,23 @@ def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, be
 # ------------------------------------------------------------------------------------------------
 # joint penalisation
 # ------------------------------------------------------------------------------------------------
+def _libm(fn, arr):
+    """fn (math.acos, math.tan, ...) applied element-wise through the C library, as the reference's scalar code does:
+    numpy's vectorised arccos / tan may differ from libm in the last bit, and L_zone decides where the penalisation points
+    lie - bit-exact only with the same function.  Evaluated once per DISTINCT value (lattices repeat a handful of
+    angles); arrays beyond a few million entries keep numpy's own loops (large lattices take the device kernel pl_lzone)."""
+    arr = np.asarray(arr, dtype=np.float64)
+    if arr.size > 4_000_000:
+        return {math.acos: np.arccos, math.tan: np.tan}[fn](arr)
+    uq, inv = np.unique(arr.ravel(), return_inverse=True)
+    vals = np.array([fn(float(v)) if np.isfinite(v) else np.nan for v in uq], dtype=np.float64)
+    return vals[inv].reshape(arr.shape)
+
+
 def _lzone_of(radius, angle_deg):
     """function_penalization_Lzone (utils.py:432-453), vectorised."""
     with np.errstate(divide="ignore", invalid="ignore"):
-        L = radius / np.tan(np.radians(angle_deg) / 2.0)
+        L = radius / _libm(math.tan, np.radians(angle_deg) / 2.0)
     L = np.where(angle_deg > 170.0, 0.0000001, L)
     return np.where(angle_deg == 0.0, 0.0, L)
 
@@ -441,7 +454,7 @@ def compute_lzone(lat: LatticeArrays, periodicity: bool = False) -> np.ndarray:
                    + d[:, :, None, 2] * d[:, None, :, 2])
             nn = dnorm[hes]
             cosang = np.clip(dot / (nn[:, :, None] * nn[:, None, :]), -1.0, 1.0)
-            ang = np.degrees(np.arccos(cosang))
+            ang = np.degrees(_libm(math.acos, cosang))
             r_other = rad[hes // 2][:, None, :] * np.ones((1, v, 1))          # (n, i, j) radius of j
             L = _lzone_of(r_other, ang)
             valid = (ang > 1e-12) & ~np.eye(v, dtype=bool)[None]

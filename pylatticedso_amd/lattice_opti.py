@@ -242,7 +242,42 @@ class LatticeOpti(LatticeSim):
             if self.objective_function == "min":
                 return mean_disp
             raise ValueError("objective_function must be 'min' or 'max'")
+        if self.objective_type == "displacement_ratio":
+            u_in, u_out, _ = self._ratio_terms()
+            return -(u_out * u_in)                 # lattice_opti.py:616-636 (inverse mechanism: u_out ~ -u_in)
+        if self.objective_type == "stiffness":
+            raise NotImplementedError("Stiffness objective not implemented yet.")     # as the reference (:638)
         raise ValueError("Invalid objective function type.")
+
+    def _ratio_terms(self):
+        """displacement_ratio (lattice_opti.py:616-636, 1560-1621): mean displacement of the loaded dofs (the boundary
+        condition named "Load", under "Force" if there is a force block, else under "Displacement"), mean displacement of
+        the objective's dofs, and q = dJ/du of J = -(u_out u_in) on the nodes.  For one DOF per set - what the reference's
+        presets use - these are the reference's own coefficients (-u_in / n_out on the output nodes, -u_out / n_in on the
+        loaded ones); with several DOFs the reference divides by the node count only, which is not the derivative of its
+        mean over nodes x DOFs: here q is the derivative."""
+        bd = self.boundary_conditions
+        if bd.get("Force", None) is not None:
+            bd = bd["Force"]
+        elif bd.get("Displacement", None) is not None:
+            bd = bd["Displacement"]
+        else:
+            raise ValueError("No boundary conditions defined for displacement ratio objective.")
+        if "Load" not in bd:
+            raise ValueError('displacement_ratio needs a boundary condition named "Load" (lattice_opti.py:625)')
+        nodes_in = np.asarray(self._objective_nodes(bd["Load"]["Surface"]), dtype=np.int64)
+        nodes_out = np.asarray(self._objective_nodes(self.objectif_data["Surface"]), dtype=np.int64)
+        c_in = [_DOF[d] for d in bd["Load"]["DOF"]]
+        c_out = [_DOF[d] for d in self.objectif_data["DOF"]]
+        u = self.displacement_vector
+        u_in = float(np.mean(u[np.ix_(nodes_in, c_in)]))
+        u_out = float(np.mean(u[np.ix_(nodes_out, c_out)]))
+        q = np.zeros_like(u)
+        for k in c_out:
+            np.add.at(q, (nodes_out, k), -u_in / (len(nodes_out) * len(c_out)))
+        for k in c_in:
+            np.add.at(q, (nodes_in, k), -u_out / (len(nodes_in) * len(c_in)))
+        return u_in, u_out, q
 
     def objective(self, r):
         self.set_optimization_parameters(r)
@@ -285,6 +320,8 @@ class LatticeOpti(LatticeSim):
             for d in self.objectif_data["DOF"]:
                 q[nodes, _DOF[d]] += sign / cnt
             return dev.sens(u, self._adjoint(q))
+        if self.objective_type == "displacement_ratio":
+            return dev.sens(u, self._adjoint(self._ratio_terms()[2]))
         raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
 
     def _ddm_adjoint(self, q_nodes):
@@ -315,6 +352,8 @@ class LatticeOpti(LatticeSim):
             for d in self.objectif_data["DOF"]:
                 q[nodes, _DOF[d]] += sign / cnt
             Lam = self._ddm_adjoint(q)[cb].reshape(len(cb), -1)
+        elif self.objective_type == "displacement_ratio":
+            Lam = self._ddm_adjoint(self._ratio_terms()[2])[cb].reshape(len(cb), -1)
         else:
             raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
         G = len(self.geom_types)

@@ -61,11 +61,36 @@ def get_schur_complement(lattice, cell_index=None, rtol=1e-13, max_iter=200000):
         raise ValueError("The lattice must contain only one cell for Schur complement calculation or specify a "
                          "cell_index.")
     if lattice.get_number_cells() > 1:
-        raise NotImplementedError("cell_index on multi-cell lattices: build a one-cell LatticeSim instead")
+        # BeamModel(..., cell_index) meshes the struts and points listed in THAT cell (lattice_generation.py:104-175:
+        # cell.points_cell / cell.beams_cell - struts shared with a neighbour included, with the radius and the
+        # penalised end segments they have in the whole lattice); condensation on the cell's boundary nodes in
+        # Cell.define_node_order_to_simulate order (utils_schur.py:36-41)
+        dev, order = cell_device(lattice, int(cell_index))
+        with dev:
+            dev.assemble()
+            return dev.schur(order, rtol=rtol, max_iter=max_iter)
     order = node_order_to_simulate(lattice, 0)
     dev = lattice.device_model()
     dev.assemble()
     return dev.schur(order, rtol=rtol, max_iter=max_iter)
+
+
+def cell_device(lattice, cell_index):
+    """(HipLattice of the sub-lattice made of one cell's struts and nodes, boundary nodes of that cell in the
+    reference's simulation order, numbered inside the sub-lattice)."""
+    from ._capi import HipLattice
+    lat, pen = lattice.lattice, lattice.penalized
+    if not 0 <= cell_index < lat.n_cells:
+        raise IndexError("cell_index out of range")
+    struts = np.unique(lat.cell_beam_idx[lat.cell_beam_ptr[cell_index]:lat.cell_beam_ptr[cell_index + 1]])
+    struts = struts[lat.beam_radius[struts] > 0]                       # (lattice_generation.py:158)
+    nodes = np.unique(np.concatenate([lat.cell_node_idx[lat.cell_node_ptr[cell_index]:lat.cell_node_ptr[cell_index + 1]],
+                                      lat.beam_conn[struts].ravel()]))
+    local = np.full(lat.n_nodes, -1, np.int64)
+    local[nodes] = np.arange(len(nodes))
+    dev = HipLattice(lat.node_xyz[nodes], local[lat.beam_conn[struts]], lat.beam_radius[struts], pen.seg_len[struts],
+                     pen.seg_nsub[struts], lattice.young_modulus, lattice.poisson_ratio)
+    return dev, local[node_order_to_simulate(lattice, cell_index)]
 
 
 def define_path_schur_complement(lattice_object):

@@ -213,6 +213,12 @@ def gen_lattice_states():
         "bcchybrid1hybrid4_3x2x1_size": _preset(["BCC", "Hybrid1", "Hybrid4"], [0.05, 0.04, 0.03], (3, 2, 1),
                                                 cell_size=(1.5, 1.0, 0.7), bcs=CANTILEVER),
     }
+    # one lattice per remaining unit cell of src/pyLatticeDesign/geometries/ (the cells above cover BCC, Octet, Hybrid1,
+    # Hybrid4): pins the re-authored strut tables of pylatticedso_amd/geometries.py through the reference's own generator
+    for cell, r in (("Auxetic", 0.03), ("BCCZ", 0.05), ("Cubic", 0.05), ("Diamond", 0.04), ("Hybrid2", 0.04),
+                    ("Hybrid3", 0.03), ("Hybrid5", 0.03), ("Kelvin", 0.03), ("Octahedron", 0.04), ("OctahedronYZ", 0.04),
+                    ("OctahedronZ", 0.04), ("OctetExt", 0.03), ("Original", 0.03), ("Original2", 0.03)):
+        cases[f"{cell.lower()}_2x2x2"] = _preset([cell], [r], (2, 2, 2), bcs=CANTILEVER)
     only = [a[len("lattice_"):] for a in sys.argv[1:] if a.startswith("lattice_")]
     for name, preset in cases.items():
         if only and name not in only:
@@ -378,6 +384,59 @@ def gen_opti():
     np.savez_compressed(os.path.join(OUT, "opti_ddm.npz"), **res)
 
 
+def gen_opti_ratio():
+    """displacement_ratio objective of the reference's LatticeOpti (lattice_opti.py:616-636: J = -(u_out * u_in), u_in the
+    mean displacement of the loaded dofs, u_out of the objective's) and whatever its adjoint branch returns for it
+    (:843-902, 1560-1621), in DDM mode on a small mechanism-like BCC block: Xmin clamped, "Load" pushes Xmax in Z, the
+    output is Z on the Zmax face.  unit_cell and constant parameterisations, non-uniform parameter vector."""
+    from pyLatticeOpti.lattice_opti import LatticeOpti
+    ddm = {"enable_preconditioner": True, "preconditioner_type": "exact", "max_iterations": 200,
+           "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}
+    bcs = {"Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"],
+                                      "Value": [0, 0, 0, 0, 0, 0]}},
+           "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}
+    res = {}
+    for name, par in (("unit_cell_ratio", {"type": "unit_cell", "hybrid": False}),
+                      ("constant_ratio", {"type": "constant", "hybrid": False})):
+        preset = _preset(["BCC"], [0.05], (4, 2, 2), bcs=bcs, periodicity=False, ddm=ddm)
+        preset["optimization_informations"] = {
+            "objective_function": "min", "objective_type": "displacement_ratio", "max_iterations": 5,
+            "objective_data": {"Surface": ["Zmax"], "DOF": ["Z"]},
+            "optimization_parameters": par, "constraints": {"relative_density": {"value": 0.2}},
+            "enable_parameter_normalization": True, "simulation_type": "DDM", "enable_gradient_computing": True}
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(preset, f)
+        f.close()
+        try:
+            L = _quiet(LatticeOpti, f.name, verbose=0)
+        finally:
+            os.unlink(f.name)
+        _quiet(L._initialize_optimization_solver)
+        x0 = np.array(L.initial_parameters, dtype=float)
+        x = x0 + 0.15 * np.sin(1.0 + np.arange(len(x0)))
+        obj = _quiet(L.objective, list(x))
+        try:
+            grad = np.asarray(_quiet(L.gradient, list(x)), dtype=float)
+        except Exception as e:      # noqa: BLE001 - recorded: the reference's adjoint branch indexes by node id
+            print("reference gradient raised:", type(e).__name__, e)
+            grad = np.full(len(x), np.nan)
+        nodes_in = L.find_point_on_lattice_surface(surfaceNames=["Xmax"])
+        nodes_out = L.find_point_on_lattice_surface(surfaceNames=["Zmax"])
+        res[f"{name}_preset_json"] = np.array(json.dumps(preset))
+        res[f"{name}_x0"] = x0
+        res[f"{name}_x"] = x
+        res[f"{name}_objective_norm"] = np.array(obj)
+        res[f"{name}_objective"] = np.array(L.denorm_objective)
+        res[f"{name}_scale"] = np.array(L.initial_value_objective)
+        res[f"{name}_gradient"] = grad
+        res[f"{name}_u_in"] = np.array(np.mean([n.displacement_vector[2] for n in nodes_in]))
+        res[f"{name}_u_out"] = np.array(np.mean([n.displacement_vector[2] for n in nodes_out]))
+        res[f"{name}_cell_radii"] = np.array([c.radii for c in L.cells])
+        res[f"{name}_cell_pos"] = np.array([c.pos for c in L.cells])
+        print(f"opti {name}: n={len(x)} objective={L.denorm_objective:.6e} grad={grad}")
+    np.savez_compressed(os.path.join(OUT, "opti_ratio.npz"), **res)
+
+
 def gen_surrogate():
     """Surrogate Schur complements of the reference (lattice_sim.py:755-813,919-977,1020-1082) evaluated through its
     own reduced basis of the BCC cell: S(r) for the three surrogate kinds (inside, at and outside the training range),
@@ -426,9 +485,11 @@ def gen_greedy():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "opti", "surrogate", "greedy"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "opti", "opti_ratio", "surrogate", "greedy"]
     if "opti" in which:
         gen_opti()
+    if "opti_ratio" in which:
+        gen_opti_ratio()
     if "ddm_precond" in which:
         gen_ddm_preconditioned()
     if "greedy" in which:

@@ -184,6 +184,35 @@ def test_schur_complement_matches_dolfinx_golden(golden_dir, geom, name):
         assert _rel(S, G) < 1e-8, (geom, r)
 
 
+@pytest.mark.parametrize("name", ["bcc_2x2x2", "bcchybrid1_2x2x2", "bcc_3x2x2_gradradius"])
+def test_schur_complement_of_one_cell_of_a_multi_cell_lattice(golden_dir, name):
+    """get_schur_complement(lattice, cell_index) (utils_schur.py:22-41 with BeamModel(..., cell_index)): the cell's own
+    struts and nodes - penalised as they are in the WHOLE lattice - condensed on its boundary nodes.  Held to the oracle:
+    assembly of exactly those struts (closed-form condensation of their penalised, sub-meshed segments, which
+    tests/test_oracle_golden.py holds to the assembled sub-mesh) and a dense static condensation.  1e-8 relative
+    Frobenius."""
+    from pylatticedso_amd.utils_schur import node_order_to_simulate
+    _, L = _sim(golden_dir, name)
+    lat, pen = L.lattice, L.penalized
+    with pytest.raises(ValueError):
+        get_schur_complement(L)                                   # several cells and no cell_index: as the reference
+    for cell in (0, lat.n_cells - 1):
+        S = get_schur_complement(L, cell)
+        struts = np.unique(lat.cell_beam_idx[lat.cell_beam_ptr[cell]:lat.cell_beam_ptr[cell + 1]])
+        nodes = np.unique(lat.beam_conn[struts])
+        loc = np.full(lat.n_nodes, -1)
+        loc[nodes] = np.arange(len(nodes))
+        sc = np.array([O.condensed_beam(r, l, n, E, NU) for r, l, n in
+                       zip(lat.beam_radius[struts], pen.seg_len[struts], pen.seg_nsub[struts])])
+        K = O.assemble_condensed(lat.node_xyz[nodes], loc[lat.beam_conn[struts]], sc).toarray()
+        order = loc[node_order_to_simulate(L, cell)]
+        bd = (6 * order[:, None] + np.arange(6)).ravel()
+        Sref = O.schur_complement(K, bd)
+        assert S.shape == Sref.shape == (6 * len(order),) * 2
+        assert _rel(S, Sref) < 1e-8, (name, cell)
+        assert _rel(S, S.T) < 1e-9
+
+
 def test_schur_dataset_construction_flow(golden_dir, tmp_path, monkeypatch):
     """The reference's construct_schur_complement_dataset.py flow on the GPU: one LatticeSim, reset_cell_with_new_radii
     per sample, get_schur_complement, save / load of the dataset - against the reference's dolfinx dataset."""
