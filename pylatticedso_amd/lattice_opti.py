@@ -330,6 +330,8 @@ class LatticeOpti(LatticeSim):
         bn = self._boundary_nodes_by_index()
         fixed = self.fixed_DOF[bn]
         dev.set_bc(fixed, None, np.where(fixed, 0.0, q_nodes[bn]))
+        if getattr(self, "_ddm_precond", 0) == 2:
+            dev.assemble()       # pl_set_bc drops the factorised assembled-Schur preconditioner (it depends on the mask)
         lam_b, _ = dev.solve(rtol=1e-10, max_iter=max(2000, self.number_iteration_max or 0))
         lam = np.zeros_like(self.displacement_vector)
         lam[bn] = lam_b

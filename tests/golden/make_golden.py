@@ -415,13 +415,17 @@ def gen_opti_ratio():
         x0 = np.array(L.initial_parameters, dtype=float)
         x = x0 + 0.15 * np.sin(1.0 + np.arange(len(x0)))
         obj = _quiet(L.objective, list(x))
+        # (read the displacements BEFORE the gradient: the reference's adjoint CG drives its matvec through the nodes'
+        # displacement vectors and leaves its NaNs there)
+        nodes_in = L.find_point_on_lattice_surface(surfaceNames=["Xmax"])
+        nodes_out = L.find_point_on_lattice_surface(surfaceNames=["Zmax"])
+        u_in = np.mean([n.displacement_vector[2] for n in nodes_in])
+        u_out = np.mean([n.displacement_vector[2] for n in nodes_out])
         try:
             grad = np.asarray(_quiet(L.gradient, list(x)), dtype=float)
         except Exception as e:      # noqa: BLE001 - recorded: the reference's adjoint branch indexes by node id
             print("reference gradient raised:", type(e).__name__, e)
             grad = np.full(len(x), np.nan)
-        nodes_in = L.find_point_on_lattice_surface(surfaceNames=["Xmax"])
-        nodes_out = L.find_point_on_lattice_surface(surfaceNames=["Zmax"])
         res[f"{name}_preset_json"] = np.array(json.dumps(preset))
         res[f"{name}_x0"] = x0
         res[f"{name}_x"] = x
@@ -429,8 +433,8 @@ def gen_opti_ratio():
         res[f"{name}_objective"] = np.array(L.denorm_objective)
         res[f"{name}_scale"] = np.array(L.initial_value_objective)
         res[f"{name}_gradient"] = grad
-        res[f"{name}_u_in"] = np.array(np.mean([n.displacement_vector[2] for n in nodes_in]))
-        res[f"{name}_u_out"] = np.array(np.mean([n.displacement_vector[2] for n in nodes_out]))
+        res[f"{name}_u_in"] = np.array(u_in)
+        res[f"{name}_u_out"] = np.array(u_out)
         res[f"{name}_cell_radii"] = np.array([c.radii for c in L.cells])
         res[f"{name}_cell_pos"] = np.array([c.pos for c in L.cells])
         print(f"opti {name}: n={len(x)} objective={L.denorm_objective:.6e} grad={grad}")

@@ -204,7 +204,7 @@ def test_schur_complement_of_one_cell_of_a_multi_cell_lattice(golden_dir, name):
         loc[nodes] = np.arange(len(nodes))
         sc = np.array([O.condensed_beam(r, l, n, E, NU) for r, l, n in
                        zip(lat.beam_radius[struts], pen.seg_len[struts], pen.seg_nsub[struts])])
-        K = O.assemble_condensed(lat.node_xyz[nodes], loc[lat.beam_conn[struts]], sc).toarray()
+        K = O.assemble_condensed(lat.node_xyz[nodes], loc[lat.beam_conn[struts]], sc)
         order = loc[node_order_to_simulate(L, cell)]
         bd = (6 * order[:, None] + np.arange(6)).ravel()
         Sref = O.schur_complement(K, bd)
