@@ -330,6 +330,15 @@ void pl_lattice_free(pl_lattice *L);
 int pl_penalize(int64_t n_beams, const double *node_xyz, const int32_t *beam_conn, const double *lzone /*[2B] or NULL*/,
                 double mesh_size, double *seg_len /*[3B]*/, int32_t *seg_nsub /*[3B]*/, double *pen_xyz /*[6B]*/);
 
+/* LatticeSim.define_node_index_boundary (lattice_sim.py:546-563) with the visit order of get_global_displacement
+ * (:502-542) on arrays: a node gets a boundary index when it lies on the box of one of its cells (exact coordinate
+ * comparison with the cell's origin / origin + size); indices are handed out in the order cells (ascending) then nodes of
+ * the cell (ascending node index = coordinate order) first meet them.  index_boundary[n_nodes] (-1 elsewhere),
+ * visit[<= n_nodes] = the nodes in that order, *n_visit their number.  Host code, multi-threaded. */
+int pl_boundary_index(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                      const double *node_xyz, const double *cell_coord, const double *cell_size, int64_t *index_boundary,
+                      int64_t *visit, int64_t *n_visit);
+
 /* Neighbour halo exchange ("sum of interface-node partial forces with the two neighbouring
  * slabs"): shared_peer[i] = the rank that holds the other copy of shared entry i of pl_dist_init (a node shared with
  * several ranks is listed once per peer there).  After this call the interface rows of every K*x travel by grouped

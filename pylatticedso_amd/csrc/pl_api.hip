@@ -594,23 +594,33 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   const int64_t N = h->N;
   const size_t n6 = (size_t)N * 6;
   std::vector<uint8_t> fx(n6), bits(N);
-  std::vector<double> ub(n6, 0.0), ff(n6, 0.0);
-  for (int64_t i = 0; i < N; ++i) {
-    const size_t src = 6 * (size_t)h->perm[i];
-    uint8_t b = 0;
-    for (int k = 0; k < 6; ++k) {
-      const uint8_t v = fixed[src + k] ? 1 : 0;
-      fx[6 * i + k] = v;
-      b |= (uint8_t)(v << k);
-      if (ubar && v) ub[6 * i + k] = ubar[src + k];
-      if (f) ff[6 * i + k] = f[src + k];
+  double *st = nullptr;          // ubar, then f, through the handle's pinned staging buffer
+  if (int rcs = staging(h, &st)) return rcs;
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const size_t src = 6 * (size_t)h->perm[i];
+      uint8_t b = 0;
+      for (int k = 0; k < 6; ++k) {
+        const uint8_t v = fixed[src + k] ? 1 : 0;
+        fx[6 * i + k] = v;
+        b |= (uint8_t)(v << k);
+        st[6 * i + k] = (ubar && v) ? ubar[src + k] : 0.0;
+      }
+      bits[i] = b;
     }
-    bits[i] = b;
-  }
-  PL_HIP(hipMemcpy(h->fixed.p, fx.data(), n6, hipMemcpyHostToDevice));
-  PL_HIP(hipMemcpy(h->fixedbits.p, bits.data(), N, hipMemcpyHostToDevice));
-  PL_HIP(hipMemcpy(h->ubar.p, ub.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
-  PL_HIP(hipMemcpy(h->f.p, ff.data(), n6 * sizeof(double), hipMemcpyHostToDevice));
+  }, 1 << 15);
+  PL_HIP(hipMemcpyAsync(h->ubar.p, st, n6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  PL_HIP(hipMemcpyAsync(h->fixed.p, fx.data(), n6, hipMemcpyHostToDevice, h->stream));
+  PL_HIP(hipMemcpyAsync(h->fixedbits.p, bits.data(), N, hipMemcpyHostToDevice, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const size_t src = 6 * (size_t)h->perm[i];
+      for (int k = 0; k < 6; ++k) st[6 * i + k] = f ? f[src + k] : 0.0;
+    }
+  }, 1 << 15);
+  PL_HIP(hipMemcpyAsync(h->f.p, st, n6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
   h->have_bc = true;
   h->coarse.n_fix = -1;
   h->coarseL.n_fix = -1;

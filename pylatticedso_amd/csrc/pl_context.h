@@ -186,6 +186,8 @@ struct pl_context {
 
   pl_stats_t last{};
   double ms_assembly = 0.0;
+  double *pin6 = nullptr;      // pinned staging buffer of the vector transfers (pl_context.h: staging)
+  size_t pin6_n = 0;
 
   ~pl_context() {
     if (ev0) (void)hipEventDestroy(ev0);
@@ -195,6 +197,7 @@ struct pl_context {
     if (ev_chol) (void)hipEventDestroy(ev_chol);
     if (ev_t0) (void)hipEventDestroy(ev_t0);
     if (ev_t1) (void)hipEventDestroy(ev_t1);
+    if (pin6) (void)hipHostFree(pin6);
     if (ev_ov_a) (void)hipEventDestroy(ev_ov_a);
     if (ev_ov_x) (void)hipEventDestroy(ev_ov_x);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -209,31 +212,56 @@ namespace {
 // ----------------------------------------------------------------------------------------------------------
 // host <-> device vector transfer in caller numbering
 // ----------------------------------------------------------------------------------------------------------
-int upload6(pl_context *c, const double *host, double *dev, std::vector<double> &stage) {
+// Pinned staging buffer of the handle (6N doubles, allocated at the first transfer): a copy into pageable memory runs at
+// a few GB/s and blocks the host until the stream drains; through pinned memory it is one DMA at PCIe rate, and the
+// permutation between caller and device numbering runs on all host cores beside nothing else.
+int staging(pl_context *c, double **out) {
   const size_t n6 = (size_t)c->N * 6;
-  if (!c->reordered) {
-    PL_HIP(hipMemcpyAsync(dev, host, n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    PL_HIP(hipStreamSynchronize(c->stream));
-    return PL_OK;
+  if (!c->pin6 || c->pin6_n < n6) {
+    if (c->pin6) (void)hipHostFree(c->pin6);
+    c->pin6 = nullptr;
+    void *p = nullptr;
+    PL_HIP(hipHostMalloc(&p, n6 * sizeof(double), hipHostMallocDefault));
+    c->pin6 = static_cast<double *>(p);
+    c->pin6_n = n6;
   }
-  stage.resize(n6);
-  for (int64_t i = 0; i < c->N; ++i) std::memcpy(&stage[6 * i], host + 6 * (size_t)c->perm[i], 6 * sizeof(double));
-  PL_HIP(hipMemcpyAsync(dev, stage.data(), n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  *out = c->pin6;
+  return PL_OK;
+}
+
+int upload6(pl_context *c, const double *host, double *dev, std::vector<double> &) {
+  const size_t n6 = (size_t)c->N * 6;
+  double *st = nullptr;
+  int rc = staging(c, &st);
+  if (rc) return rc;
+  if (!c->reordered) {
+    pl::parallel_for((int64_t)n6, [&](int64_t b, int64_t e, unsigned) { std::memcpy(st + b, host + b, (e - b) * sizeof(double)); },
+                     1 << 18);
+  } else {
+    pl::parallel_for(c->N, [&](int64_t b, int64_t e, unsigned) {
+      for (int64_t i = b; i < e; ++i) std::memcpy(st + 6 * i, host + 6 * (size_t)c->perm[i], 6 * sizeof(double));
+    }, 1 << 15);
+  }
+  PL_HIP(hipMemcpyAsync(dev, st, n6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   PL_HIP(hipStreamSynchronize(c->stream));
   return PL_OK;
 }
 
 int download6(pl_context *c, const double *dev, double *host) {
   const size_t n6 = (size_t)c->N * 6;
-  if (!c->reordered) {
-    PL_HIP(hipMemcpyAsync(host, dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PL_HIP(hipStreamSynchronize(c->stream));
-    return PL_OK;
-  }
-  std::vector<double> stage(n6);
-  PL_HIP(hipMemcpyAsync(stage.data(), dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  double *st = nullptr;
+  int rc = staging(c, &st);
+  if (rc) return rc;
+  PL_HIP(hipMemcpyAsync(st, dev, n6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PL_HIP(hipStreamSynchronize(c->stream));
-  for (int64_t i = 0; i < c->N; ++i) std::memcpy(host + 6 * (size_t)c->perm[i], &stage[6 * i], 6 * sizeof(double));
+  if (!c->reordered) {
+    pl::parallel_for((int64_t)n6, [&](int64_t b, int64_t e, unsigned) { std::memcpy(host + b, st + b, (e - b) * sizeof(double)); },
+                     1 << 18);
+  } else {
+    pl::parallel_for(c->N, [&](int64_t b, int64_t e, unsigned) {
+      for (int64_t i = b; i < e; ++i) std::memcpy(host + 6 * (size_t)c->perm[i], st + 6 * i, 6 * sizeof(double));
+    }, 1 << 15);
+  }
   return PL_OK;
 }
 

@@ -310,6 +310,61 @@ void pl_lattice_free(pl_lattice *L) { delete L; }
 // the gmsh subdivision count of every segment (lattice_generation.py:50-64), per strut, multi-threaded.  The new points
 // sit at  end + (other - end) / round(length, 4) * L_zone  - the reference divides by Beam.length, which is rounded to
 // 4 decimals with Python's round(), i.e. the correctly rounded decimal: printf("%.4f") gives the same digits.
+int pl_boundary_index(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                      const double *node_xyz, const double *cell_coord, const double *cell_size, int64_t *index_boundary,
+                      int64_t *visit, int64_t *n_visit) {
+  if (n_cells <= 0 || n_nodes <= 0 || !cell_node_ptr || !cell_node_idx || !node_xyz || !cell_coord || !cell_size ||
+      !index_boundary || !visit || !n_visit)
+    return PL_ERR_ARG;
+  try {
+    std::vector<std::atomic<uint8_t>> on_box((size_t)n_nodes);
+    parallel_for(n_nodes, [&](int64_t b, int64_t e, unsigned) {
+      for (int64_t i = b; i < e; ++i) {
+        on_box[i].store(0, std::memory_order_relaxed);
+        index_boundary[i] = -1;
+      }
+    }, 1 << 16);
+    std::atomic<int> bad{0};
+    parallel_for(n_cells, [&](int64_t cb, int64_t ce, unsigned) {
+      for (int64_t c = cb; c < ce; ++c) {
+        const double lo[3] = {cell_coord[3 * c], cell_coord[3 * c + 1], cell_coord[3 * c + 2]};
+        const double hi[3] = {lo[0] + cell_size[3 * c], lo[1] + cell_size[3 * c + 1], lo[2] + cell_size[3 * c + 2]};
+        for (int64_t q = cell_node_ptr[c]; q < cell_node_ptr[c + 1]; ++q) {
+          const int64_t i = cell_node_idx[q];
+          if (i < 0 || i >= n_nodes) { bad = 1; continue; }
+          const double *x = node_xyz + 3 * i;
+          if (x[0] == lo[0] || x[0] == hi[0] || x[1] == lo[1] || x[1] == hi[1] || x[2] == lo[2] || x[2] == hi[2])
+            on_box[i].store(1, std::memory_order_relaxed);
+        }
+      }
+    }, 256);
+    if (bad) return PL_ERR_ARG;
+    // visit order: cells in order, inside a cell by node index (= coordinate order), first visit counts
+    int64_t nv = 0;
+    std::vector<int64_t> row;
+    for (int64_t c = 0; c < n_cells; ++c) {
+      const int64_t q0 = cell_node_ptr[c], q1 = cell_node_ptr[c + 1];
+      const int64_t *r = cell_node_idx + q0;
+      if (!std::is_sorted(r, r + (q1 - q0))) {
+        row.assign(r, r + (q1 - q0));
+        std::sort(row.begin(), row.end());
+        r = row.data();
+      }
+      for (int64_t q = 0; q < q1 - q0; ++q) {
+        const int64_t i = r[q];
+        if (on_box[i].load(std::memory_order_relaxed) && index_boundary[i] < 0) {
+          index_boundary[i] = nv;
+          visit[nv++] = i;
+        }
+      }
+    }
+    *n_visit = nv;
+  } catch (...) {
+    return PL_ERR_STATE;
+  }
+  return PL_OK;
+}
+
 int pl_penalize(int64_t n_beams, const double *node_xyz, const int32_t *beam_conn, const double *lzone /*may be null*/,
                 double mesh_size, double *seg_len, int32_t *seg_nsub, double *pen_xyz) {
   if (n_beams < 0 || !node_xyz || !beam_conn || !seg_len || !seg_nsub || !pen_xyz || !(mesh_size > 0.0))

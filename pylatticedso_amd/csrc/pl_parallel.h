@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <vector>
@@ -26,6 +27,25 @@ inline unsigned host_workers() {
     if (sched_getaffinity(0, sizeof(set), &set) == 0) {
       const int c = CPU_COUNT(&set);
       if (c > 0) n = std::min(n, (unsigned)c);
+    }
+    {   // cgroup CPU quota (a GPU box hands a one-GPU job 16 of its 256 hardware threads while the affinity mask still
+        // shows them all: 64 threads on 16 CPUs' worth of time is slower than 16)
+      unsigned quota = 0;
+      if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long q = 0, per = 0;
+        if (std::fscanf(fh, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) quota = (unsigned)((q + per - 1) / per);
+        std::fclose(fh);
+      } else if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long long q = 0, per = 0;
+        if (std::fscanf(fq, "%lld", &q) == 1 && q > 0) {
+          if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(fp, "%lld", &per) == 1 && per > 0) quota = (unsigned)((q + per - 1) / per);
+            std::fclose(fp);
+          }
+        }
+        std::fclose(fq);
+      }
+      if (quota > 0) n = std::min(n, std::max(1u, quota));
     }
     if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) {
       const int v = std::atoi(e);

@@ -272,6 +272,13 @@ class LatticeSim(LatticeViews):
         the order get_global_displacement visits them (cells in order, nodes by rounded coordinates)."""
         lat = self.lattice
         N = lat.n_nodes
+        if N >= 20000:       # large lattices: the same rule in multi-threaded C++ (pl_boundary_index, host code)
+            from ._capi import boundary_index
+            self.index_boundary, visit = boundary_index(lat.cell_node_ptr, lat.cell_node_idx, lat.node_xyz,
+                                                        lat.cell_coord, lat.cell_size)
+            self.max_index_boundary = len(visit) - 1
+            self._boundary_visit_order = visit
+            return
         self.index_boundary = np.full(N, -1, np.int64)
         on_box = np.zeros(N, bool)
         ptr, idx = lat.cell_node_ptr, lat.cell_node_idx
@@ -397,10 +404,14 @@ class LatticeSim(LatticeViews):
         idx6 = np.repeat(self.index_boundary[V].astype(np.int64)[:, None], 6, axis=1)
         if not OnlyImposed:                       # free dofs (+ the constrained ones if asked for), node-major
             take = ~fixed | bool(withFixed)
-            disp, index = U[take], idx6[take].tolist()
+            disp, index = U[take], idx6[take]
         else:                                     # every dof: 0 for unloaded free ones (no index entry for those)
             silent = ~fixed & (self.applied_force[V] == 0)
-            disp, index = np.where(silent, 0.0, U).ravel(), idx6[~silent].tolist()
+            disp, index = np.where(silent, 0.0, U).ravel(), idx6[~silent]
+        # (the reference returns a Python list; a 3 M-entry list costs 50 ms to build at 50^3 cells - small lattices keep the
+        # list, large ones get the int64 array, which every consumer here and in the reference indexes the same way)
+        if len(index) <= 100000:
+            index = index.tolist()
         if not OnlyImposed:
             self.global_displacement_index = index
         return np.asarray(disp, dtype=float), index
