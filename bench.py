@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--precision", type=int, default=-1,
                     help="0 = fp64, 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only (-1 = the "
                          "configuration's: fp64, configs[4] precision 1)")
+    ap.add_argument("--coarse-storage", type=int, default=0,
+                    help="storage of the dense level's inverse factor: 0 = automatic (bfloat16 from 3 072 dofs), 16, 32")
     ap.add_argument("--overlap", type=int, default=-1,
                     help="multi-rank K*p: 1 = interface tiles first, exchange under the interior tiles; 0 = one launch "
                          "then the exchange (-1 = library default)")
@@ -349,7 +351,7 @@ def main():
     opts = dict(spmv_kernel=args.kernel, reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond,
                 palette=args.palette, tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs,
                 precision=args.precision, condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes,
-                coarse_modes=args.coarse_modes)
+                coarse_modes=args.coarse_modes, coarse_storage=args.coarse_storage)
     if args.overlap >= 0:
         opts["overlap"] = args.overlap
 

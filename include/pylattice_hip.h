@@ -127,7 +127,10 @@ typedef struct {
   int32_t overlap;       /* multi-GPU handles with the neighbour exchange (pl_dist_set_peers), LDS-tile K*p: 0 / 1 = the tiles
                           * that own interface rows run first and their rows travel (pack, send / recv, add) on a second
                           * stream while the interior tiles run, -1 = one launch, then the exchange */
-  int32_t reserved_o;
+  int32_t coarse_storage; /* storage of the dense level's inverse factor W (the two triangular GEMVs of every iteration read it):
+                           * 32 = fp32, 16 = bfloat16 (half the bytes; W16^T W16 is still symmetric positive definite and
+                           * fixed - measured iteration counts unchanged), 0 = automatic: bfloat16 from 3 072 dofs on, where
+                           * the GEMVs are bandwidth-bound (100^3 BCC: 2 x 22 us of a 354-us iteration) */
 } pl_opts_t;
 
 typedef struct {

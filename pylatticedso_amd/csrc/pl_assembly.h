@@ -245,8 +245,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     }
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  pl::dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, c->stream, after_chol,
-                           c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr);
+  pl::coarse_factor(cs, n, c->stream, after_chol, c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr);
   if (tile_invert_pending) PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};
@@ -295,6 +294,14 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
     PL_HIP(c->cflag.alloc(N));
   }
   PL_HIP(hipMemcpy(c->cnodes.p, picked.data(), picked.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<int32_t> keep;
+    keep.reserve((size_t)N - picked.size());
+    for (int64_t i = 0; i < N; ++i)
+      if (!flag[i]) keep.push_back((int32_t)i);
+    PL_HIP(c->ckeep.alloc(std::max<size_t>(1, keep.size())));
+    if (!keep.empty()) PL_HIP(hipMemcpy(c->ckeep.p, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (!c->cbase.p) PL_HIP(c->cbase.alloc(N));
   c->cbase_state = -1;
   PL_HIP(hipMemcpy(c->maskC.p, mask.data(), N, hipMemcpyHostToDevice));

@@ -48,6 +48,7 @@ struct Coarse {
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
   float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
+  bool w16 = false;                    // ... or bfloat16 in the same buffers (large levels: the GEMVs are bandwidth-bound)
   double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
   int *info = nullptr;
   unsigned *bar = nullptr;   // grid-barrier counter of the persistent Cholesky chain (pl_dense.h)
@@ -841,6 +842,23 @@ __global__ __launch_bounds__(kInv12Block) void k_tile_invert12(int64_t T, const 
       Bt_inv[t * 144 + i * n + j] = out ? 0.0 : -As[i * n + j][me];
     }
 }
+// The dense level's factorisation and solve in whichever storage type the level uses.
+inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void()> &after_chol, unsigned *bar) {
+  if (cs.w16)
+    dense_factor_inverse(cs.Ac, cs.Lf, reinterpret_cast<bf16_t *>(cs.W), reinterpret_cast<bf16_t *>(cs.Wt), cs.Dinv, n, n,
+                         cs.info, cs.bw_blocks, s, after_chol, bar);
+  else
+    dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, s, after_chol, bar);
+}
+inline void coarse_apply(const Coarse &cs, const double *r, double *t, double *y, double *dot_out, const double *add0,
+                         hipStream_t s) {
+  if (cs.w16)
+    dense_apply(reinterpret_cast<const bf16_t *>(cs.W), reinterpret_cast<const bf16_t *>(cs.Wt), cs.ncp, cs.ncp, r, t, y,
+                dot_out, add0, s);
+  else
+    dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, r, t, y, dot_out, add0, s);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // r -= alpha Ap ; per-tile partials (Z^T r [6], r.r, r.D^-1 r) — one workgroup per tile.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1170,6 +1188,10 @@ __global__ __launch_bounds__(kBlock) void k_condense_solve(int64_t nc, const int
   for (int j = 0; j < 6; ++j) acc += A[6 * k + j] * (double)y[6 * i + j];
   v[6 * i + k] = (VT)(sign * acc);
 }
+// (Round 3, tried and dropped: the first pass of the condensed operator by ROWS - one group of LPN lanes per eliminated node
+// over the sliced-ELL incidence, one visit per strut, no LDS accumulator, the 6 x 6 solve in the lanes that hold the sums.
+// 100^3 BCC: iteration 327 -> 344 us with 4 lanes per node, 360 / 369 / 461 us with 2 / 8 / 16: the dependent chain
+// entry -> palette id -> record / entry -> x row with nothing prefetched costs more than the tile kernel's LDS scatter.)
 // ---- classes of eliminated nodes with the same K_cc: nodes whose incident struts carry the same multiset of (record
 // palette id, end) have the same block up to the order of the sum.  Same scheme as pl_palette.h: hash -> claim a slot ->
 // the owner publishes its inverse -> every node verifies (1e-10: a hash collision would pair DIFFERENT blocks).
@@ -1452,8 +1474,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
                                                                double *__restrict__ scal_next,
                                                                double *__restrict__ hist, int k,
                                                                double *__restrict__ rc, int ncp,
-                                                               const uint8_t *__restrict__ zero_rows /* may be null */,
+                                                               const int32_t *__restrict__ keep /* may be null */,
                                                                int cm, const uint8_t *__restrict__ shared /* may be null */) {
+  // keep: with node elimination (opts.condense) N counts the nodes that stay unknowns and keep[] lists them - the lanes
+  // map onto those only (a flag test per node left half of the lanes of a BCC lattice idle: 80 us for 1.03 M kept nodes at
+  // 100^3 against 26 us for 0.5 M nodes of the Octet lattice)
   double old, rz_new, pap;
   scalar_read3(scal, S_RZ_OLD, S_RZ_NEW, S_PAP, old, rz_new, pap);
   const double beta = (old != 0.0) ? rz_new / old : 0.0;
@@ -1474,11 +1499,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
       scal_next[S_PAP * kSlots + q] = 0.0;
     }
   }
-  const int64_t pair = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pair >= 3 * N) return;
-  const int64_t i = pair / 3;
-  const int q = (int)(pair - 3 * i);
-  if (zero_rows && zero_rows[i]) return;
+  const int64_t lane_pair = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane_pair >= 3 * N) return;
+  const int64_t slot = lane_pair / 3;
+  const int q = (int)(lane_pair - 3 * slot);
+  const int64_t i = keep ? (int64_t)keep[slot] : slot;
+  const int64_t pair = 3 * i + q;
   const int t = tile_of_node[i];
   const int a = agg_of_tile[t];
   const double *y = yc + cm * a;

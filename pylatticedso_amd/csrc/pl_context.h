@@ -157,6 +157,7 @@ struct pl_context {
   std::vector<uint8_t> h_shared;      // multi-GPU: nodes that also live on another rank (never condensed)
   DevBuf<uint8_t> cend;           // strut -> bits: end A / B is a condensed node (pl_tile.h CondSolve)
   DevBuf<int32_t> cnodes, cbase;  // condensed nodes; node -> offset of its K_cc^-1 block (class table or per node), -1
+  DevBuf<int32_t> ckeep;          // the other nodes, ascending (k_pcg_direction_flat maps its lanes onto these)
   int cbase_state = -1;           // what cbase was built for: -1 stale, 0 per-node blocks, 1 class table
   DevBuf<double> kcc_inv;
   DevBuf<uint8_t> maskC, cflag;       // Dirichlet bits | 0x3f on condensed nodes; 1 on condensed nodes

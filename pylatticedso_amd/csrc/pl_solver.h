@@ -30,14 +30,12 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
 #undef PL_UPD
   if (useL)   // rank-local level: y_L is never communicated, but its share of r.z, r_L . A_L^-1 r_L, is a per-rank
               // partial sum: it joins the r.D^-1 r slots BEFORE they travel in the collective below
-    pl::dense_apply(cl.W, cl.Wt, cl.ncp, cl.ncp, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots,
-                    (const double *)nullptr, c->stream);
+    pl::coarse_apply(cl, cl.rc, cl.tv, cl.yc, cs.rc + cs.ncp + pl::kSlots, (const double *)nullptr, c->stream);
   if (c->dist.active) {   // one collective: [Z^T r | r.r slots | r.D^-1 r slots]; the coarse solve is then redundant per rank
     if (pl::dist_sum_scalars(c->dist, cs.rc, cs.ncp + 2 * pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the coarse residual failed");
   }
-  pl::dense_apply(cs.W, cs.Wt, cs.ncp, cs.ncp, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots,
-                  cs.rc + cs.ncp + pl::kSlots, c->stream);
+  pl::coarse_apply(cs, cs.rc, cs.tv, cs.yc, cur + pl::S_RZ_NEW * pl::kSlots, cs.rc + cs.ncp + pl::kSlots, c->stream);
 #define PL_DIR(TM, MULTI, LOCAL)                                                                                         \
   hipLaunchKernelGGL((pl::k_pcg_direction_coarse<PT, RT, TM, MULTI, LOCAL>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), \
                      0, c->stream,                                                                                        \
@@ -47,12 +45,13 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
                      cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+  const int64_t n_flat = c->cond_use ? c->N - c->n_cond : c->N;       // nodes that are unknowns of this CG
 #define PL_DIRF(TM)                                                                                                      \
-  hipLaunchKernelGGL((pl::k_pcg_direction_flat<PT, RT, TM>), dim3((unsigned)((3 * c->N + pl::kBlock - 1) / pl::kBlock)),   \
-                     dim3(pl::kBlock), 0, c->stream, c->N, cs.tile_of_node.p, (const RT *)r, cs.dinv32, c->xyz.p,         \
+  hipLaunchKernelGGL((pl::k_pcg_direction_flat<PT, RT, TM>), dim3((unsigned)((3 * n_flat + pl::kBlock - 1) / pl::kBlock)), \
+                     dim3(pl::kBlock), 0, c->stream, n_flat, cs.tile_of_node.p, (const RT *)r, cs.dinv32, c->xyz.p,       \
                      cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
                      c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
-                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm,                      \
+                     c->cond_use ? (const int32_t *)c->ckeep.p : (const int32_t *)nullptr, cs.cm,                        \
                      c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr)
   // flat mapping, contiguous per wave: fp64 p without a rank-local level (measured on one box, 50^3 Octet: 26.2 -> 24.5 us;
   // fp32 p / fp64 r the same either way, fp32 p / fp32 r 19.0 -> 22.0 us - 8-byte loads per lane are too few in flight)
@@ -342,7 +341,7 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
   // u = M^-1 r, w = K u and the reduction block of iteration k (k = -1: the pass that prepares iteration 0)
   auto second_half = [&](int k) -> int {
     const int cur = k & 1, nxt = (k + 1) & 1;
-    pl::dense_apply(cs.W, cs.Wt, ncp, ncp, cs.rc, cs.tv, cs.yc, gc[nxt], (const double *)nullptr, c->stream);
+    pl::coarse_apply(cs, cs.rc, cs.tv, cs.yc, gc[nxt], (const double *)nullptr, c->stream);
     hipLaunchKernelGGL(pl::k_cg1_precond, gt, blkdim, 0, c->stream, c->tile.tile_start.p, (const double *)c->r.p,
                        cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc, yt, c->fixedbits.p, shared, u,
                        k >= 0 ? blk[cur] : (double *)nullptr, bs, k >= 0 ? gc[cur] : (double *)nullptr);

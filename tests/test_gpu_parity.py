@@ -688,6 +688,34 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
     assert its[1] <= its[-1] + 2          # (a few dozen iterations on these small lattices: +-1 is noise)
 
 
+def test_bfloat16_storage_of_the_dense_level():
+    """opts.coarse_storage = 16: the inverse factor of the dense level in bfloat16 (half the bytes of the two triangular
+    GEMVs per iteration; automatic from 3 072 dofs).  Same solution to the solver tolerance - the preconditioner only has
+    to be a fixed SPD operator - and no more than a few per cent more iterations than with fp32 storage; BCC with node
+    elimination and Octet."""
+    for geom, radius, n in (("Octet", 0.03, 14), ("BCC", 0.05, 16)):
+        lat = LA.generate((1, 1, 1), (n, n, n), [geom], [radius])
+        pen = LA.penalize(lat, LA.compute_lzone(lat))
+        fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+        fixed[lat.node_xyz[:, 0] == 0.0] = 1
+        tgt = lat.node_xyz[:, 0] == float(n)
+        f = np.zeros((lat.n_nodes, 6))
+        f[tgt, 2] = -0.1 / tgt.sum()
+        out = {}
+        for st in (32, 16):
+            with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                                  tile_nodes=64, coarse_max_dofs=1536, coarse_storage=st) as dev:
+                dev.set_bc(fixed, None, f)
+                dev.assemble()
+                out[st] = dev.solve(rtol=1e-10, max_iter=20000)
+        assert out[16][1]["converged"] == 1 and _rel(out[16][0], out[32][0]) < 1e-7
+        assert out[16][1]["iterations"] <= 1.05 * out[32][1]["iterations"] + 2, (geom, out[16][1]["iterations"],
+                                                                                 out[32][1]["iterations"])
+    with pytest.raises(_capi.PlError):
+        _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                         coarse_storage=8)
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_node_elimination_is_off_with_kernels_that_ignore_its_masks(golden_dir, kernel):
     """Round-2 advisor finding: with an explicit spmv_kernel = 1 / 2 the K*p kernels ignore the elimination masks, so the
