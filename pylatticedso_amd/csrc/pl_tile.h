@@ -298,6 +298,21 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
                                            const Record *__restrict__ rec,
                                            const double *__restrict__ xyz, const uint8_t *__restrict__ cflag,
                                            const VT *__restrict__ x, double *ys, int stride, AfterLoads &&after_loads) {
+  constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
+  bool takeB = c.y >= n0 && c.y < n1, takeA = c.x >= n0 && c.x < n1;
+  // (pid carries the strut's condensed-end bits above the palette id: CondSolve::cend)
+  const bool cA = ENDS != kEndsAll && ((pid >> 16) & 1u), cB = ENDS != kEndsAll && ((pid >> 17) & 1u);
+  if (ENDS != kEndsAll) {
+    takeB = takeB && (cB == kToCondensed);
+    takeA = takeA && (cA == kToCondensed);
+    // a pass over one kind of strut ends: the tile that does not own an end of that kind has nothing to take from this
+    // visit (bipartite lattices: every strut has one end of each kind, so 20-25 % of the visits of either pass) - known
+    // from the indices alone, before any gather is requested
+    if (!(takeA || takeB)) {
+      after_loads();
+      return;
+    }
+  }
   Record r;
   if (REC == kRecCompact) {
     const Rec5 q = reinterpret_cast<const Rec5 *>(rec)[b];
@@ -308,18 +323,10 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
     r = (REC == kRecPalette) ? load_record(rec, pid & 0xFFFFu) : load_record(rec, b);
   }
   V3 uA = {0, 0, 0}, tA = {0, 0, 0}, uB = {0, 0, 0}, tB = {0, 0, 0}, F, M;
-  constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
-  bool takeB = c.y >= n0 && c.y < n1, takeA = c.x >= n0 && c.x < n1;
-  // (pid carries the strut's condensed-end bits above the palette id: CondSolve::cend)
-  const bool cA = ENDS != kEndsAll && ((pid >> 16) & 1u), cB = ENDS != kEndsAll && ((pid >> 17) & 1u);
   // a condensed end's own row is being rewritten by its tile in the fused first pass: it counts as zero and is not read
   if (!(ENDS == kEndsCondensedSolve && cA)) load6(x + 6 * (int64_t)c.x, uA, tA);
   if (!(ENDS == kEndsCondensedSolve && cB)) load6(x + 6 * (int64_t)c.y, uB, tB);
   after_loads();
-  if (ENDS != kEndsAll) {
-    takeB = takeB && (cB == kToCondensed);
-    takeA = takeA && (cA == kToCondensed);
-  }
   tip_force(r, uA, tA, uB, tB, F, M);
   if (takeB) lds_add6(ys + (c.y - n0), stride, F, M);
   if (takeA) {
