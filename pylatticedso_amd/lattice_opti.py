@@ -59,8 +59,6 @@ class LatticeOpti(LatticeSim):
         self._history = {"iteration": [], "objective_norm": [], "objective": [], "relative_density": [],
                          "parameters": [], "timestamp": []}
         lat = self.lattice
-        self.size_x, self.size_y, self.size_z = (self.x_max - self.x_min, self.y_max - self.y_min,
-                                                 self.z_max - self.z_min)
         self._get_optimization_parameters(name_file)
         self._set_number_parameters_optimization()
         # strut -> (cell, type) of the LAST cell that holds it: Cell.change_beam_radius (cell.py:896-917) is called

@@ -265,6 +265,23 @@ class LatticeSim(LatticeViews):
         self.penalized = LA.penalize(self.lattice, self.lzone)
         self.is_penalized = True
 
+    def reset_penalized_beams(self) -> None:
+        """lattice_sim.py:313-400: undo set_penalized_beams - every strut is one segment again, the penalisation points
+        go away (the design struts and nodes were never replaced here, so nothing has to be rewired); a device handle
+        built for the penalised model is dropped."""
+        if not self.is_penalized:
+            print("Warning: lattice does not appear to be penalized.")
+            return
+        self.lzone = np.zeros((self.lattice.n_beams, 2))
+        self.penalized = LA.penalize(self.lattice, None)
+        self.is_penalized = False
+        if self._device is not None:
+            self._device.close()
+            self._device = None
+        for name in ("_view_tables", "_node_mod_store"):
+            if hasattr(self, name):
+                delattr(self, name)
+
     @timing.category("simulation")
     @timing.timeit
     def define_node_index_boundary(self):
@@ -691,3 +708,28 @@ class LatticeSim(LatticeViews):
         nodes = np.flatnonzero(self.index_boundary >= 0)
         bn[self.index_boundary[nodes]] = nodes
         return bn
+
+
+# -- design-side attributes of the reference's base class (lattice.py:58-60, 346-385), for every class on the array model
+def _design_properties(cls):
+    from statistics import mean
+    cls.size_x = property(lambda self: float(self.x_max - self.x_min))
+    cls.size_y = property(lambda self: float(self.y_max - self.y_min))
+    cls.size_z = property(lambda self: float(self.z_max - self.z_min))
+
+    def get_relative_density(self) -> float:
+        """Mean of the cells' relative densities (lattice.py:346-360)."""
+        return float(mean(c.relative_density for c in self.cells))
+
+    def get_beam_radius_min_max(self):
+        r = self.lattice.beam_radius
+        return float(r.max()), float(r.min())
+
+    def getName(self):
+        return getattr(self, "name_lattice", "lattice")
+    cls.get_relative_density = get_relative_density
+    cls.get_beam_radius_min_max = get_beam_radius_min_max
+    cls.getName = getName
+
+
+_design_properties(LatticeSim)

@@ -42,3 +42,34 @@ class LatticePlotting:
             plt.close(fig)
             return path
         plt.show()
+
+    def subplot_lattice_hybrid_geometries(self, lattice, explode_voxel: float = 0.0, file_save_path=None):
+        """One panel per geometry of a hybrid lattice, struts coloured by radius (plotting_lattice.py:637-700)."""
+        import matplotlib
+        if not os.environ.get("DISPLAY"):
+            matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        from mpl_toolkits.mplot3d.art3d import Line3DCollection
+        lat = lattice.lattice
+        geoms = list(lattice.geom_types)
+        if len(geoms) <= 1:
+            print("Lattice is not hybrid; only one geometry type found.")
+        fig = plt.figure(figsize=(5 * len(geoms), 5))
+        for g, name in enumerate(geoms):
+            ax = fig.add_subplot(1, len(geoms), g + 1, projection="3d")
+            sel = lat.beam_type == g
+            col = Line3DCollection(lat.node_xyz[lat.beam_conn[sel]], linewidths=0.6, cmap="viridis")
+            col.set_array(lat.beam_radius[sel])
+            col.set_clim(0.025, 0.1)
+            ax.add_collection3d(col)
+            ax.set_xlim(lattice.x_min, lattice.x_max)
+            ax.set_ylim(lattice.y_min, lattice.y_max)
+            ax.set_zlim(lattice.z_min, lattice.z_max)
+            ax.set_title(str(name))
+        if matplotlib.get_backend().lower() == "agg" or file_save_path:
+            os.makedirs(self.out_dir, exist_ok=True)
+            path = file_save_path or os.path.join(self.out_dir, "lattice_hybrid_geometries.png")
+            fig.savefig(path, dpi=120)
+            plt.close(fig)
+            return path
+        plt.show()
