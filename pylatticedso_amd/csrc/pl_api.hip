@@ -1195,6 +1195,13 @@ int pl_lzone(int device, int64_t n_nodes, int64_t n_beams, const double *node_xy
   return PL_OK;
 }
 
+#ifdef PL_TILE_STAMPS
+// experiment builds only (not in the header): the clock stamps of the last tile K*p launch, out[8 * 4096]
+int pl_debug_tile_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pl::g_tile_stamps), sizeof(unsigned long long) * 8 * 4096) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int pl_dist_unique_id_bytes(void) { return pl::dist_unique_id_bytes(); }
 int pl_dist_unique_id(void *id_out) {
   if (!id_out) return fail(PL_ERR_ARG, "pl_dist_unique_id: null argument");

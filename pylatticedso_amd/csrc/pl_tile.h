@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -343,6 +345,17 @@ __device__ __forceinline__ void tile_strut(int64_t b, const int2 c, const unsign
 #define PL_TILE_BLOCK 512
 #endif
 constexpr int kTileBlock = PL_TILE_BLOCK;
+// -DPL_TILE_STAMPS: thread 0 of the first 4096 workgroups of the tile K*p records the constant-rate clock (100 MHz) at five
+// points of its life; pl_debug_tile_stamps() reads them (tools/experiments/tile_stamps.py).  Experiment builds only.
+#ifdef PL_TILE_STAMPS
+__device__ unsigned long long g_tile_stamps[8 * 4096];
+#define PL_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_tile_stamps[8 * blockIdx.x + (k)] = wall_clock64();   \
+  } while (0)
+#else
+#define PL_STAMP(k) do { } while (0)
+#endif
 // VT = storage type of x and y (double, or float for the fp32 solver modes: the strut forces are still evaluated
 // and accumulated in fp64 - the forces on a node nearly cancel for the smooth fields a solve is made of, so rounding
 // them to fp32 before the sum would cost cond(K) * 6e-8, rounding the stored result costs 6e-8).
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   __shared__ int32_t sbase[ENDS == kEndsCondensedSolve ? kTileMaxNodes : 1];
   // tile_list: a launch over a subset of the tiles (multi-GPU overlap: the tiles that own interface rows first, the
   // exchange under the others) - ascending tile numbers, so the XCD mapping keeps its contiguous eighths
+  PL_STAMP(0);
   unsigned t = xcd_block(blockIdx.x, gridDim.x);
   if (tile_list) t = (unsigned)tile_list[t];
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
@@ -373,6 +387,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
   if (ENDS == kEndsCondensedSolve)           // fetched now, needed after the strut loops: no dependent load in the tail
     for (int i = threadIdx.x; i < nn; i += kTileBlock) sbase[i] = cs.base[n0 + i];
   __syncthreads();
+  PL_STAMP(1);
   // A thread makes 2-3 visits per tile, each a chain of two memory hops (conn -> x rows, palette id -> record) before
   // the arithmetic.  The first hop of the NEXT visit (10 bytes) is requested right AFTER the current visit's second hop
   // (tile_strut's after_loads), so only a thread's first visit pays both (SQ counters: the waves of this kernel spent 52 %
@@ -391,6 +406,7 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     if (REC == kRecPalette) pid = pal[b];
     if (ENDS != kEndsAll) pid |= (unsigned)cs.cend[b] << 16;
   }
+  PL_STAMP(2);
   while (live) {
     // next visit: the following home strut, else this thread's first / next foreign one
     int64_t bn = b;
@@ -420,7 +436,9 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     home = home_n;
     live = live_n;
   }
+  PL_STAMP(3);
   __syncthreads();
+  PL_STAMP(4);
   if (ENDS == kEndsCondensedSolve) {
     for (int i = threadIdx.x; i < nn * 6; i += kTileBlock) {
       const int node = i / 6, k = i - 6 * node;
@@ -460,8 +478,17 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
       for (int q = 0; q < kTileBlock / kWave; ++q) s += red[q];
     if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
   }
+  PL_STAMP(5);
 }
 
+// (Round 3, tried and dropped: PERSISTENT workgroups - each walks several tiles of its XCD's eighth, the LDS accumulator
+// cleared once (the epilogue zeroes what it reads), the next tile's first visit requested before the barrier and the
+// epilogue of the current one, the fused dot reduced once per workgroup, 32-bit strut ids to stay at 64 VGPRs / 8 waves.
+// In-kernel clock stamps of the kernel above (tools/experiments/tile_stamps.py, 50^3 Octet, palette) had shown a workgroup
+// living 9.3 us of which 1.0 us clear + barrier, 0.8 us until the first visit's indices are requested, 5.2 us strut loop,
+// 1.2 us barrier + epilogue.  Measured: 848 workgroups of 4 tiles each 49.3 us, 1 024 of 3-4 tiles 43.3 us, 2 048 of 1-2
+// tiles 41.7 us against 40.8 us of one tile per workgroup, with or without the prefetch: the per-workgroup overheads are
+// already hidden behind the other resident workgroups' strut loops, and workgroups in lockstep hide them worse.)
 // pal != nullptr: `rec` is the palette table and pal[b] the strut's entry; xyz != nullptr: `rec` is the compact
 // 5-scalar table (Rec5) and the strut vectors come from the node coordinates.  ends / cflag: see tile_strut.
 template <typename VT>
@@ -470,7 +497,8 @@ inline void launch_tile_spmv(const TilePlan &plan, const int32_t *conn, const Re
                              const double *xyz = nullptr, int ends = kEndsAll, const uint8_t *cflag = nullptr,
                              CondSolve cs = CondSolve(), const int32_t *tile_list = nullptr, int64_t n_list = 0) {
   if (tile_list && n_list <= 0) return;
-  const dim3 g((unsigned)(tile_list ? n_list : plan.n_tiles)), blk(kTileBlock);
+  const int64_t n_units = tile_list ? n_list : plan.n_tiles;
+  const dim3 g((unsigned)n_units), blk(kTileBlock);
   const int stride = plan.max_nodes | 1;                             // odd pitch of the component-major accumulator
   const size_t lds = (size_t)stride * 6 * sizeof(double);            // sized by the largest tile: more resident waves
   const int2 *conn2 = reinterpret_cast<const int2 *>(conn);
