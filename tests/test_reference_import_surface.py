@@ -51,3 +51,41 @@ def test_simulation_example_end_to_end(tmp_path):
     assert np.abs(disp[166:]).max() > 0.1 * np.abs(disp[:166]).max()       # node_mod points carry real displacements
     radius = np.array([float(v) for v in txt[txt.index("SCALARS radius double 1") + 2:][:1288]])
     assert set(np.round(radius, 12)) == {0.1, 0.15}
+    # the same data as VTU + PVD (what the reference's dolfinx VTKFile writes), plus the reference's per-element (DG0) fields:
+    # local frame, section forces and moments in it
+    ex2 = exportSimulationResults(model, "t2", out_dir=str(tmp_path))
+    ex2.full_export()
+    import xml.etree.ElementTree as ET
+    pvd = ET.parse(ex2.pvd_path).getroot()
+    vtu_name = pvd.find("Collection/DataSet").attrib["file"]
+    piece = ET.parse(str(tmp_path / vtu_name)).getroot().find("UnstructuredGrid/Piece")
+    assert piece.attrib == {"NumberOfPoints": "1022", "NumberOfCells": "1288"}
+    cell = {d.attrib["Name"]: np.array(d.text.split(), float).reshape(1288, -1) for d in piece.find("CellData")}
+    assert {"radius", "beam_mod", "type_beam", "Moment", "Forces", "a1", "a2", "t"} <= set(cell)
+    tt, a1, a2 = cell["t"], cell["a1"], cell["a2"]
+    assert np.allclose(np.einsum("ij,ij->i", tt, a1), 0, atol=1e-12) and np.allclose(np.cross(tt, a1), a2, atol=1e-12)
+    # section forces against the oracle's element: for every design strut the end force of the condensed element, rotated
+    # into the local frame of its middle segment
+    from oracle import timoshenko_oracle as O
+    from pylatticedso_amd.views import _tables
+    lat, pen, t = L.lattice, L.penalized, _tables(L)
+    mid = np.flatnonzero(~t.beam_mod)                                   # the un-penalised (middle) segments
+    par = t.beam_parent[mid]
+    worst = 0.0
+    for k in range(0, len(mid), 37):
+        b = par[k]
+        A, B = lat.beam_conn[b]
+        sc = O.condensed_beam(lat.beam_radius[b], pen.seg_len[b], pen.seg_nsub[b], L.young_modulus, L.poisson_ratio)
+        d = lat.node_xyz[B] - lat.node_xyz[A]
+        fA, fB = O.beam_apply(sc, d, model.u[A], model.u[B])
+        sgn = np.sign(tt[mid[k]] @ d)
+        F_loc = sgn * np.array([fB[:3] @ tt[mid[k]], fB[:3] @ a1[mid[k]], fB[:3] @ a2[mid[k]]])
+        worst = max(worst, np.abs(F_loc - cell["Forces"][mid[k]]).max() / max(np.abs(cell["Forces"]).max(), 1e-300))
+    assert worst < 1e-9
+    # free lattice nodes are in equilibrium: the section forces of the segments meeting there cancel (global components)
+    Fg = cell["Forces"][:, :1] * tt + cell["Forces"][:, 1:2] * a1 + cell["Forces"][:, 2:3] * a2
+    net = np.zeros((1022, 3))
+    np.add.at(net, t.beam_conn[:, 1], Fg)           # +t side of the cut at the segment's second node ...
+    np.add.at(net, t.beam_conn[:, 0], -Fg)          # ... -t side at its first
+    free = ~L.fixed_DOF[:, :3].any(axis=1) & ~(L.applied_force[:, :3] != 0).any(axis=1)
+    assert np.abs(net[:166][free]).max() < 1e-8 * np.abs(Fg).max()
