@@ -773,6 +773,8 @@ int pl_assemble(pl_handle h) {
     rc_fill = launch_bsr_fill(h, h->bsr_with_bc, h->side);
     if (hipEventRecord(h->ev_join, h->side) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
   };
+  // (round 3, tried: the fill queued HERE, beside the tile-block front of the assembly instead of behind the chain's last
+  // link: assembly 2.27 -> 2.46 ms in two alternating pairs of runs - it slows the front and the first links)
   PL_HIP(hipEventRecord(h->ev_join, h->side));
   rc = build_coarse(h, h->coarse.enabled && h->have_bc ? std::function<void()>(queue_fill) : std::function<void()>());
   if (rc) return rc;
