@@ -296,6 +296,9 @@ int pl_dist_unique_id(void *id_out);
  * test_gpu_loopback.py); it also serves to run several sub-domains on one GPU.  A rank that never arrives at a
  * collective makes the others fail with PL_ERR_HIP after 120 s instead of hanging. */
 int pl_dist_loopback_id(void *id_out);
+/* Loopback groups only (no-op otherwise): declare the group broken, so that ranks waiting at a collective return
+ * PL_ERR_HIP at once - what a driver calls when one of its rank threads failed outside a collective. */
+int pl_dist_abort(pl_handle h);
 /* Attach this handle (one per rank/GPU) to a communicator.  shared_nodes lists, for each node of THIS rank's
  * sub-lattice that also exists on other ranks, its local index and a global id (dense 0..n_shared_global-1);
  * partial forces on those nodes are summed across ranks after every local K*x. */

@@ -23,7 +23,7 @@ EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version",
            "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
-           "pl_dist_unique_id", "pl_dist_loopback_id", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
+           "pl_dist_unique_id", "pl_dist_loopback_id", "pl_dist_abort", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
            "pl_lattice_free", "pl_penalize", "pl_boundary_index"]
 
 
@@ -90,7 +90,7 @@ def load_library(path: str | None = None):
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V], "pl_node_mod": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
-           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V], "pl_dist_loopback_id": [V],
+           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V], "pl_dist_loopback_id": [V], "pl_dist_abort": [V],
            "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V],
            "pl_generate_lattice": [I64, V, V, V, I32, I32, V, V, V, V], "pl_lattice_fetch": [V] * 12,
            "pl_lattice_free": [V], "pl_penalize": [I64, V, V, V, D, V, V, V],
@@ -458,6 +458,11 @@ class HipLattice:
         buf = C.create_string_buffer(lib.pl_dist_unique_id_bytes())
         _check(lib, lib.pl_dist_loopback_id(buf))
         return buf.raw
+
+    def dist_abort(self):
+        """Break this handle's loopback group (ranks waiting at a collective return an error at once)."""
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pl_dist_abort(self._h)
 
     def dist_init(self, rank, world, unique_id: bytes, shared_local, shared_global, n_shared_global, shared_peer=None):
         """Attach the handle to the RCCL communicator; ``shared_peer`` (rank on the other side of every shared entry)

@@ -1246,6 +1246,16 @@ int pl_dist_init(pl_handle h, int rank, int world, const void *unique_id, const 
   return PL_OK;
 }
 
+int pl_dist_abort(pl_handle h) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_dist_abort: null handle");
+  if (h->dist.loop) {
+    std::lock_guard<std::mutex> lk(h->dist.loop->m);
+    h->dist.loop->broken = true;
+    h->dist.loop->cv.notify_all();
+  }
+  return PL_OK;
+}
+
 int pl_dist_set_peers(pl_handle h, const int32_t *shared_peer) {
   if (!valid(h) || !shared_peer) return fail(PL_ERR_ARG, "pl_dist_set_peers: null argument");
   if (!h->dist.active) return fail(PL_ERR_STATE, "pl_dist_set_peers: call pl_dist_init first");

@@ -75,14 +75,17 @@ class LoopbackGroup:
                 out[r] = fn(r)
             except BaseException as e:     # noqa: BLE001 - re-raised below, on the caller's thread
                 err[r] = e
+                d = self.devs[r] if r < len(self.devs) else None
+                if d is not None:          # the other ranks may be waiting for this one at a collective: let them go
+                    d.dist_abort()
         th = [threading.Thread(target=run, args=(r,), name=f"pl-rank-{r}") for r in range(self.world)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        for e in err:
-            if e is not None:
-                raise e
+        first = [e for e in err if e is not None and not (isinstance(e, _capi.PlError) and "exchange" in str(e))]
+        for e in first + [e for e in err if e is not None]:
+            raise e                        # the rank that failed first, not the ones that were let go
         return out
 
     # -- the collective calls ----------------------------------------------------------------------------------------

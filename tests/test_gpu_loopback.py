@@ -172,3 +172,24 @@ def test_missing_rank_is_an_error_not_a_hang():
         assert not t.is_alive() and len(err) == 1 and err[0].code == _capi.PL_ERR_HIP
     finally:
         g.close()
+
+
+def test_a_rank_that_fails_outside_a_collective_lets_the_others_go():
+    """One rank raises before it reaches the collective (bad argument): LoopbackGroup.each breaks the group, the other rank's
+    pl_assemble returns instead of waiting 120 s, and the caller sees the first failure."""
+    import time
+    g = _group("bcc12", 2, axis=0, precond=1, condense=-1)
+    try:
+        fixed, f = g.cantilever(12.0)
+        g.set_bc(fixed, None, f)
+
+        def step(r):
+            if r == 1:
+                raise ValueError("rank 1 never calls pl_assemble")
+            g.devs[r].assemble()
+        t0 = time.time()
+        with pytest.raises(ValueError):
+            g.each(step)
+        assert time.time() - t0 < 30.0
+    finally:
+        g.close()
