@@ -219,6 +219,32 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
                       grid, o->grid_nodes > 0 ? global_grid : nullptr,
                       (o->precond >= 2 && o->precond <= 4) ? coarse_budget(o, N) * 6 / coarse_modes_of(o, N) : 0);
     c->reordered = true;
+    // Inside a tile: nodes of one KIND together (kind = the set of directions of a node's struts: in a periodic lattice
+    // the corner nodes, the face centres of each orientation, ...; original order within a kind).  Struts of one
+    // direction then join consecutive rows on both ends, which is what keeps the LDS-resident K*p (pl_tile.h) free of
+    // bank conflicts; the other kernels do not care about the order inside a tile.
+    {
+      std::vector<uint64_t> kind((size_t)N, 0);
+      pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t b = b0; b < b1; ++b) {
+          const int32_t u = m->beam_conn[2 * b], v = m->beam_conn[2 * b + 1];
+          uint64_t d = 0;
+          for (int k = 0; k < 3; ++k) {
+            const int64_t q = (int64_t)std::llround((m->node_xyz[3 * (size_t)v + k] - m->node_xyz[3 * (size_t)u + k]) * 4096.0);
+            d = d * 0x9E3779B97F4A7C15ull + (uint64_t)(q + (1 << 20));
+          }
+          auto mix = [](uint64_t h) { h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; return h; };
+          __atomic_fetch_add(&kind[u], mix(d), __ATOMIC_RELAXED);
+          __atomic_fetch_add(&kind[v], mix(~d), __ATOMIC_RELAXED);
+        }
+      }, 1 << 16);
+      const int64_t T = (int64_t)tile_start.size() - 1;
+      pl::parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
+        for (int64_t t = t0; t < t1; ++t)
+          std::stable_sort(c->perm.begin() + tile_start[t], c->perm.begin() + tile_start[t + 1],
+                           [&](int32_t l, int32_t r) { return kind[l] < kind[r]; });
+      }, 16);
+    }
   } else {
     pl::chunk_tiles(N, tile_start);
   }
@@ -343,7 +369,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_TRY(build_incidence(c, conn));
   stage.mark("incidence + BSR pattern");
   {
-    int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of);
+    int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of, xyz.data());
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
   c->h_tile_start = tile_start;

@@ -13,9 +13,20 @@ int launch_records(pl_context *c) {
 }
 
 // Try to replace the per-strut records by palette ids (periodic lattices); leaves pal_ready = false otherwise.
+// Visit words of the LDS-resident K*p (pl_tile.h): static local rows | dense palette id | condensed-end bits.  Rebuilt
+// behind every palette build and whenever the set of eliminated nodes changes (needs the palette's dense ids: a no-op
+// before the first assembly, whose own palette build then picks the condensed-end bits up).
+void refresh_visit_words(pl_context *c, hipStream_t st) {
+  if (!c->vword.p || !c->pal_dense_of_slot.p) return;
+  hipLaunchKernelGGL(pl::k_visit_words, dim3(grid_for(c->tile.n_visits)), dim3(pl::kBlock), 0, st, c->tile.n_visits,
+                     c->tile.vloc.p, c->tile.vstrut.p, c->pal_id.p, c->pal_dense_of_slot.p,
+                     c->cend.p ? (const uint8_t *)c->cend.p : (const uint8_t *)nullptr, c->vword.p);
+}
+
 // launch_palette queues the kernels and the flag read-back on `st`; finish_palette (after a sync) reads the verdict.
 int launch_palette(pl_context *c, hipStream_t st) {
   c->pal_ready = false;
+  c->pal_lds = false;
   c->pal_host_flags[0] = 1;
   c->pal_host_flags[1] = 0;
   if (!c->opt.palette) return PL_OK;
@@ -25,6 +36,9 @@ int launch_palette(pl_context *c, hipStream_t st) {
     PL_HIP(c->pal_flags.alloc(2));
     PL_HIP(c->pal_id.alloc(c->B));
     PL_HIP(c->palette.alloc(pl::kPalSize));
+    PL_HIP(c->pal_dense_of_slot.alloc(pl::kPalSize));
+    PL_HIP(c->pal_dense.alloc(pl::kPalDenseMax));
+    if (c->tile.vis_ready) PL_HIP(c->vword.alloc((size_t)c->tile.n_visits));
     void *pinned = nullptr;
     PL_HIP(hipHostMalloc(&pinned, 2 * sizeof(int), hipHostMallocDefault));
     c->pal_host_flags = static_cast<int *>(pinned);
@@ -40,7 +54,8 @@ int launch_palette(pl_context *c, hipStream_t st) {
                      c->pal_flags.p);
   hipLaunchKernelGGL(pl::k_pal_publish, g, blk, 0, st, c->B, c->rec.p, c->pal_owner.p, c->pal_id.p, c->palette.p);
   hipLaunchKernelGGL(pl::k_pal_verify, g, blk, 0, st, c->B, c->rec.p, c->pal_id.p, c->palette.p, c->pal_owner.p,
-                     c->pal_flags.p);
+                     c->pal_flags.p, c->pal_dense_of_slot.p, c->pal_dense.p, pl::kPalDenseMax);
+  refresh_visit_words(c, st);
   PL_HIP(hipGetLastError());
   PL_HIP(hipMemcpyAsync(c->pal_host_flags, c->pal_flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   return PL_OK;
@@ -49,6 +64,9 @@ void finish_palette(pl_context *c) {
   if (!c->opt.palette) return;
   c->pal_entries = c->pal_host_flags[1];
   c->pal_ready = (c->pal_host_flags[0] == 0);
+  // the LDS-resident K*p (pl_tile.h) when the whole palette fits its LDS table; PL_TILE_LDS=0 keeps the gather kernel (A/B)
+  static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
+  c->pal_lds = c->pal_ready && c->vword.p && c->pal_entries > 0 && c->pal_entries <= pl::kPalDenseMax && !lds_off;
 }
 int build_palette(pl_context *c) {
   int rc = launch_palette(c, c->stream);
@@ -310,6 +328,7 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   if (!c->cend.p) PL_HIP(c->cend.alloc(c->B));
   hipLaunchKernelGGL(k_cond_ends, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B,
                      reinterpret_cast<const int2 *>(c->conn.p), (const uint8_t *)c->cflag.p, c->cend.p);
+  refresh_visit_words(c, c->stream);   // (the same bits ride in the visit words of the LDS-resident K*p)
   PL_HIP(hipGetLastError());
   c->n_cond = (int64_t)picked.size();
   return PL_OK;

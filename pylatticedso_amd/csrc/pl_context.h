@@ -141,6 +141,10 @@ struct pl_context {
   DevBuf<unsigned long long> pal_keys;
   DevBuf<int> pal_owner, pal_flags;
   DevBuf<uint16_t> pal_id;
+  DevBuf<int> pal_dense_of_slot;      // hash slot -> dense palette id (0 .. pal_entries-1)
+  DevBuf<pl::Record> pal_dense;       // the first kPalDenseMax entries, densely numbered (LDS table of k_spmv_tile_lds)
+  DevBuf<uint32_t> vword;             // per strut visit: local rows | dense palette id | condensed-end bits (k_visit_words)
+  bool pal_lds = false;               // the LDS-resident K*p applies (palette holds, <= kPalDenseMax entries, visit plan)
   DevBuf<pl::Record> palette;
   bool pal_ready = false;
   int pal_entries = 0;

@@ -91,11 +91,15 @@ __global__ __launch_bounds__(kBlock) void k_pal_publish(int64_t B, const Record 
   const unsigned slot = pal[b];
   if (owner[slot] == (int)b) palette[slot] = rec[b];
 }
-// pass 3: every strut checks that its slot really holds its (quantised) record; counts the distinct entries
+// pass 3: every strut checks that its slot really holds its (quantised) record; the owners count the distinct entries and
+// number them densely (dense_of_slot[slot] = 0, 1, ... in arrival order; the first kDense of them copied to `dense`: the
+// table the LDS-resident K*p keeps in LDS, pl_tile.h)
 __global__ __launch_bounds__(kBlock) void k_pal_verify(int64_t B, const Record *__restrict__ rec,
                                                        const uint16_t *__restrict__ pal,
                                                        const Record *__restrict__ palette,
-                                                       const int *__restrict__ owner, int *__restrict__ flags) {
+                                                       const int *__restrict__ owner, int *__restrict__ flags,
+                                                       int *__restrict__ dense_of_slot, Record *__restrict__ dense,
+                                                       int n_dense_max) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
   const Record r = load_record(rec, b), q = load_record(palette, pal[b]);
@@ -104,7 +108,10 @@ __global__ __launch_bounds__(kBlock) void k_pal_verify(int64_t B, const Record *
                     pal_quant(r.e3) == pal_quant(q.e3) && pal_quant(r.dx) == pal_quant(q.dx) &&
                     pal_quant(r.dy) == pal_quant(q.dy) && pal_quant(r.dz) == pal_quant(q.dz);
   if (!same) flags[0] = 1;
-  if (owner[pal[b]] == (int)b) atomicAdd(flags + 1, 1);
+  if (owner[pal[b]] == (int)b) {
+    const int d = atomicAdd(flags + 1, 1);
+    dense_of_slot[pal[b]] = d;
+    if (d < n_dense_max) dense[d] = q;
+  }
 }
-
 }  // namespace pl

@@ -187,6 +187,11 @@ struct TBuf {
   }
 };
 
+struct TileDesc {
+  int32_t n0, n1, n_int, n_cross;   // node range, interior / crossing visit counts
+  int64_t v0, c0;                   // first visit (interior, then crossing at v0 + n_int), first entry of vother
+};
+
 struct TilePlan {
   bool ready = false;
   int64_t n_tiles = 0;
@@ -196,7 +201,19 @@ struct TilePlan {
   TBuf<int32_t> foreign_idx;    // strut ids
   int64_t n_foreign = 0;
   int max_nodes = 0;            // largest tile: sizes the LDS accumulator of the K*p launch
+  // Visit lists of the LDS-resident K*p (k_spmv_tile_lds).  Per tile: first the INTERIOR visits (struts with both ends in
+  // the tile; 32-bit word = local row of end A | local row of end B << 10), then the CROSSING ones (home struts whose
+  // other end lies in a higher tile, and the foreign struts; word = local row of the tile's own end | (own end is B) << 10,
+  // vother = node id of the other end).  vstrut = the strut of a visit (palette id / condensed-end bits per visit are
+  // derived from it at assembly time); tdesc = everything a workgroup needs to know about its tile in one 32-byte read.
+  bool vis_ready = false;
+  int64_t n_visits = 0, n_cross = 0;
+  TBuf<TileDesc> tdesc;         // [n_tiles]
+  TBuf<uint32_t> vloc;          // [n_visits]
+  TBuf<int32_t> vstrut;         // [n_visits]
+  TBuf<int32_t> vother;         // [n_cross]
 };
+constexpr int kVisRowBits = 10;                       // local rows of a visit word: < 1024 (a tile has <= 512 nodes)
 
 // Computes the strut permutation (bperm[new] = old) that numbers struts by home tile and, inside a tile, so that
 // consecutive struts touch different nodes (LDS atomics of one wave instruction then hit distinct addresses).
@@ -234,7 +251,8 @@ inline void tile_strut_order(const std::vector<int32_t> &conn, int64_t N, int64_
 
 // conn must already be in the NEW strut numbering.
 inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int64_t N, int64_t B,
-                           const std::vector<int32_t> &tile_start, const std::vector<int32_t> &tile_of) {
+                           const std::vector<int32_t> &tile_start, const std::vector<int32_t> &tile_of,
+                           const double *xyz = nullptr) {
   const int64_t T = (int64_t)tile_start.size() - 1;
   std::vector<int64_t> home_ptr(T + 1, 0), foreign_ptr(T + 1, 0);
   for (int64_t b = 0; b < B; ++b) {
@@ -269,6 +287,75 @@ inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int
   if (plan.foreign_ptr.upload(foreign_ptr) != hipSuccess) return 3;
   if (plan.foreign_idx.upload(foreign_idx) != hipSuccess) return 3;
   plan.ready = true;
+  // ---- visit lists of the LDS-resident kernel ----
+  plan.vis_ready = false;
+  std::vector<TileDesc> td((size_t)T);
+  {
+    int64_t v = 0, cx = 0;
+    for (int64_t t = 0; t < T; ++t) {
+      // crossing visits of tile t: its foreign struts + its home struts that are some higher tile's foreign struts
+      int64_t cross_home = 0;
+      for (int64_t b = home_ptr[t]; b < home_ptr[t + 1]; ++b) cross_home += tile_of[conn[2 * b]] != tile_of[conn[2 * b + 1]];
+      const int64_t nf = foreign_ptr[t + 1] - foreign_ptr[t], nh = home_ptr[t + 1] - home_ptr[t];
+      td[t] = {tile_start[t], tile_start[t + 1], (int32_t)(nh - cross_home), (int32_t)(cross_home + nf), v, cx};
+      v += nh + nf;
+      cx += cross_home + nf;
+    }
+    plan.n_visits = v;
+    plan.n_cross = cx;
+  }
+  std::vector<uint32_t> vloc((size_t)plan.n_visits);
+  std::vector<int32_t> vstrut((size_t)plan.n_visits), vother((size_t)std::max<int64_t>(1, plan.n_cross));
+  // Order inside a tile: by strut DIRECTION class (quantised end-to-end vector), then by the local row of the first end.
+  // In a periodic lattice the struts of one direction connect row i to row i + const: the 64 lanes of a wave then read
+  // and accumulate both ends at (nearly) consecutive LDS rows - few bank conflicts on either - and share one record.
+  parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
+    struct Vis { uint64_t key; uint32_t w; int32_t b, other; };
+    std::vector<Vis> in, cr;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int32_t n0 = tile_start[t], n1 = tile_start[t + 1];
+      in.clear();
+      cr.clear();
+      auto put = [&](int64_t b) {
+        const int32_t a = conn[2 * b], d = conn[2 * b + 1];
+        const bool inA = a >= n0 && a < n1, inB = d >= n0 && d < n1;
+        uint64_t dir = 0;
+        if (xyz)
+          for (int k = 0; k < 3; ++k) {
+            const int64_t q = (int64_t)std::llround((xyz[3 * (size_t)d + k] - xyz[3 * (size_t)a + k]) * 4096.0) + (1 << 19);
+            dir = (dir << 20) | (uint64_t)(q & 0xFFFFF);
+          }
+        if (inA && inB)
+          in.push_back({(dir << 4), (uint32_t)(a - n0) | ((uint32_t)(d - n0) << kVisRowBits), (int32_t)b, 0});
+        else      // exactly one end is this tile's (home and foreign lists hold nothing else)
+          cr.push_back({(dir << 4) | (inB ? 1u : 0u), inB ? ((uint32_t)(d - n0) | (1u << kVisRowBits)) : (uint32_t)(a - n0),
+                        (int32_t)b, inB ? a : d});
+      };
+      for (int64_t b = home_ptr[t]; b < home_ptr[t + 1]; ++b) put(b);
+      for (int64_t k = foreign_ptr[t]; k < foreign_ptr[t + 1]; ++k) put(foreign_idx[k]);
+      auto by_key = [](const Vis &l, const Vis &r) {
+        return l.key != r.key ? l.key < r.key : (l.w & 1023u) < (r.w & 1023u);
+      };
+      if (xyz) {
+        std::stable_sort(in.begin(), in.end(), by_key);
+        std::stable_sort(cr.begin(), cr.end(), by_key);
+      }
+      int64_t vi = td[t].v0, cx = td[t].c0;
+      for (const Vis &q : in) {
+        vloc[vi] = q.w;
+        vstrut[vi++] = q.b;
+      }
+      for (const Vis &q : cr) {
+        vloc[vi] = q.w;
+        vstrut[vi++] = q.b;
+        vother[cx++] = q.other;
+      }
+    }
+  }, 16);
+  if (plan.tdesc.upload(td) != hipSuccess || plan.vloc.upload(vloc) != hipSuccess ||
+      plan.vstrut.upload(vstrut) != hipSuccess || plan.vother.upload(vother) != hipSuccess)
+    return 3;
+  plan.vis_ready = true;
   return 0;
 }
 
@@ -496,6 +583,264 @@ __global__ __launch_bounds__(kTileBlock) void k_spmv_tile(const int32_t *__restr
     if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
   }
   PL_STAMP(5);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// LDS-resident K*p (round 3).  A tile copies its OWN rows of x (coalesced, one 16-byte load per lane) and the record
+// palette (a periodic lattice has a few dozen distinct records) into LDS.  An interior visit - two thirds of all - is
+// then one streamed 32-bit word + a 2-byte dense palette id, ten ds_read_b128, the arithmetic and twelve ds_add_f64:
+// no gather from global memory and no dependent memory hop inside the loop (the gather kernel above spends 52 % of its
+// waves' life in s_waitcnt behind two hops per visit).  A crossing visit gathers the one out-of-tile row from global
+// memory - requested before the interior loop starts - and accumulates only the tile's own end.
+// (First form, measured and replaced: the out-of-tile rows staged in LDS as a per-tile halo list - three dependent hops
+// (descriptor, halo index, row) before the barrier: 4.2 us of a 10.3-us workgroup life, K*p 45.6 us against 41.0.)
+// Same accumulation, masks, fused dot and node-elimination passes as k_spmv_tile; used when the palette applies with
+// <= kPalDenseMax entries (TilePlan::vis_ready, pl_context::pal_lds).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int kPalDenseMax = 256;
+// 16-byte chunks per record of the LDS palette: 5 (80 B) spreads records p and p + 4 over different banks - with 4 the
+// twelve records of an Octet lattice fall on four bank groups, three deep (measured: K*p 47.0 against 45.6 us)
+#ifndef PL_LDS_PALSTRIDE
+#define PL_LDS_PALSTRIDE 5
+#endif
+constexpr int kPalLdsChunks = PL_LDS_PALSTRIDE;
+#ifndef PL_LDS_BLOCK
+#define PL_LDS_BLOCK 512
+#endif
+constexpr int kLdsBlock = PL_LDS_BLOCK;
+
+// One 32-bit word per visit (k_visit_words, at assembly time): the plan's static bits (TilePlan::vloc: local rows, 21 bits)
+// | dense palette id << kVisPidShift (8 bits) | condensed-end bits of the strut << kVisCendShift (end A, end B).
+constexpr int kVisPidShift = 21, kVisCendShift = 29;
+__global__ __launch_bounds__(kBlock) void k_visit_words(int64_t n_visits, const uint32_t *__restrict__ vloc,
+                                                        const int32_t *__restrict__ vstrut,
+                                                        const uint16_t *__restrict__ pal,
+                                                        const int *__restrict__ dense_of_slot,
+                                                        const uint8_t *__restrict__ cend /* may be null */,
+                                                        uint32_t *__restrict__ vword) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v >= n_visits) return;
+  const int32_t b = vstrut[v];
+  const unsigned d = (unsigned)dense_of_slot[pal[b]] & 0xFFu;      // (only read when the palette has <= 256 entries)
+  const unsigned ce = cend ? (unsigned)(cend[b] & 3u) : 0u;
+  vword[v] = vloc[v] | (d << kVisPidShift) | (ce << kVisCendShift);
+}
+
+template <bool MASK, bool DOT, typename VT, int ENDS = kEndsAll>
+__global__ __launch_bounds__(kLdsBlock) void k_spmv_tile_lds(const TileDesc *__restrict__ tdesc,
+                                                         const uint32_t *__restrict__ vword,
+                                                         const int32_t *__restrict__ vother,
+                                                         const Record *__restrict__ pal_dense, int n_pal,
+                                                         const uint8_t *__restrict__ fixedbits,
+                                                         const VT *__restrict__ x, VT *__restrict__ y,
+                                                         double *__restrict__ dot_out, int stride,
+                                                         const uint8_t *__restrict__ cflag = nullptr,
+                                                         CondSolve cs = CondSolve(),
+                                                         const int32_t *__restrict__ tile_list = nullptr) {
+  constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
+  extern __shared__ double ys[];                                        // [6][stride] accumulator, component-major
+  double2 *xs2 = reinterpret_cast<double2 *>(ys + 6 * stride);          // [stride][3]: the tile's rows of x, node-major
+  double2 *ps2 = xs2 + 3 * stride;                                      // [n_pal][kPalLdsChunks]: the record palette
+  uint8_t *sflag = reinterpret_cast<uint8_t *>(ps2 + kPalLdsChunks * n_pal);   // [stride] condensed flags (ENDS != All)
+  __shared__ double red[kLdsBlock / kWave];
+  __shared__ int32_t sbase[ENDS == kEndsCondensedSolve ? kTileMaxNodes : 1];
+  PL_STAMP(0);
+  unsigned t = xcd_block(blockIdx.x, gridDim.x);
+  if (tile_list) t = (unsigned)tile_list[t];
+  const TileDesc td = tdesc[t];
+  const int n0 = td.n0, nn = td.n1 - td.n0;
+  // this thread's first interior and first crossing visit: requested together with the rows of x
+  int ki = threadIdx.x, kc = threadIdx.x;
+  bool ilive = ki < td.n_int, clive = kc < td.n_cross;
+  unsigned w = 0, cw = 0;
+  int32_t co = 0;
+  if (ilive) w = vword[td.v0 + ki];
+  const int64_t vc0 = td.v0 + td.n_int;
+  if (clive) {
+    cw = vword[vc0 + kc];
+    co = vother[td.c0 + kc];
+  }
+  for (int i = threadIdx.x; i < 6 * stride; i += kLdsBlock) ys[i] = 0.0;
+  for (int i = threadIdx.x; i < 3 * nn; i += kLdsBlock) {               // own rows: 16 B per lane, contiguous
+    uint8_t f = 0;
+    if (ENDS != kEndsAll) {
+      const int node = i / 3;
+      f = cflag[n0 + node];
+      if (i - 3 * node == 0) sflag[node] = f;
+    }
+    // (fused first pass of the condensed operator: a condensed node's row is being rewritten by its tile - it counts as
+    // zero and is not read)
+    double2 val = {0.0, 0.0};
+    if (!(ENDS == kEndsCondensedSolve && f)) val = load_pair(x, 3 * (int64_t)n0 + i);
+    xs2[i] = val;
+  }
+  for (int i = threadIdx.x; i < 4 * n_pal; i += kLdsBlock)
+    ps2[(i >> 2) * kPalLdsChunks + (i & 3)] = reinterpret_cast<const double2 *>(pal_dense)[i];
+  if (ENDS == kEndsCondensedSolve)
+    for (int i = threadIdx.x; i < nn; i += kLdsBlock) sbase[i] = cs.base[n0 + i];
+  // a crossing visit: is the tile's own end of the kind this pass accumulates, and does the other end's row count?
+  auto cross_take = [&](unsigned cwv) -> bool {
+    if (ENDS == kEndsAll) return true;
+    const bool ownB = (cwv >> kVisRowBits) & 1u;
+    return (((cwv >> (kVisCendShift + (ownB ? 1 : 0))) & 1u) != 0) == kToCondensed;
+  };
+  auto other_zero = [&](unsigned cwv) -> bool {        // (first pass: condensed rows count as zero)
+    if (ENDS != kEndsCondensedSolve) return false;
+    const bool ownB = (cwv >> kVisRowBits) & 1u;
+    return ((cwv >> (kVisCendShift + (ownB ? 0 : 1))) & 1u) != 0;
+  };
+  // the first crossing visit's out-of-tile row: in flight during the barrier and the interior loop
+  V3 uO = {0, 0, 0}, tO = {0, 0, 0};
+  if (clive && cross_take(cw) && !other_zero(cw)) load6(x + 6 * (int64_t)co, uO, tO);
+  PL_STAMP(1);
+  __syncthreads();
+  PL_STAMP(2);
+  auto record_of = [&](unsigned id) -> Record {
+#ifdef PL_LDS_REC_GLOBAL
+    const double2 *q = reinterpret_cast<const double2 *>(pal_dense) + 4 * id;
+#else
+    const double2 *q = ps2 + kPalLdsChunks * id;
+#endif
+    const double2 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
+    Record r;
+    r.a = r0.x; r.c = r0.y; r.e1 = r1.x; r.e2 = r1.y; r.e3 = r2.x; r.dx = r2.y; r.dy = r3.x; r.dz = r3.y;
+    return r;
+  };
+  while (ilive) {
+    const int kn = ki + kLdsBlock;
+    const bool live_n = kn < td.n_int;
+    unsigned w_n = 0;
+    if (live_n) w_n = vword[td.v0 + kn];
+    const int la = (int)(w & ((1u << kVisRowBits) - 1)), lb = (int)((w >> kVisRowBits) & ((1u << kVisRowBits) - 1));
+    bool takeA = true, takeB = true;
+    if (ENDS != kEndsAll) {
+      takeA = (((w >> kVisCendShift) & 1u) != 0) == kToCondensed;
+      takeB = (((w >> kVisCendShift) & 2u) != 0) == kToCondensed;
+    }
+    if (takeA || takeB) {
+      const Record r = record_of((w >> kVisPidShift) & 0xFFu);
+      const double2 *pa = xs2 + 3 * la, *pb = xs2 + 3 * lb;
+      const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+      const V3 uA = {a0.x, a0.y, a1.x}, tA = {a1.y, a2.x, a2.y}, uB = {b0.x, b0.y, b1.x}, tB = {b1.y, b2.x, b2.y};
+      V3 F, M;
+      tip_force(r, uA, tA, uB, tB, F, M);
+      if (takeB) lds_add6(ys + lb, stride, F, M);
+      if (takeA) {
+        const V3 d = {r.dx, r.dy, r.dz};
+        lds_add6(ys + la, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
+      }
+    }
+    ki = kn;
+    w = w_n;
+    ilive = live_n;
+  }
+  while (clive) {
+    const int kn = kc + kLdsBlock;
+    const bool live_n = kn < td.n_cross;
+    unsigned cw_n = 0;
+    int32_t co_n = 0;
+    if (live_n) {
+      cw_n = vword[vc0 + kn];
+      co_n = vother[td.c0 + kn];
+    }
+    if (cross_take(cw)) {
+      const int lo = (int)(cw & ((1u << kVisRowBits) - 1));
+      const bool ownB = (cw >> kVisRowBits) & 1u;
+      const Record r = record_of((cw >> kVisPidShift) & 0xFFu);
+      const double2 *po = xs2 + 3 * lo;
+      const double2 a0 = po[0], a1 = po[1], a2 = po[2];
+      const V3 uW = {a0.x, a0.y, a1.x}, tW = {a1.y, a2.x, a2.y};
+      V3 F, M;
+      if (ownB) {
+        tip_force(r, uO, tO, uW, tW, F, M);
+        lds_add6(ys + lo, stride, F, M);
+      } else {
+        tip_force(r, uW, tW, uO, tO, F, M);
+        const V3 d = {r.dx, r.dy, r.dz};
+        lds_add6(ys + lo, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
+      }
+    }
+    uO = {0, 0, 0};
+    tO = {0, 0, 0};
+    if (live_n && cross_take(cw_n) && !other_zero(cw_n)) load6(x + 6 * (int64_t)co_n, uO, tO);
+    kc = kn;
+    cw = cw_n;
+    clive = live_n;
+  }
+  PL_STAMP(3);
+  __syncthreads();
+  PL_STAMP(4);
+  if (ENDS == kEndsCondensedSolve) {
+    for (int i = threadIdx.x; i < nn * 6; i += kLdsBlock) {
+      const int node = i / 6, k = i - 6 * node;
+      const int32_t b0 = sbase[node];
+      if (b0 < 0) continue;
+      const double *A = cs.inv + b0 + 6 * k;
+      double vv = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) vv += A[j] * ys[j * stride + node];
+      y[6 * (int64_t)(n0 + node) + k] = (VT)(-vv);
+    }
+    return;
+  }
+  double acc = 0.0;
+  const int64_t pair0 = 3 * (int64_t)n0;
+  for (int i = threadIdx.x; i < nn * 3; i += kLdsBlock) {
+    const int node = i / 3, part = i - 3 * node;
+    if (ENDS != kEndsAll && ((sflag[node] != 0) != (ENDS == kEndsCondensed))) continue;   // rows of the other kind
+    double2 val = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
+    if (MASK) {
+      const unsigned fb = fixedbits[n0 + node] >> (2 * part);
+      if (fb & 1u) val.x = 0.0;
+      if (fb & 2u) val.y = 0.0;
+    }
+    store_pair(y, pair0 + i, val);
+    if (DOT) {
+      const double2 xv = xs2[i];
+      acc += xv.x * val.x + xv.y * val.y;
+    }
+  }
+  if (DOT) {
+    double s = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = 0.0;
+    if (threadIdx.x == 0)
+      for (int q = 0; q < kLdsBlock / kWave; ++q) s += red[q];
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+  }
+  PL_STAMP(5);
+}
+
+// false: this launch does not fit the LDS-resident kernel (the caller falls back to launch_tile_spmv)
+template <typename VT>
+inline bool launch_tile_spmv_lds(const TilePlan &plan, const uint32_t *vword, const Record *pal_dense, int n_pal, const uint8_t *fixedbits, const VT *x, VT *y,
+                                 double *dot_dev, hipStream_t s, int ends = kEndsAll, const uint8_t *cflag = nullptr,
+                                 CondSolve cs = CondSolve(), const int32_t *tile_list = nullptr, int64_t n_list = 0) {
+  if (!plan.vis_ready || n_pal <= 0 || n_pal > kPalDenseMax) return false;
+  const int stride = plan.max_nodes | 1;
+  const size_t lds = (size_t)stride * 96 + (size_t)n_pal * 16 * kPalLdsChunks + (ends != kEndsAll ? (size_t)stride : 0);
+  if (lds > 60 * 1024) return false;
+  if (tile_list && n_list <= 0) return true;
+  const int64_t n_units = tile_list ? n_list : plan.n_tiles;
+  const dim3 g((unsigned)n_units), blk(kLdsBlock);
+#define PL_T(M, D, E)                                                                                              \
+  hipLaunchKernelGGL((k_spmv_tile_lds<M, D, VT, E>), g, blk, lds, s, plan.tdesc.p, vword, plan.vother.p,      \
+                     pal_dense, n_pal, fixedbits, x, y, dot_dev, stride, cflag, cs, tile_list)
+#define PL_TT(E)                                           \
+  do {                                                     \
+    if (fixedbits && dot_dev) PL_T(true, true, E);         \
+    else if (fixedbits) PL_T(true, false, E);              \
+    else if (dot_dev) PL_T(false, true, E);                \
+    else PL_T(false, false, E);                            \
+  } while (0)
+  if (ends == kEndsCondensed) PL_TT(kEndsCondensed);
+  else if (ends == kEndsCondensedSolve) PL_T(false, false, kEndsCondensedSolve);
+  else if (ends == kEndsOthers) PL_TT(kEndsOthers);
+  else PL_TT(kEndsAll);
+#undef PL_TT
+#undef PL_T
+  return true;
 }
 
 // (Round 3, tried and dropped: PERSISTENT workgroups - each walks several tiles of its XCD's eighth, the LDS accumulator

@@ -68,13 +68,14 @@ class LoopbackGroup:
     # -- one host thread per rank ------------------------------------------------------------------------------------
     def each(self, fn):
         """fn(rank) on one thread per rank (every collective call of the library must be made this way)."""
-        out, err = [None] * self.world, [None] * self.world
+        out, err, lock = [None] * self.world, [], threading.Lock()
 
         def run(r):
             try:
                 out[r] = fn(r)
             except BaseException as e:     # noqa: BLE001 - re-raised below, on the caller's thread
-                err[r] = e
+                with lock:
+                    err.append(e)          # in the order the ranks failed
                 d = self.devs[r] if r < len(self.devs) else None
                 if d is not None:          # the other ranks may be waiting for this one at a collective: let them go
                     d.dist_abort()
@@ -83,9 +84,8 @@ class LoopbackGroup:
             t.start()
         for t in th:
             t.join()
-        first = [e for e in err if e is not None and not (isinstance(e, _capi.PlError) and "exchange" in str(e))]
-        for e in first + [e for e in err if e is not None]:
-            raise e                        # the rank that failed first, not the ones that were let go
+        if err:
+            raise err[0]                   # the rank that failed first, not the ones that were let go afterwards
         return out
 
     # -- the collective calls ----------------------------------------------------------------------------------------
