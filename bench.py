@@ -65,8 +65,10 @@ def cantilever_bc(xyz, x_max, n_targets_global=None):
     return fixed, f, tgt
 
 
-def dev_kernel_name(kernel, reorder):
+def dev_kernel_name(kernel, reorder, palette=0):
     k = kernel if kernel else (3 if reorder else 2)
+    if k == 3 and palette and os.environ.get("PL_TILE_LDS", "1")[:1] != "0":
+        return "k_spmv_tile_lds"      # periodic lattice: every operand of a strut visit in LDS (pl_tile.h)
     return {1: "k_spmv_atomic", 2: "k_spmv_gather", 3: "k_spmv_tile"}[k]
 
 
@@ -469,7 +471,8 @@ def main():
             {"file": "profiles/" + name, "measured_on": pmc.get("build", "unknown build"),
              "note": "PMC counters cannot be read inside this run (rocprofv3 --pmc is a separate pass); this is the "
                      "committed pass for this workload / kernel / palette setting"}
-    traffic, traffic_src = committed_pmc("pmc_spmv_latest.json", spmv_kernel=dev_kernel_name(args.kernel, args.reorder),
+    traffic, traffic_src = committed_pmc("pmc_spmv_latest.json",
+                                         spmv_kernel=dev_kernel_name(args.kernel, args.reorder, args.palette),
                                          record_palette=args.palette)
 
     # The same kernel on lattices whose records do NOT repeat (graded / optimised radii: what every pl_update_radii loop
@@ -582,14 +585,15 @@ def main():
                                     "a loaded face (its per-cell strut copies, DESIGN.md section 2 defect 1); here only "
                                     "lattice nodes carry boundary data - an un-pinned divergence from the reference on "
                                     "this geometry (BCC / hybrid presets match bit-exactly)" if "Octet" in cfg["geom"] else None},
-        "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder),
+        "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder, args.palette),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "real_frac": (traffic / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
                      "note": "frac prices the ALGORITHMIC bytes of SURVEY 8(d) (64-byte record per strut); on this "
-                             "single-radius lattice the record palette replaces them by 2-byte ids, so the bytes that really "
-                             "move (traffic, PMC) are ~0.4 x and real_frac = traffic / time / peak is the honest HBM figure "
+                             "single-radius lattice the record palette replaces them by an id inside one 32-bit word per "
+                             "strut visit (k_spmv_tile_lds: rows of x and the palette in LDS), so the bytes that really "
+                             "move (traffic, PMC) are a fraction of them and real_frac = traffic / time / peak is the honest HBM figure "
                              "of this launch - and at 50^3 the working set fits the 256 MiB Infinity Cache, whose hits "
                              "FETCH_SIZE counts: see roofline_large (far beyond that cache) and roofline_streaming (lattices "
                              "with per-strut records, what every pl_update_radii loop runs)"},

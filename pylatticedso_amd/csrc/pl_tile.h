@@ -608,6 +608,16 @@ constexpr int kPalLdsChunks = PL_LDS_PALSTRIDE;
 #define PL_LDS_BLOCK 512
 #endif
 constexpr int kLdsBlock = PL_LDS_BLOCK;
+// waves per SIMD the compiler must allow (8 = 64 VGPRs: four 512-thread workgroups per CU; left alone it interleaves the
+// unrolled visits and takes 78)
+#ifndef PL_LDS_WAVES
+#define PL_LDS_WAVES 8
+#endif
+#ifndef PL_LDS_PRE
+#define PL_LDS_PRE 3
+#endif
+constexpr int kLdsPre = PL_LDS_PRE;               // interior visits per thread whose words are fetched before the barrier
+constexpr unsigned kNoVisit = 0xFFFFFFFFu;         // (bit 31 of a visit word is never set)
 
 // One 32-bit word per visit (k_visit_words, at assembly time): the plan's static bits (TilePlan::vloc: local rows, 21 bits)
 // | dense palette id << kVisPidShift (8 bits) | condensed-end bits of the strut << kVisCendShift (end A, end B).
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void k_visit_words(int64_t n_visits, const 
 }
 
 template <bool MASK, bool DOT, typename VT, int ENDS = kEndsAll>
-__global__ __launch_bounds__(kLdsBlock) void k_spmv_tile_lds(const TileDesc *__restrict__ tdesc,
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(PL_LDS_WAVES, 8))) void k_spmv_tile_lds(const TileDesc *__restrict__ tdesc,
                                                          const uint32_t *__restrict__ vword,
                                                          const int32_t *__restrict__ vother,
                                                          const Record *__restrict__ pal_dense, int n_pal,
@@ -649,12 +659,20 @@ __global__ __launch_bounds__(kLdsBlock) void k_spmv_tile_lds(const TileDesc *__r
   if (tile_list) t = (unsigned)tile_list[t];
   const TileDesc td = tdesc[t];
   const int n0 = td.n0, nn = td.n1 - td.n0;
-  // this thread's first interior and first crossing visit: requested together with the rows of x
-  int ki = threadIdx.x, kc = threadIdx.x;
-  bool ilive = ki < td.n_int, clive = kc < td.n_cross;
-  unsigned w = 0, cw = 0;
+  // this thread's first kLdsPre interior visits and its first crossing visit: requested together with the rows of x, so
+  // that the interior loop holds no load from global memory at all (a load inside it makes the compiler wait for
+  // vmcnt(0) at the top of every iteration - for the word it has just requested AND for the crossing visit's row, which
+  // is meant to stay in flight behind the loop)
+  unsigned wv[kLdsPre];
+#pragma unroll
+  for (int j = 0; j < kLdsPre; ++j) {
+    const int k = (int)threadIdx.x + j * kLdsBlock;
+    wv[j] = k < td.n_int ? vword[td.v0 + k] : kNoVisit;
+  }
+  int kc = threadIdx.x;
+  bool clive = kc < td.n_cross;
+  unsigned cw = 0;
   int32_t co = 0;
-  if (ilive) w = vword[td.v0 + ki];
   const int64_t vc0 = td.v0 + td.n_int;
   if (clive) {
     cw = vword[vc0 + kc];
@@ -706,11 +724,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_spmv_tile_lds(const TileDesc *__r
     r.a = r0.x; r.c = r0.y; r.e1 = r1.x; r.e2 = r1.y; r.e3 = r2.x; r.dx = r2.y; r.dy = r3.x; r.dz = r3.y;
     return r;
   };
-  while (ilive) {
-    const int kn = ki + kLdsBlock;
-    const bool live_n = kn < td.n_int;
-    unsigned w_n = 0;
-    if (live_n) w_n = vword[td.v0 + kn];
+  auto interior = [&](unsigned w) {
     const int la = (int)(w & ((1u << kVisRowBits) - 1)), lb = (int)((w >> kVisRowBits) & ((1u << kVisRowBits) - 1));
     bool takeA = true, takeB = true;
     if (ENDS != kEndsAll) {
@@ -730,10 +744,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_spmv_tile_lds(const TileDesc *__r
         lds_add6(ys + la, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
       }
     }
-    ki = kn;
-    w = w_n;
-    ilive = live_n;
-  }
+  };
+#pragma unroll
+  for (int j = 0; j < kLdsPre; ++j)
+    if (wv[j] != kNoVisit) interior(wv[j]);
+  for (int k = (int)threadIdx.x + kLdsPre * kLdsBlock; k < td.n_int; k += kLdsBlock) interior(vword[td.v0 + k]);   // large tiles
   while (clive) {
     const int kn = kc + kLdsBlock;
     const bool live_n = kn < td.n_cross;

@@ -28,7 +28,7 @@ f, w = d[best]["FETCH_SIZE_KB_median"], d[best]["WRITE_SIZE_KB_median"]
 print(sys.argv[2], best, "fetch KB", f, "write KB", w, "traffic MB", (2 * f + w) / 1024)
 name = {"p50": "pmc_spmv_latest.json", "s50": "pmc_spmv_streaming_latest.json", "p100": "pmc_spmv_large_palette_latest.json",
         "s100": "pmc_spmv_large_streaming_latest.json"}[sys.argv[2]]
-json.dump({"spmv_kernel": "k_spmv_tile", "record_palette": 1 if sys.argv[2][0] == "p" else 0, "fetch_kb": f, "write_kb": w,
+json.dump({"spmv_kernel": best.split("<")[0].split("::")[-1].split()[-1], "record_palette": 1 if sys.argv[2][0] == "p" else 0, "fetch_kb": f, "write_kb": w,
            "build": "round 3, " + sys.argv[3],
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/prof_round3.sh), median over the "
                      "dispatches of " + best + "; traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of "
