@@ -65,10 +65,12 @@ def cantilever_bc(xyz, x_max, n_targets_global=None):
     return fixed, f, tgt
 
 
-def dev_kernel_name(kernel, reorder, palette=0):
+def dev_kernel_name(kernel, reorder, palette=0, streaming=False):
     k = kernel if kernel else (3 if reorder else 2)
-    if k == 3 and palette and os.environ.get("PL_TILE_LDS", "1")[:1] != "0":
-        return "k_spmv_tile_lds"      # periodic lattice: every operand of a strut visit in LDS (pl_tile.h)
+    if k == 3 and os.environ.get("PL_TILE_LDS", "1")[:1] != "0":
+        if palette and not streaming:
+            return "k_spmv_tile_lds"      # periodic lattice: every operand of a strut visit in LDS (pl_tile.h)
+        return "k_spmv_tile_lds_t"        # per-strut records: x rows and strut directions in LDS, 40-byte records streamed
     return {1: "k_spmv_atomic", 2: "k_spmv_gather", 3: "k_spmv_tile"}[k]
 
 
@@ -515,8 +517,9 @@ def main():
                                    "beams_per_s": glat.n_beams / dtg, "ms_per_step": dtg * 1e3,
                                    "pcg_iterations": gst["iterations"],
                                    "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
-        s_traffic, s_src = committed_pmc("pmc_spmv_streaming_latest.json", spmv_kernel=dev_kernel_name(args.kernel, args.reorder))
-        streaming.update({"bound": "hbm", "kernel": "K*p: k_spmv_tile<.., kRecCompact>", "peak": HBM_PEAK_GBS,
+        s_traffic, s_src = committed_pmc("pmc_spmv_streaming_latest.json",
+                                        spmv_kernel=dev_kernel_name(args.kernel, args.reorder, 0, True))
+        streaming.update({"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder, 0, True) + " (40-byte records streamed)", "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "algorithmic_bytes": ab["spmv"], "traffic": s_traffic, "traffic_source": s_src})
         if s_traffic:
             streaming["real_frac"] = s_traffic / (streaming["palette_off"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -330,7 +330,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     pl::parallel_for(2 * B, [&](int64_t k0, int64_t k1, unsigned) {
       for (int64_t k = k0; k < k1; ++k) conn0[k] = c->iperm[m->beam_conn[k]];
     });
-    pl::tile_strut_order(conn0, N, B, tile_start, tile_of, c->bperm);
+    pl::tile_strut_order(conn0, N, B, tile_start, tile_of, c->bperm, xyz.data());
     pl::parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
       for (int64_t b = b0; b < b1; ++b) {
         conn[2 * b] = conn0[2 * (size_t)c->bperm[b]];

@@ -22,6 +22,17 @@ void refresh_visit_words(pl_context *c, hipStream_t st) {
                      c->tile.vloc.p, c->tile.vstrut.p, c->pal_id.p, c->pal_dense_of_slot.p,
                      c->cend.p ? (const uint8_t *)c->cend.p : (const uint8_t *)nullptr, c->vword.p);
 }
+// The streaming form's words (direction-palette entry instead of the record-palette id): static but for the condensed-end
+// bits, so rebuilt only when the set of eliminated nodes changes (and once at the first assembly).
+int refresh_visit_words_dir(pl_context *c, hipStream_t st) {
+  if (!c->tile.vis_ready || c->tile.n_dir <= 0 || !c->rec5.p) return PL_OK;
+  if (!c->vword_dir.p) PL_HIP(c->vword_dir.alloc((size_t)c->tile.n_visits));
+  hipLaunchKernelGGL(pl::k_visit_words, dim3(grid_for(c->tile.n_visits)), dim3(pl::kBlock), 0, st, c->tile.n_visits,
+                     c->tile.vloc.p, c->tile.vstrut.p, (const uint16_t *)nullptr, (const int *)nullptr,
+                     c->cend.p ? (const uint8_t *)c->cend.p : (const uint8_t *)nullptr, c->vword_dir.p);
+  c->vword_dir_fresh = true;
+  return PL_OK;
+}
 
 // launch_palette queues the kernels and the flag read-back on `st`; finish_palette (after a sync) reads the verdict.
 int launch_palette(pl_context *c, hipStream_t st) {
@@ -29,6 +40,10 @@ int launch_palette(pl_context *c, hipStream_t st) {
   c->pal_lds = false;
   c->pal_host_flags[0] = 1;
   c->pal_host_flags[1] = 0;
+  if (!c->vword_dir_fresh) {      // (first assembly of a handle without node elimination)
+    int rcw = refresh_visit_words_dir(c, st);
+    if (rcw) return rcw;
+  }
   if (!c->opt.palette) return PL_OK;
   if (!c->pal_keys.p) {
     PL_HIP(c->pal_keys.alloc(pl::kPalSize));
@@ -329,6 +344,7 @@ int select_condensed(pl_context *c, const std::vector<uint8_t> &bits) {
   hipLaunchKernelGGL(k_cond_ends, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B,
                      reinterpret_cast<const int2 *>(c->conn.p), (const uint8_t *)c->cflag.p, c->cend.p);
   refresh_visit_words(c, c->stream);   // (the same bits ride in the visit words of the LDS-resident K*p)
+  if (refresh_visit_words_dir(c, c->stream)) return PL_ERR_HIP;
   PL_HIP(hipGetLastError());
   c->n_cond = (int64_t)picked.size();
   return PL_OK;

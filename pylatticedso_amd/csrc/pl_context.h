@@ -144,6 +144,8 @@ struct pl_context {
   DevBuf<int> pal_dense_of_slot;      // hash slot -> dense palette id (0 .. pal_entries-1)
   DevBuf<pl::Record> pal_dense;       // the first kPalDenseMax entries, densely numbered (LDS table of k_spmv_tile_lds)
   DevBuf<uint32_t> vword;             // per strut visit: local rows | dense palette id | condensed-end bits (k_visit_words)
+  DevBuf<uint32_t> vword_dir;         // the same with the direction-palette entry (streaming form of the LDS-resident K*p)
+  bool vword_dir_fresh = false;
   bool pal_lds = false;               // the LDS-resident K*p applies (palette holds, <= kPalDenseMax entries, visit plan)
   DevBuf<pl::Record> palette;
   bool pal_ready = false;

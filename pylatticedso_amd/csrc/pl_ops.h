@@ -89,9 +89,15 @@ int spmv_interface_sum(pl_context *c, VT *y, double *dot_dev, bool reduce_dot = 
 template <typename VT>
 void tile_launch(pl_context *c, const uint8_t *maskbits, const VT *x, VT *y, double *dot_dev, int ends, const uint8_t *cf,
                  const pl::CondSolve &cs, const int32_t *list = nullptr, int64_t n_list = 0) {
+  static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
   if (c->pal_lds &&
-      pl::launch_tile_spmv_lds<VT>(c->tile, c->vword.p, c->pal_dense.p, c->pal_entries, maskbits, x, y, dot_dev, c->stream,
-                                   ends, cf, cs, list, n_list))
+      pl::launch_tile_spmv_lds<VT>(c->tile, c->vword.p, c->pal_dense.p, c->pal_entries, nullptr, maskbits, x, y, dot_dev,
+                                   c->stream, ends, cf, cs, list, n_list))
+    return;
+  if (!c->pal_ready && c->rec5.p && c->vword_dir.p && c->vword_dir_fresh && !lds_off &&
+      pl::launch_tile_spmv_lds<VT>(c->tile, c->vword_dir.p, c->tile.dir_table.p, c->tile.n_dir,
+                                   reinterpret_cast<const pl::Rec5 *>(c->rec5.p), maskbits, x, y, dot_dev, c->stream, ends,
+                                   cf, cs, list, n_list))
     return;
   if (c->pal_ready)
     pl::launch_tile_spmv<VT>(c->tile, c->conn.p, c->palette.p, c->pal_id.p, maskbits, x, y, dot_dev, c->stream,

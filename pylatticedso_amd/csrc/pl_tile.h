@@ -18,7 +18,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <mutex>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "pl_kernels.h"
@@ -188,8 +191,12 @@ struct TBuf {
 };
 
 struct TileDesc {
-  int32_t n0, n1, n_int, n_cross;   // node range, interior / crossing visit counts
+  int32_t n0, n1;                   // node range
+  int32_t n_int, n_cross, n_ch;     // visits: interior, crossing (of which the first n_ch are home struts, the rest foreign)
+  int32_t pad;
   int64_t v0, c0;                   // first visit (interior, then crossing at v0 + n_int), first entry of vother
+  int64_t h0, f0;                   // first home strut (visits 0 .. n_int + n_ch - 1 are struts h0, h0 + 1, ...), first
+                                    // entry of foreign_idx (crossing visit kc >= n_ch is strut foreign_idx[f0 + kc - n_ch])
 };
 
 struct TilePlan {
@@ -212,28 +219,54 @@ struct TilePlan {
   TBuf<uint32_t> vloc;          // [n_visits]
   TBuf<int32_t> vstrut;         // [n_visits]
   TBuf<int32_t> vother;         // [n_cross]
+  // direction palette: the distinct end-to-end vectors of the struts, compared bit for bit (<= kDirMax of them, else
+  // n_dir = 0): bits 21..28 of vloc hold a strut's entry, so that the streaming form of the LDS-resident kernel reads
+  // d = x_B - x_A from an LDS table and only five stiffness scalars per strut from HBM
+  int n_dir = 0;
+  TBuf<double> dir_table;       // [n_dir][4]
 };
+constexpr int kDirMax = 256;
 constexpr int kVisRowBits = 10;                       // local rows of a visit word: < 1024 (a tile has <= 512 nodes)
 
-// Computes the strut permutation (bperm[new] = old) that numbers struts by home tile and, inside a tile, so that
-// consecutive struts touch different nodes (LDS atomics of one wave instruction then hit distinct addresses).
+// Quantised end-to-end vector of a strut as one integer (1/4096 of a length unit per axis): the strut's DIRECTION class.
+inline uint64_t strut_dir_code(const double *xyz, int32_t a, int32_t d) {
+  uint64_t dir = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int64_t q = (int64_t)std::llround((xyz[3 * (size_t)d + k] - xyz[3 * (size_t)a + k]) * 4096.0) + (1 << 19);
+    dir = (dir << 20) | (uint64_t)(q & 0xFFFFF);
+  }
+  return dir;
+}
+// Sort key of a strut inside its tile [n0, n1): interior struts (both ends in the tile) first, then the crossing ones;
+// inside each group by direction class, then by the local row of the end that lies in the tile (end A for interior
+// struts).  In a periodic lattice the struts of one direction join row i to row i + const: the 64 lanes of a wave then
+// touch (nearly) consecutive rows on both ends - few LDS bank conflicts in the tile kernels, contiguous gathers - and
+// share one record.
+struct StrutKey {
+  uint64_t hi, lo;      // hi: crossing flag | direction; lo: row
+  bool operator<(const StrutKey &o) const { return hi != o.hi ? hi < o.hi : lo < o.lo; }
+};
+inline StrutKey strut_key(const double *xyz, int32_t a, int32_t d, int32_t n0, int32_t n1) {
+  const bool inA = a >= n0 && a < n1, inB = d >= n0 && d < n1;
+  const uint64_t dir = xyz ? strut_dir_code(xyz, a, d) : 0;
+  if (inA && inB) return {dir, (uint64_t)(a - n0)};
+  return {(1ull << 63) | dir, (uint64_t)((inB ? d : a) - n0)};
+}
+
+// Computes the strut permutation (bperm[new] = old) that numbers struts by home tile and, inside a tile, by strut_key
+// (xyz = node coordinates in the numbering of conn; without them: interior first, by row).
 inline void tile_strut_order(const std::vector<int32_t> &conn, int64_t N, int64_t B,
                              const std::vector<int32_t> &tile_start, std::vector<int32_t> &tile_of,
-                             std::vector<int32_t> &bperm) {
+                             std::vector<int32_t> &bperm, const double *xyz = nullptr) {
   const int64_t T = (int64_t)tile_start.size() - 1;
   tile_of.assign(N, 0);
   for (int64_t t = 0; t < T; ++t)
     for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) tile_of[i] = (int32_t)t;
-  std::vector<int32_t> home(B), occ(B);
-  std::vector<int32_t> cnt(N, 0);
-  for (int64_t b = 0; b < B; ++b) {
-    const int32_t a = conn[2 * b], d = conn[2 * b + 1];
-    home[b] = std::min(tile_of[a], tile_of[d]);
-    const int32_t pivot = tile_of[d] == home[b] ? d : a;   // an end that lies in the home tile
-    occ[b] = cnt[pivot]++;
-  }
-  // order by (home tile, occurrence, original index): counting sort into the home tiles, then every tile's short run
-  // sorted on its own - the same permutation as one stable sort of all struts, in O(B) and in parallel
+  std::vector<int32_t> home(B);
+  parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+    for (int64_t b = b0; b < b1; ++b) home[b] = std::min(tile_of[conn[2 * b]], tile_of[conn[2 * b + 1]]);
+  }, 1 << 16);
+  // counting sort into the home tiles, then every tile's short run sorted on its own
   std::vector<int64_t> hp(T + 1, 0);
   for (int64_t b = 0; b < B; ++b) hp[home[b] + 1]++;
   for (int64_t t = 0; t < T; ++t) hp[t + 1] += hp[t];
@@ -243,9 +276,17 @@ inline void tile_strut_order(const std::vector<int32_t> &conn, int64_t N, int64_
     for (int64_t b = 0; b < B; ++b) bperm[fill[home[b]]++] = (int32_t)b;      // ascending original index inside a tile
   }
   parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
-    for (int64_t t = t0; t < t1; ++t)
-      std::stable_sort(bperm.begin() + hp[t], bperm.begin() + hp[t + 1],
-                       [&](int32_t l, int32_t r) { return occ[l] < occ[r]; });
+    std::vector<std::pair<StrutKey, int32_t>> run;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int32_t n0 = tile_start[t], n1 = tile_start[t + 1];
+      run.clear();
+      for (int64_t q = hp[t]; q < hp[t + 1]; ++q) {
+        const int32_t b = bperm[q];
+        run.push_back({strut_key(xyz, conn[2 * (size_t)b], conn[2 * (size_t)b + 1], n0, n1), b});
+      }
+      std::stable_sort(run.begin(), run.end(), [](const auto &l, const auto &r) { return l.first < r.first; });
+      for (int64_t q = hp[t]; q < hp[t + 1]; ++q) bperm[q] = run[q - hp[t]].second;
+    }
   }, 16);
 }
 
@@ -285,71 +326,107 @@ inline int build_tile_plan(TilePlan &plan, const std::vector<int32_t> &conn, int
   if (plan.tile_start.upload(tile_start) != hipSuccess) return 3;
   if (plan.home_ptr.upload(home_ptr) != hipSuccess) return 3;
   if (plan.foreign_ptr.upload(foreign_ptr) != hipSuccess) return 3;
+  // every tile's foreign list in strut_key order (the tile kernels walk it in wave-sized pieces: see strut_key)
+  parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
+    std::vector<std::pair<StrutKey, int32_t>> run;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int32_t n0 = tile_start[t], n1 = tile_start[t + 1];
+      run.clear();
+      for (int64_t k = foreign_ptr[t]; k < foreign_ptr[t + 1]; ++k) {
+        const int32_t b = foreign_idx[k];
+        run.push_back({strut_key(xyz, conn[2 * (size_t)b], conn[2 * (size_t)b + 1], n0, n1), b});
+      }
+      std::stable_sort(run.begin(), run.end(), [](const auto &l, const auto &r) { return l.first < r.first; });
+      for (int64_t k = foreign_ptr[t]; k < foreign_ptr[t + 1]; ++k) foreign_idx[k] = run[k - foreign_ptr[t]].second;
+    }
+  }, 16);
   if (plan.foreign_idx.upload(foreign_idx) != hipSuccess) return 3;
   plan.ready = true;
   // ---- visit lists of the LDS-resident kernel ----
   plan.vis_ready = false;
+  // direction palette (exact end-to-end vectors)
+  struct D3 {
+    uint64_t k[3];
+    bool operator<(const D3 &o) const { return k[0] != o.k[0] ? k[0] < o.k[0] : k[1] != o.k[1] ? k[1] < o.k[1] : k[2] < o.k[2]; }
+    bool operator==(const D3 &o) const { return k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
+  };
+  auto d3_of = [&](int64_t b) {
+    D3 q;
+    for (int k = 0; k < 3; ++k) {
+      const double v = xyz[3 * (size_t)conn[2 * b + 1] + k] - xyz[3 * (size_t)conn[2 * b] + k] + 0.0;   // (-0 -> +0)
+      std::memcpy(&q.k[k], &v, 8);
+    }
+    return q;
+  };
+  std::vector<D3> dirs;
+  if (xyz) {
+    std::mutex mu;
+    bool too_many = false;
+    parallel_for(B, [&](int64_t b0, int64_t b1, unsigned) {
+      std::vector<D3> loc;
+      for (int64_t b = b0; b < b1 && loc.size() <= (size_t)kDirMax; ++b) {
+        const D3 q = d3_of(b);
+        if (std::find(loc.begin(), loc.end(), q) == loc.end()) loc.push_back(q);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (loc.size() > (size_t)kDirMax) too_many = true;
+      dirs.insert(dirs.end(), loc.begin(), loc.end());
+    }, 1 << 18);
+    std::sort(dirs.begin(), dirs.end());
+    dirs.erase(std::unique(dirs.begin(), dirs.end()), dirs.end());
+    if (too_many || dirs.size() > (size_t)kDirMax) dirs.clear();
+  }
+  plan.n_dir = (int)dirs.size();
+  {
+    std::vector<double> table((size_t)std::max(1, plan.n_dir) * 4, 0.0);
+    for (int q = 0; q < plan.n_dir; ++q)
+      for (int k = 0; k < 3; ++k) std::memcpy(&table[4 * (size_t)q + k], &dirs[q].k[k], 8);
+    if (plan.dir_table.upload(table) != hipSuccess) return 3;
+  }
   std::vector<TileDesc> td((size_t)T);
   {
     int64_t v = 0, cx = 0;
     for (int64_t t = 0; t < T; ++t) {
-      // crossing visits of tile t: its foreign struts + its home struts that are some higher tile's foreign struts
-      int64_t cross_home = 0;
-      for (int64_t b = home_ptr[t]; b < home_ptr[t + 1]; ++b) cross_home += tile_of[conn[2 * b]] != tile_of[conn[2 * b + 1]];
+      const int32_t n0 = tile_start[t], n1 = tile_start[t + 1];
+      // home struts are numbered interior first (tile_strut_order): count them
+      int64_t n_int = 0;
+      for (int64_t b = home_ptr[t]; b < home_ptr[t + 1]; ++b) {
+        const int32_t a = conn[2 * b], d = conn[2 * b + 1];
+        const bool interior = a >= n0 && a < n1 && d >= n0 && d < n1;
+        if (interior && b != home_ptr[t] + n_int) return 1;      // struts are not in tile_strut_order's order
+        n_int += interior;
+      }
       const int64_t nf = foreign_ptr[t + 1] - foreign_ptr[t], nh = home_ptr[t + 1] - home_ptr[t];
-      td[t] = {tile_start[t], tile_start[t + 1], (int32_t)(nh - cross_home), (int32_t)(cross_home + nf), v, cx};
+      td[t] = {n0, n1, (int32_t)n_int, (int32_t)(nh - n_int + nf), (int32_t)(nh - n_int), 0, v, cx, home_ptr[t], foreign_ptr[t]};
       v += nh + nf;
-      cx += cross_home + nf;
+      cx += nh - n_int + nf;
     }
     plan.n_visits = v;
     plan.n_cross = cx;
   }
   std::vector<uint32_t> vloc((size_t)plan.n_visits);
   std::vector<int32_t> vstrut((size_t)plan.n_visits), vother((size_t)std::max<int64_t>(1, plan.n_cross));
-  // Order inside a tile: by strut DIRECTION class (quantised end-to-end vector), then by the local row of the first end.
-  // In a periodic lattice the struts of one direction connect row i to row i + const: the 64 lanes of a wave then read
-  // and accumulate both ends at (nearly) consecutive LDS rows - few bank conflicts on either - and share one record.
   parallel_for(T, [&](int64_t t0, int64_t t1, unsigned) {
-    struct Vis { uint64_t key; uint32_t w; int32_t b, other; };
-    std::vector<Vis> in, cr;
     for (int64_t t = t0; t < t1; ++t) {
       const int32_t n0 = tile_start[t], n1 = tile_start[t + 1];
-      in.clear();
-      cr.clear();
+      int64_t v = td[t].v0, cx = td[t].c0;
       auto put = [&](int64_t b) {
         const int32_t a = conn[2 * b], d = conn[2 * b + 1];
         const bool inA = a >= n0 && a < n1, inB = d >= n0 && d < n1;
-        uint64_t dir = 0;
-        if (xyz)
-          for (int k = 0; k < 3; ++k) {
-            const int64_t q = (int64_t)std::llround((xyz[3 * (size_t)d + k] - xyz[3 * (size_t)a + k]) * 4096.0) + (1 << 19);
-            dir = (dir << 20) | (uint64_t)(q & 0xFFFFF);
-          }
-        if (inA && inB)
-          in.push_back({(dir << 4), (uint32_t)(a - n0) | ((uint32_t)(d - n0) << kVisRowBits), (int32_t)b, 0});
-        else      // exactly one end is this tile's (home and foreign lists hold nothing else)
-          cr.push_back({(dir << 4) | (inB ? 1u : 0u), inB ? ((uint32_t)(d - n0) | (1u << kVisRowBits)) : (uint32_t)(a - n0),
-                        (int32_t)b, inB ? a : d});
+        uint32_t dir = 0;
+        if (plan.n_dir > 0) dir = (uint32_t)(std::lower_bound(dirs.begin(), dirs.end(), d3_of(b)) - dirs.begin());
+        uint32_t w;
+        if (inA && inB) {
+          w = (uint32_t)(a - n0) | ((uint32_t)(d - n0) << kVisRowBits);
+        } else {      // exactly one end is this tile's (home and foreign lists hold nothing else)
+          w = inB ? ((uint32_t)(d - n0) | (1u << kVisRowBits)) : (uint32_t)(a - n0);
+          vother[cx++] = inB ? a : d;
+        }
+        vloc[v] = w | (dir << 21);
+        vstrut[v++] = (int32_t)b;
       };
       for (int64_t b = home_ptr[t]; b < home_ptr[t + 1]; ++b) put(b);
       for (int64_t k = foreign_ptr[t]; k < foreign_ptr[t + 1]; ++k) put(foreign_idx[k]);
-      auto by_key = [](const Vis &l, const Vis &r) {
-        return l.key != r.key ? l.key < r.key : (l.w & 1023u) < (r.w & 1023u);
-      };
-      if (xyz) {
-        std::stable_sort(in.begin(), in.end(), by_key);
-        std::stable_sort(cr.begin(), cr.end(), by_key);
-      }
-      int64_t vi = td[t].v0, cx = td[t].c0;
-      for (const Vis &q : in) {
-        vloc[vi] = q.w;
-        vstrut[vi++] = q.b;
-      }
-      for (const Vis &q : cr) {
-        vloc[vi] = q.w;
-        vstrut[vi++] = q.b;
-        vother[cx++] = q.other;
-      }
     }
   }, 16);
   if (plan.tdesc.upload(td) != hipSuccess || plan.vloc.upload(vloc) != hipSuccess ||
@@ -613,29 +690,287 @@ constexpr int kLdsBlock = PL_LDS_BLOCK;
 #ifndef PL_LDS_WAVES
 #define PL_LDS_WAVES 8
 #endif
+#ifndef PL_LDS_CROSS_FIRST
+#define PL_LDS_CROSS_FIRST 0
+#endif
+#ifndef PL_LDS_WAVES_STREAM
+#define PL_LDS_WAVES_STREAM 6
+#endif
 #ifndef PL_LDS_PRE
 #define PL_LDS_PRE 3
 #endif
 constexpr int kLdsPre = PL_LDS_PRE;               // interior visits per thread whose words are fetched before the barrier
 constexpr unsigned kNoVisit = 0xFFFFFFFFu;         // (bit 31 of a visit word is never set)
 
-// One 32-bit word per visit (k_visit_words, at assembly time): the plan's static bits (TilePlan::vloc: local rows, 21 bits)
-// | dense palette id << kVisPidShift (8 bits) | condensed-end bits of the strut << kVisCendShift (end A, end B).
+// One 32-bit word per visit: the plan's static bits (TilePlan::vloc: local rows in bits 0..20, direction-palette entry in
+// bits 21..28) with, in the palette form, the strut's dense RECORD-palette id in place of the direction entry, and the
+// condensed-end bits of the strut (end A, end B) in bits 29..30.  k_visit_words writes both forms: `vword_pal` behind every
+// palette build (ids change with the radii), `vword_dir` whenever the set of eliminated nodes changes.
 constexpr int kVisPidShift = 21, kVisCendShift = 29;
 __global__ __launch_bounds__(kBlock) void k_visit_words(int64_t n_visits, const uint32_t *__restrict__ vloc,
                                                         const int32_t *__restrict__ vstrut,
-                                                        const uint16_t *__restrict__ pal,
+                                                        const uint16_t *__restrict__ pal /* null: direction form */,
                                                         const int *__restrict__ dense_of_slot,
                                                         const uint8_t *__restrict__ cend /* may be null */,
                                                         uint32_t *__restrict__ vword) {
   const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (v >= n_visits) return;
   const int32_t b = vstrut[v];
-  const unsigned d = (unsigned)dense_of_slot[pal[b]] & 0xFFu;      // (only read when the palette has <= 256 entries)
-  const unsigned ce = cend ? (unsigned)(cend[b] & 3u) : 0u;
-  vword[v] = vloc[v] | (d << kVisPidShift) | (ce << kVisCendShift);
+  unsigned w = vloc[v];
+  if (pal) {      // (dense ids are only read when the palette has <= 256 entries)
+    const unsigned d = (unsigned)dense_of_slot[pal[b]] & 0xFFu;
+    w = (w & ~(0xFFu << kVisPidShift)) | (d << kVisPidShift);
+  }
+  if (cend) w |= (unsigned)(cend[b] & 3u) << kVisCendShift;
+  vword[v] = w;
 }
 
+__device__ __forceinline__ Rec5 load_rec5(const Rec5 *__restrict__ rec5, int64_t b) { return rec5[b]; }
+
+// REC = kRecPalette: tab = the dense record palette (Record[n_tab]), the whole record of a visit comes from LDS;
+// REC = kRecCompact: tab = the direction palette (double[n_tab][4]), d from LDS and the five stiffness scalars of the strut
+//   streamed from rec5 - home visits are consecutive struts (TileDesc::h0), so a wave reads 2.5 KB contiguous; crossing
+//   visits run FIRST in this form (their record and out-of-tile row are requested before the barrier; nothing of them
+//   stays live across the interior visits, which hold the next visit's record in registers instead).
+template <bool MASK, bool DOT, int REC, typename VT, int ENDS = kEndsAll>
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(REC == kRecPalette ? PL_LDS_WAVES : PL_LDS_WAVES_STREAM, 8)))
+void k_spmv_tile_lds_t(const TileDesc *__restrict__ tdesc, const uint32_t *__restrict__ vword,
+                       const int32_t *__restrict__ vother, const double2 *__restrict__ tab, int n_tab,
+                     const Rec5 *__restrict__ rec5, const int32_t *__restrict__ foreign_idx,
+                     const uint8_t *__restrict__ fixedbits, const VT *__restrict__ x, VT *__restrict__ y,
+                     double *__restrict__ dot_out, int stride, const uint8_t *__restrict__ cflag = nullptr,
+                     CondSolve cs = CondSolve(), const int32_t *__restrict__ tile_list = nullptr) {
+  constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
+  constexpr bool kStream = REC == kRecCompact;
+  constexpr int kSrcChunks = kStream ? 2 : 4, kTabChunks = kStream ? 2 : kPalLdsChunks;
+  struct NoRec {};
+  using RQ = typename std::conditional<kStream, Rec5, NoRec>::type;      // a visit's streamed scalars (nothing in the palette form)
+  extern __shared__ double ys[];                                        // [6][stride] accumulator, component-major
+  double2 *xs2 = reinterpret_cast<double2 *>(ys + 6 * stride);          // [stride][3]: the tile's rows of x, node-major
+  double2 *ps2 = xs2 + 3 * stride;                                      // [n_tab][kTabChunks]: record / direction palette
+  uint8_t *sflag = reinterpret_cast<uint8_t *>(ps2 + kTabChunks * n_tab);      // [stride] condensed flags (ENDS != All)
+  __shared__ double red[kLdsBlock / kWave];
+  __shared__ int32_t sbase[ENDS == kEndsCondensedSolve ? kTileMaxNodes : 1];
+  PL_STAMP(0);
+  unsigned t = xcd_block(blockIdx.x, gridDim.x);
+  if (tile_list) t = (unsigned)tile_list[t];
+  const TileDesc td = tdesc[t];
+  const int n0 = td.n0, nn = td.n1 - td.n0;
+  // this thread's first kLdsPre interior visits and its first crossing visit: requested together with the rows of x, so
+  // that the interior visits hold no load of a visit word at all (a load inside a loop makes the compiler wait for
+  // vmcnt(0) at the top of every iteration - for the word it has just requested AND for whatever else is meant to stay
+  // in flight behind the loop)
+  unsigned wv[kLdsPre];
+#pragma unroll
+  for (int j = 0; j < kLdsPre; ++j) {
+    const int k = (int)threadIdx.x + j * kLdsBlock;
+    wv[j] = k < td.n_int ? vword[td.v0 + k] : kNoVisit;
+  }
+  int kc = threadIdx.x;
+  bool clive = kc < td.n_cross;
+  unsigned cw = 0;
+  int32_t co = 0;
+  int64_t cb = 0;                      // (streaming form) the crossing visit's strut
+  (void)cb;
+  const int64_t vc0 = td.v0 + td.n_int;
+  auto cross_strut = [&](int k) -> int64_t {
+    return k < td.n_ch ? td.h0 + td.n_int + k : (int64_t)foreign_idx[td.f0 + (k - td.n_ch)];
+  };
+  if (clive) {
+    cw = vword[vc0 + kc];
+    co = vother[td.c0 + kc];
+    if constexpr (kStream) cb = cross_strut(kc);
+  }
+  RQ qn = RQ();                        // (streaming form) record of the next interior visit
+  if constexpr (kStream)
+    if (wv[0] != kNoVisit) qn = load_rec5(rec5, td.h0 + threadIdx.x);
+  for (int i = threadIdx.x; i < 6 * stride; i += kLdsBlock) ys[i] = 0.0;
+  for (int i = threadIdx.x; i < 3 * nn; i += kLdsBlock) {               // own rows: 16 B per lane, contiguous
+    uint8_t f = 0;
+    if (ENDS != kEndsAll) {
+      const int node = i / 3;
+      f = cflag[n0 + node];
+      if (i - 3 * node == 0) sflag[node] = f;
+    }
+    // (fused first pass of the condensed operator: a condensed node's row is being rewritten by its tile - it counts as
+    // zero and is not read)
+    double2 val = {0.0, 0.0};
+    if (!(ENDS == kEndsCondensedSolve && f)) val = load_pair(x, 3 * (int64_t)n0 + i);
+    xs2[i] = val;
+  }
+  for (int i = threadIdx.x; i < kSrcChunks * n_tab; i += kLdsBlock)
+    ps2[(i / kSrcChunks) * kTabChunks + (i % kSrcChunks)] = tab[i];
+  if (ENDS == kEndsCondensedSolve)
+    for (int i = threadIdx.x; i < nn; i += kLdsBlock) sbase[i] = cs.base[n0 + i];
+  // a crossing visit: is the tile's own end of the kind this pass accumulates, and does the other end's row count?
+  auto cross_take = [&](unsigned cwv) -> bool {
+    if (ENDS == kEndsAll) return true;
+    const bool ownB = (cwv >> kVisRowBits) & 1u;
+    return (((cwv >> (kVisCendShift + (ownB ? 1 : 0))) & 1u) != 0) == kToCondensed;
+  };
+  auto other_zero = [&](unsigned cwv) -> bool {        // (first pass: condensed rows count as zero)
+    if (ENDS != kEndsCondensedSolve) return false;
+    const bool ownB = (cwv >> kVisRowBits) & 1u;
+    return ((cwv >> (kVisCendShift + (ownB ? 0 : 1))) & 1u) != 0;
+  };
+  // the first crossing visit's out-of-tile row (and, streaming, its record): in flight during the barrier - and, in the
+  // palette form, during the interior visits
+  V3 uO = {0, 0, 0}, tO = {0, 0, 0};
+  RQ cq = RQ();
+  if (clive && cross_take(cw)) {
+    if (!other_zero(cw)) load6(x + 6 * (int64_t)co, uO, tO);
+    if constexpr (kStream) cq = load_rec5(rec5, cb);
+  }
+  PL_STAMP(1);
+  __syncthreads();
+  PL_STAMP(2);
+  // record of a visit: palette form - all of it from LDS; streaming form - d from the LDS direction table, the rest from q
+  auto record_of = [&](unsigned id, const RQ &q) -> Record {
+    const double2 *p = ps2 + kTabChunks * id;
+    Record r;
+    if constexpr (kStream) {
+      const double2 d0 = p[0];
+      const double dz = reinterpret_cast<const double *>(p)[2];
+      r.a = q.a; r.c = q.c; r.e1 = q.e1; r.e2 = q.e2; r.e3 = q.e3; r.dx = d0.x; r.dy = d0.y; r.dz = dz;
+    } else {
+      const double2 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+      r.a = r0.x; r.c = r0.y; r.e1 = r1.x; r.e2 = r1.y; r.e3 = r2.x; r.dx = r2.y; r.dy = r3.x; r.dz = r3.y;
+    }
+    return r;
+  };
+  auto interior = [&](unsigned w, const RQ &q) {
+    const int la = (int)(w & ((1u << kVisRowBits) - 1)), lb = (int)((w >> kVisRowBits) & ((1u << kVisRowBits) - 1));
+    bool takeA = true, takeB = true;
+    if (ENDS != kEndsAll) {
+      takeA = (((w >> kVisCendShift) & 1u) != 0) == kToCondensed;
+      takeB = (((w >> kVisCendShift) & 2u) != 0) == kToCondensed;
+    }
+    if (takeA || takeB) {
+      const Record r = record_of((w >> kVisPidShift) & 0xFFu, q);
+      const double2 *pa = xs2 + 3 * la, *pb = xs2 + 3 * lb;
+      const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+      const V3 uA = {a0.x, a0.y, a1.x}, tA = {a1.y, a2.x, a2.y}, uB = {b0.x, b0.y, b1.x}, tB = {b1.y, b2.x, b2.y};
+      V3 F, M;
+      tip_force(r, uA, tA, uB, tB, F, M);
+      if (takeB) lds_add6(ys + lb, stride, F, M);
+      if (takeA) {
+        const V3 d = {r.dx, r.dy, r.dz};
+        lds_add6(ys + la, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
+      }
+    }
+  };
+  auto interior_visits = [&]() {
+#pragma unroll
+    for (int j = 0; j < kLdsPre; ++j) {
+      const RQ qc = qn;
+      if constexpr (kStream)
+        if (j + 1 < kLdsPre && wv[j + 1] != kNoVisit)
+          qn = load_rec5(rec5, td.h0 + (int64_t)threadIdx.x + (j + 1) * kLdsBlock);
+      if (wv[j] != kNoVisit) interior(wv[j], qc);
+      __builtin_amdgcn_sched_barrier(0);      // (visits interleaved by the scheduler cost 14 more registers: spills at 64)
+    }
+    for (int k = (int)threadIdx.x + kLdsPre * kLdsBlock; k < td.n_int; k += kLdsBlock) {      // large tiles
+      RQ q = RQ();
+      if constexpr (kStream) q = load_rec5(rec5, td.h0 + k);
+      interior(vword[td.v0 + k], q);
+    }
+  };
+  auto crossing_visits = [&]() {
+    while (clive) {
+      const int kn = kc + kLdsBlock;
+      const bool live_n = kn < td.n_cross;
+      unsigned cw_n = 0;
+      int32_t co_n = 0;
+      int64_t cb_n = 0;
+      (void)cb_n;
+      if (live_n) {
+        cw_n = vword[vc0 + kn];
+        co_n = vother[td.c0 + kn];
+        if constexpr (kStream) cb_n = cross_strut(kn);
+      }
+      if (cross_take(cw)) {
+        const int lo = (int)(cw & ((1u << kVisRowBits) - 1));
+        const bool ownB = (cw >> kVisRowBits) & 1u;
+        const Record r = record_of((cw >> kVisPidShift) & 0xFFu, cq);
+        const double2 *po = xs2 + 3 * lo;
+        const double2 a0 = po[0], a1 = po[1], a2 = po[2];
+        const V3 uW = {a0.x, a0.y, a1.x}, tW = {a1.y, a2.x, a2.y};
+        V3 F, M;
+        if (ownB) {
+          tip_force(r, uO, tO, uW, tW, F, M);
+          lds_add6(ys + lo, stride, F, M);
+        } else {
+          tip_force(r, uW, tW, uO, tO, F, M);
+          const V3 d = {r.dx, r.dy, r.dz};
+          lds_add6(ys + lo, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
+        }
+      }
+      uO = {0, 0, 0};
+      tO = {0, 0, 0};
+      if (live_n && cross_take(cw_n)) {
+        if (!other_zero(cw_n)) load6(x + 6 * (int64_t)co_n, uO, tO);
+        if constexpr (kStream) cq = load_rec5(rec5, cb_n);
+      }
+      kc = kn;
+      cw = cw_n;
+      clive = live_n;
+    }
+  };
+  if constexpr (kStream || PL_LDS_CROSS_FIRST) {
+    crossing_visits();
+    interior_visits();
+  } else {
+    interior_visits();
+    crossing_visits();
+  }
+  PL_STAMP(3);
+  __syncthreads();
+  PL_STAMP(4);
+  if (ENDS == kEndsCondensedSolve) {
+    for (int i = threadIdx.x; i < nn * 6; i += kLdsBlock) {
+      const int node = i / 6, k = i - 6 * node;
+      const int32_t b0 = sbase[node];
+      if (b0 < 0) continue;
+      const double *A = cs.inv + b0 + 6 * k;
+      double vv = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) vv += A[j] * ys[j * stride + node];
+      y[6 * (int64_t)(n0 + node) + k] = (VT)(-vv);
+    }
+    return;
+  }
+  double acc = 0.0;
+  const int64_t pair0 = 3 * (int64_t)n0;
+  for (int i = threadIdx.x; i < nn * 3; i += kLdsBlock) {
+    const int node = i / 3, part = i - 3 * node;
+    if (ENDS != kEndsAll && ((sflag[node] != 0) != (ENDS == kEndsCondensed))) continue;   // rows of the other kind
+    double2 val = {ys[(2 * part) * stride + node], ys[(2 * part + 1) * stride + node]};
+    if (MASK) {
+      const unsigned fb = fixedbits[n0 + node] >> (2 * part);
+      if (fb & 1u) val.x = 0.0;
+      if (fb & 2u) val.y = 0.0;
+    }
+    store_pair(y, pair0 + i, val);
+    if (DOT) {
+      const double2 xv = xs2[i];
+      acc += xv.x * val.x + xv.y * val.y;
+    }
+  }
+  if (DOT) {
+    double s = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = 0.0;
+    if (threadIdx.x == 0)
+      for (int q = 0; q < kLdsBlock / kWave; ++q) s += red[q];
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+  }
+  PL_STAMP(5);
+}
+
+// The palette form as its own function: the same text as k_spmv_tile_lds_t<.., kRecPalette, ..>, which the register allocator
+// fits into 64 VGPRs here and spills from there (16 VGPRs of the crossing visit's row to scratch: 2 x 27 MB of traffic per
+// launch at 50^3, K*p 33.7 -> 36.4 us) - the streaming form is held to 6 waves per SIMD instead.
 template <bool MASK, bool DOT, typename VT, int ENDS = kEndsAll>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(PL_LDS_WAVES, 8))) void k_spmv_tile_lds(const TileDesc *__restrict__ tdesc,
                                                          const uint32_t *__restrict__ vword,
@@ -827,32 +1162,50 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(PL_LD
   PL_STAMP(5);
 }
 
-// false: this launch does not fit the LDS-resident kernel (the caller falls back to launch_tile_spmv)
+
+// false: this launch does not fit the LDS-resident kernel (the caller falls back to launch_tile_spmv).
+// rec5 == nullptr: palette form (tab = dense record palette); else streaming form (tab = the plan's direction palette).
 template <typename VT>
-inline bool launch_tile_spmv_lds(const TilePlan &plan, const uint32_t *vword, const Record *pal_dense, int n_pal, const uint8_t *fixedbits, const VT *x, VT *y,
-                                 double *dot_dev, hipStream_t s, int ends = kEndsAll, const uint8_t *cflag = nullptr,
+inline bool launch_tile_spmv_lds(const TilePlan &plan, const uint32_t *vword, const void *tab, int n_tab,
+                                 const Rec5 *rec5, const uint8_t *fixedbits, const VT *x, VT *y, double *dot_dev,
+                                 hipStream_t s, int ends = kEndsAll, const uint8_t *cflag = nullptr,
                                  CondSolve cs = CondSolve(), const int32_t *tile_list = nullptr, int64_t n_list = 0) {
-  if (!plan.vis_ready || n_pal <= 0 || n_pal > kPalDenseMax) return false;
+  if (!plan.vis_ready || !vword || n_tab <= 0 || n_tab > kPalDenseMax) return false;
   const int stride = plan.max_nodes | 1;
-  const size_t lds = (size_t)stride * 96 + (size_t)n_pal * 16 * kPalLdsChunks + (ends != kEndsAll ? (size_t)stride : 0);
+  const size_t lds = (size_t)stride * 96 + (size_t)n_tab * 16 * (rec5 ? 2 : kPalLdsChunks) + (ends != kEndsAll ? (size_t)stride : 0);
   if (lds > 60 * 1024) return false;
   if (tile_list && n_list <= 0) return true;
   const int64_t n_units = tile_list ? n_list : plan.n_tiles;
   const dim3 g((unsigned)n_units), blk(kLdsBlock);
-#define PL_T(M, D, E)                                                                                              \
-  hipLaunchKernelGGL((k_spmv_tile_lds<M, D, VT, E>), g, blk, lds, s, plan.tdesc.p, vword, plan.vother.p,      \
-                     pal_dense, n_pal, fixedbits, x, y, dot_dev, stride, cflag, cs, tile_list)
-#define PL_TT(E)                                           \
-  do {                                                     \
-    if (fixedbits && dot_dev) PL_T(true, true, E);         \
-    else if (fixedbits) PL_T(true, false, E);              \
-    else if (dot_dev) PL_T(false, true, E);                \
-    else PL_T(false, false, E);                            \
+  const double2 *tab2 = static_cast<const double2 *>(tab);
+#define PL_T(M, D, R, E)                                                                                              \
+  do {                                                                                                                \
+    if (R == kRecPalette)                                                                                             \
+      hipLaunchKernelGGL((k_spmv_tile_lds<M, D, VT, E>), g, blk, lds, s, plan.tdesc.p, vword, plan.vother.p,          \
+                         static_cast<const Record *>(tab), n_tab, fixedbits, x, y, dot_dev, stride, cflag, cs,        \
+                         tile_list);                                                                                  \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_spmv_tile_lds_t<M, D, kRecCompact, VT, E>), g, blk, lds, s, plan.tdesc.p, vword,          \
+                         plan.vother.p, tab2, n_tab, rec5, plan.foreign_idx.p, fixedbits, x, y, dot_dev, stride,      \
+                         cflag, cs, tile_list);                                                                       \
   } while (0)
-  if (ends == kEndsCondensed) PL_TT(kEndsCondensed);
-  else if (ends == kEndsCondensedSolve) PL_T(false, false, kEndsCondensedSolve);
-  else if (ends == kEndsOthers) PL_TT(kEndsOthers);
-  else PL_TT(kEndsAll);
+#define PL_TT(R, E)                                           \
+  do {                                                        \
+    if (fixedbits && dot_dev) PL_T(true, true, R, E);         \
+    else if (fixedbits) PL_T(true, false, R, E);              \
+    else if (dot_dev) PL_T(false, true, R, E);                \
+    else PL_T(false, false, R, E);                            \
+  } while (0)
+#define PL_TE(R)                                                                       \
+  do {                                                                                 \
+    if (ends == kEndsCondensed) PL_TT(R, kEndsCondensed);                              \
+    else if (ends == kEndsCondensedSolve) PL_T(false, false, R, kEndsCondensedSolve);  \
+    else if (ends == kEndsOthers) PL_TT(R, kEndsOthers);                               \
+    else PL_TT(R, kEndsAll);                                                           \
+  } while (0)
+  if (rec5) PL_TE(kRecCompact);
+  else PL_TE(kRecPalette);
+#undef PL_TE
 #undef PL_TT
 #undef PL_T
   return true;
