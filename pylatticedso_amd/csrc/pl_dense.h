@@ -504,6 +504,9 @@ __device__ __forceinline__ double row_dot(const bf16_t *__restrict__ Wr, const d
   return s;
 }
 
+// (Round 3, tried and dropped: FOUR rows per wave for the bfloat16 W of a 6 144-dof level, the fp64 vector entries - 8 bytes
+// against 2 of W - loaded once for the four rows: 100^3 BCC iteration 285 -> 296 us; a quarter of the waves, each with a four
+// times longer dependent loop, loses more than the vector L1 traffic it saves.)
 // t = W r (W lower triangular, one wave per row); dot_out[slot] += t.t
 // (rows are zero right of the diagonal and n is a multiple of 64, so reading a few columns past it is harmless)
 template <typename WT>
