@@ -530,6 +530,37 @@ def test_full_size_properties_config3():
         assert np.all(u[fixed != 0] == 0.0)
 
 
+def test_full_size_properties_config5():
+    """BASELINE.json configs[4] AS NAMED on one GPU: 200 x 200 x 50 cells of BCC + Octet (r = 0.04 / 0.03), 64.2 M struts,
+    fp32 matrix-free PCG with fp64 refinement (opts.precision = 1): converged against the TRUE fp64 residual, Clapeyron's
+    theorem, clamped face at rest, and the same solve in fp64 arithmetic and storage within 1e-6 (the bar of BASELINE.json)."""
+    from pylatticedso_amd import lattice_arrays as LA
+    lat = LA.generate((1, 1, 1), (200, 200, 50), ["BCC", "Octet"], [0.04, 0.03])
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius))
+    assert lat.n_beams > 64_000_000
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    tgt = lat.node_xyz[:, 0] == 200.0
+    f = np.zeros((lat.n_nodes, 6))
+    f[tgt, 2] = -0.1 / tgt.sum()
+    sols = {}
+    for precision in (1, 0):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
+                              precond=3, palette=1, precision=precision) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-8, max_iter=5000)
+            assert st["converged"] == 1 and int(st["precision_used"]) == precision and st["iterations"] < 500
+            assert st["rel_residual"] <= 1.0000001e-8
+            if precision == 1:
+                res = np.where(fixed != 0, 0.0, f - dev.spmv(u))
+                assert np.linalg.norm(res) / np.linalg.norm(f) < 5e-8         # the residual the solver reports is the true one
+                assert abs((f * u).sum() - 2.0 * dev.energy(u)) < 1e-6 * abs((f * u).sum())
+            assert np.all(u[fixed != 0] == 0.0)
+            sols[precision] = u
+    assert _rel(sols[1], sols[0]) < 1e-6
+
+
 def test_two_rank_workload_emulated_on_one_gpu():
     """The 2-GPU weak-scaling workload of bench.py (50 x 100 x 50 Octet, 6.05 M struts) solved on ONE GPU through the
     multi-rank code path (single-rank RCCL communicator) with the slab interface plane declared shared, so that the
