@@ -115,6 +115,37 @@ def test_lds_resident_spmv_matches_oracle(golden_dir, name):
         assert _rel(np.load(os.path.join(tmp, "y.npy")), y_lds) < 1e-13
 
 
+def test_irregular_lattice_takes_the_gather_kernel(golden_dir):
+    """Node coordinates jittered at random: every strut has its own end-to-end vector and its own record, so neither the
+    direction palette (<= 256 distinct vectors, compared bit for bit) nor the LDS record palette applies and the tile K*p
+    falls back to the kernel that gathers x rows and records from global memory - same oracle parity, with and without the
+    palette attempt, and through a solve."""
+    _, L = _sim(golden_dir, "bcc_4x4x4")
+    lat, pen = L.lattice, L.penalized
+    rng = np.random.default_rng(11)
+    xyz = lat.node_xyz + 1e-3 * rng.standard_normal(lat.node_xyz.shape)
+    sc = _oracle_scalars(L)
+    K = O.assemble_condensed(xyz, lat.beam_conn, sc)
+    x = rng.standard_normal(6 * lat.n_nodes)
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == 4.0, 2] = -1e-3
+    free = np.flatnonzero(fixed.ravel() == 0)
+    import scipy.sparse.linalg as spla
+    u_ref = np.zeros(6 * lat.n_nodes)
+    u_ref[free] = spla.spsolve(K.tocsr()[free][:, free].tocsc(), f.ravel()[free])
+    for palette in (0, 1):
+        with _capi.HipLattice(xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, spmv_kernel=3,
+                              palette=palette, precond=3, tile_nodes=32) as dev:
+            dev.assemble()
+            assert _rel(dev.spmv(x).ravel(), K @ x) < 1e-11
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=5000)
+            assert st["converged"] == 1 and _rel(u.ravel(), u_ref) < 1e-7
+
+
 def test_spmv_edge_cases(golden_dir):
     _, L = _sim(golden_dir, "bcc_2x2x2")
     lat = L.lattice
