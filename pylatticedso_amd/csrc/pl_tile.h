@@ -1049,11 +1049,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(PL_LD
   __syncthreads();
   PL_STAMP(2);
   auto record_of = [&](unsigned id) -> Record {
-#ifdef PL_LDS_REC_GLOBAL
-    const double2 *q = reinterpret_cast<const double2 *>(pal_dense) + 4 * id;
-#else
     const double2 *q = ps2 + kPalLdsChunks * id;
-#endif
     const double2 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
     Record r;
     r.a = r0.x; r.c = r0.y; r.e1 = r1.x; r.e2 = r1.y; r.e3 = r2.x; r.dx = r2.y; r.dy = r3.x; r.dz = r3.y;
