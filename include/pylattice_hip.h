@@ -56,7 +56,7 @@ typedef struct {
  * stamps struct_size / abi_version, pl_create / pl_create_ddm check the stamp, and pl_solve checks stats->struct_size,
  * which the caller sets (= sizeof(pl_stats_t)) before the call.  pl_opts_size() / pl_stats_size() / pl_abi_version()
  * let a binding assert its layout when it loads the library. */
-#define PL_ABI_VERSION 3u
+#define PL_ABI_VERSION 4u
 
 typedef struct {
   uint32_t struct_size;  /* sizeof(pl_opts_t) as the caller sees it; written by pl_default_opts, checked by pl_create */
@@ -131,6 +131,12 @@ typedef struct {
                            * 32 = fp32, 16 = bfloat16 (half the bytes; W16^T W16 is still symmetric positive definite and
                            * fixed - measured iteration counts unchanged), 0 = automatic: bfloat16 from 3 072 dofs on, where
                            * the GEMVs are bandwidth-bound (100^3 BCC: 2 x 22 us of a 354-us iteration) */
+  int32_t warm_start;    /* design loops (LatticeOpti.objective / gradient call the solver over and over on a slowly changing
+                          * lattice, lattice_opti.py:569-570): 1 = pl_solve starts from the previous CONVERGED solution of this
+                          * handle instead of from zero (one extra K*x; the stopping test is unchanged: ||r|| <= rtol ||b|| of the
+                          * current right-hand side).  Multi-level PCG in fp64, ordinary form, single-GPU handles; ignored
+                          * elsewhere.  0 = every solve starts from zero (what bench.py times on configs[1] / [2] / [4]: a loop of
+                          * IDENTICAL solves must not start from its own answer) */
 } pl_opts_t;
 
 typedef struct {

@@ -114,6 +114,8 @@ struct pl_context {
   DevBuf<double> ubar, f;
   // solver state
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
+  DevBuf<double> xprev;               // previous solution (warm-start experiment)
+  bool xprev_valid = false;
   DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
   int hist_cap = 0;
   // LDS-tile operator

@@ -5,6 +5,23 @@
 
 namespace {
 
+// Warm start (opts.warm_start, design loops): p <- the previous converged solution of this handle with the eliminated nodes'
+// rows zeroed, then r -= (operator p), x = p on the rows that are unknowns of the CG.
+__global__ __launch_bounds__(pl::kBlock) void k_warm_mask(int64_t N, const uint8_t *__restrict__ cflag /* may be null */,
+                                                         const uint8_t *__restrict__ fixed, double *__restrict__ p) {
+  const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (t < 6 * N && ((cflag && cflag[t / 6]) || fixed[t])) p[t] = 0.0;     // (the Dirichlet set may have changed since)
+}
+__global__ __launch_bounds__(pl::kBlock) void k_warm_apply(int64_t N, const uint8_t *__restrict__ cflag /* may be null */,
+                                                          const double *__restrict__ Ap, const double *__restrict__ p,
+                                                          double *__restrict__ r, double *__restrict__ x) {
+  const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (t >= 6 * N) return;
+  if (cflag && cflag[t / 6]) return;
+  r[t] -= Ap[t];
+  x[t] = p[t];
+}
+
 // Everything of a two-level PCG iteration after K*p: update + restriction, coarse solve, new direction.
 template <typename PT, typename RT>
 int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT *p, const PT *Ap, RT *x, RT *r) {
@@ -180,6 +197,26 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        (const double *)c->tmp2.p, c->r.p);
     PL_HIP(hipGetLastError());
   }
+  const bool warm = c->opt.warm_start == 1 && c->coarse.ready && !c->dist.active;
+  if (warm && c->xprev.p && c->xprev_valid) {
+    // x0 = the previous solution: r0 = b - S x0 through the same operator the iterations apply (with node elimination: first
+    // pass fills the eliminated rows of p, second pass takes the others); the tail below then builds z0, p0 from r0
+    PL_HIP(hipMemcpyAsync(c->p.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_warm_mask, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, (const uint8_t *)c->fixed.p, c->p.p);
+    if (c->cond_use) {
+      rc = launch_spmv(c, c->p.p, c->p.p, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+      if (rc) return rc;
+      rc = launch_spmv(c, c->p.p, c->Ap.p, true, nullptr, c->maskC.p, pl::kEndsOthers);
+    } else {
+      rc = launch_spmv(c, c->p.p, c->Ap.p, true, nullptr);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_warm_apply, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, (const double *)c->Ap.p,
+                       (const double *)c->p.p, c->r.p, c->x.p);
+    PL_HIP(hipGetLastError());
+  }
   if (c->coarse.ready) {
     // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
     // scalar set 1; its direction kernel leaves p = z0 and rz_old = r0.z0 in set 0, where iteration 0 starts.
@@ -279,6 +316,11 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     hipLaunchKernelGGL(pl::k_condense_backsubst<double>, dim3(grid_for(c->n_cond * 6)), dim3(pl::kBlock), 0, c->stream,
                        c->n_cond, c->cnodes.p, cinv(c), ccls(c), (const double *)c->r.p, (const double *)c->tmp2.p, c->x.p);
     PL_HIP(hipGetLastError());
+  }
+  if (warm && st->converged) {      // keep the solution for the next solve (before the caller's download adds ubar)
+    if (!c->xprev.p) PL_HIP(c->xprev.alloc(n6));
+    PL_HIP(hipMemcpyAsync(c->xprev.p, c->x.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->xprev_valid = true;
   }
   return PL_OK;
 }

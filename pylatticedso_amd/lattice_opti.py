@@ -203,6 +203,14 @@ class LatticeOpti(LatticeSim):
         dev = self.device_model()
         dev.update_radii(lat.beam_radius)
 
+    def device_model(self, **kw):
+        """As LatticeSim.device_model; a compliance loop solves ONE slowly changing system over and over, so its handle
+        starts every solve from the previous solution (pl_opts_t.warm_start; objectives with adjoint solves alternate two
+        right-hand sides on the handle and keep the cold start)."""
+        if self._device is None and getattr(self, "objective_type", None) == "compliance":
+            kw.setdefault("warm_start", 1)
+        return super().device_model(**kw)
+
     # -- equilibrium / objective ------------------------------------------------------------------------------
     def _initialize_simulation_parameters(self):
         self.reaction_force_vector[:] = 0.0
