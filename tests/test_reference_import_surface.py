@@ -88,4 +88,6 @@ def test_simulation_example_end_to_end(tmp_path):
     np.add.at(net, t.beam_conn[:, 1], Fg)           # +t side of the cut at the segment's second node ...
     np.add.at(net, t.beam_conn[:, 0], -Fg)          # ... -t side at its first
     free = ~L.fixed_DOF[:, :3].any(axis=1) & ~(L.applied_force[:, :3] != 0).any(axis=1)
-    assert np.abs(net[:166][free]).max() < 1e-8 * np.abs(Fg).max()
+    # (to the solver's tolerance: ||r|| <= 1e-8 ||b|| leaves nodal residuals of that order, 1.0e-8 ... 1.3e-8 of the largest
+    # section force from run to run - the LDS accumulation order of K*p is not fixed)
+    assert np.abs(net[:166][free]).max() < 1e-7 * np.abs(Fg).max()
