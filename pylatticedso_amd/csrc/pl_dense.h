@@ -442,6 +442,75 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
   }
 }
 
+// The same walk on the matrix pipe for LARGE levels (band too wide for the LDS ring: the 6 144-dof level of configs[2] /
+// configs[4] and of 8-GPU runs, 77 GFLOP).  A workgroup owns 16 columns; wave w computes rows 16 w .. 16 w + 15 of every
+// 64 x 16 product with v_mfma_f64_16x16x4_f64: per 64 x 64 tile 16 instructions and 32 LDS reads per lane, where the vector
+// form issues 128 multiply-adds and 192 LDS reads per lane - the walk was LDS-bound (1.14 us per tile product).  The fp64
+// matrix rate equals the vector rate on gfx950; what the MFMA saves is operand traffic.
+// Operand / result layout of v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[row = (lane >> 4) + 4 reg][col = lane & 15].
+constexpr int kCwM = 16;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <typename WT>
+__global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__restrict__ L, int ld, int nb, int bw,
+                                                            const double *__restrict__ Dinv, WT *__restrict__ W,
+                                                            WT *__restrict__ Wt) {
+  __shared__ double At[kNB * kLdT];
+  __shared__ double Ws[kNB * kCwM], S[kNB * kCwM];
+  constexpr int kSl = kNB / kCwM;
+  const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCwM;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  for (int e = threadIdx.x; e < kNB * kCwM; e += kBlock) {
+    const int row = e / kCwM, c = e % kCwM;
+    const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
+    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
+    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
+  }
+  double regs[kNB * kNB / kBlock];
+  if (kb + 1 < nb) tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)max(kb, kb + 1 - bw) * kNB, ld, regs);
+  // one 64 x 64 (staged k-minor in At) times 64 x 16 (row-major in B) product into this wave's 16 x 16 block
+  auto product = [&](const double *B, v4f64 acc) -> v4f64 {
+#pragma unroll
+    for (int s4 = 0; s4 < kNB / 4; ++s4) {
+      const double a = At[(4 * s4 + lk) * kLdT + 16 * wv + li];
+      const double b = B[(4 * s4 + lk) * kCwM + li];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  for (int ib = kb + 1; ib < nb; ++ib) {
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const int jlo = max(kb, ib - bw);
+    for (int jb = jlo; jb < ib; ++jb) {
+      __syncthreads();                                                 // previous tile consumed, earlier W rows written
+      tile_store_k_minor(regs, At);                                    // At[m][row] = L_ij[row][m]
+      for (int e = threadIdx.x; e < kNB * kCwM; e += kBlock) {         // (re-read as stored: the same workgroup wrote it)
+        const int m = e / kCwM, c = e % kCwM;
+        Ws[e] = (double)W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
+      }
+      __syncthreads();
+      if (jb + 1 < ib) tile_fetch(L + ((size_t)ib * kNB) * ld + (size_t)(jb + 1) * kNB, ld, regs);
+      else tile_fetch(Dinv + (size_t)ib * kNB * kNB, kNB, regs);
+      acc = product(Ws, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S[(16 * wv + lk + 4 * q) * kCwM + li] = acc[q];
+    tile_store_k_minor(regs, At);                                      // At[m][row] = Dinv_i[row][m]
+    __syncthreads();
+    if (ib + 1 < nb) tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)max(kb, ib + 1 - bw) * kNB, ld, regs);
+    v4f64 o = {0.0, 0.0, 0.0, 0.0};
+    o = product(S, o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * wv + lk + 4 * q;
+      W[((size_t)ib * kNB + row) * ld + (size_t)kb * kNB + c0 + li] = (WT)(-o[q]);
+      Wt[((size_t)kb * kNB + c0 + li) * ld + (size_t)ib * kNB + row] = (WT)(-o[q]);
+    }
+  }
+}
+
 // bfloat16 storage of the inverse factor (large dense levels: at 6 144 dofs the two triangular GEMVs read 2 x 75 MB in
 // fp32 - 44 of the 354 us of a 100^3 BCC iteration; bf16 halves that).  fp32's exponent range (entries of W span many
 // decades between translational and rotational modes), 8 bits of mantissa: W16^T W16 is still exactly symmetric positive
@@ -579,7 +648,7 @@ inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *D
   if (bw + 1 <= kRing)
     hipLaunchKernelGGL((k_trtri_cols<WT, true>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
   else
-    hipLaunchKernelGGL((k_trtri_cols<WT, false>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+    hipLaunchKernelGGL((k_trtri_cols_mfma<WT>), dim3(nb * (kNB / kCwM)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)

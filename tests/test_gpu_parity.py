@@ -998,7 +998,7 @@ def test_fp32_solver_quarter_of_config5():
     assert _rel(out[1][0], out[0][0]) < 1e-6 and _rel(out[2][0], out[0][0]) < 1e-6
 
 
-@pytest.mark.parametrize("n", [5, 64, 100, 700])
+@pytest.mark.parametrize("n", [5, 64, 100, 700, 1000])      # (1000: band wider than the LDS ring - the MFMA walk)
 def test_device_dense_spd_solver(n):
     """Blocked Cholesky + inverse factor on the device (coarse solver of the two-level preconditioner) vs numpy."""
     rng = np.random.default_rng(n)
