@@ -458,6 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
   __shared__ double At[kNB * kLdT];
   __shared__ double Ws[kNB * kCwM], S[kNB * kCwM];
   constexpr int kSl = kNB / kCwM;
+  constexpr int kWr = kNB * kCwM / kBlock;                             // entries of a 64 x 16 slice per thread
   const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCwM;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -467,8 +468,23 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
     W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
     Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
   }
+  // slice jb of this workgroup's columns, as stored (the same workgroup wrote it, at least one barrier ago): requested one
+  // product ahead, like the L tiles - a load inside the walk is a memory round trip per tile product
+  auto slice_fetch = [&](int jb, WT wr[kWr]) {
+#pragma unroll
+    for (int q = 0; q < kWr; ++q) {
+      const int e = threadIdx.x + q * kBlock;
+      wr[q] = W[((size_t)jb * kNB + e / kCwM) * ld + (size_t)kb * kNB + c0 + e % kCwM];
+    }
+  };
   double regs[kNB * kNB / kBlock];
-  if (kb + 1 < nb) tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)max(kb, kb + 1 - bw) * kNB, ld, regs);
+  WT wregs[kWr];
+  __syncthreads();                                                     // (the diagonal slice above is written)
+  if (kb + 1 < nb) {
+    const int j0 = max(kb, kb + 1 - bw);
+    tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)j0 * kNB, ld, regs);
+    slice_fetch(j0, wregs);
+  }
   // one 64 x 64 (staged k-minor in At) times 64 x 16 (row-major in B) product into this wave's 16 x 16 block
   auto product = [&](const double *B, v4f64 acc) -> v4f64 {
 #pragma unroll
@@ -485,13 +501,16 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
     for (int jb = jlo; jb < ib; ++jb) {
       __syncthreads();                                                 // previous tile consumed, earlier W rows written
       tile_store_k_minor(regs, At);                                    // At[m][row] = L_ij[row][m]
-      for (int e = threadIdx.x; e < kNB * kCwM; e += kBlock) {         // (re-read as stored: the same workgroup wrote it)
-        const int m = e / kCwM, c = e % kCwM;
-        Ws[e] = (double)W[((size_t)jb * kNB + m) * ld + (size_t)kb * kNB + c0 + c];
-      }
+#pragma unroll
+      for (int q = 0; q < kWr; ++q) Ws[threadIdx.x + q * kBlock] = (double)wregs[q];
       __syncthreads();
-      if (jb + 1 < ib) tile_fetch(L + ((size_t)ib * kNB) * ld + (size_t)(jb + 1) * kNB, ld, regs);
-      else tile_fetch(Dinv + (size_t)ib * kNB * kNB, kNB, regs);
+      if (jb + 1 < ib) {
+        tile_fetch(L + ((size_t)ib * kNB) * ld + (size_t)(jb + 1) * kNB, ld, regs);
+        // (slice ib - 1 was written in the previous round of the outer loop, before at least one barrier)
+        slice_fetch(jb + 1, wregs);
+      } else {
+        tile_fetch(Dinv + (size_t)ib * kNB * kNB, kNB, regs);
+      }
       acc = product(Ws, acc);
     }
     __syncthreads();
@@ -499,7 +518,11 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
     for (int q = 0; q < 4; ++q) S[(16 * wv + lk + 4 * q) * kCwM + li] = acc[q];
     tile_store_k_minor(regs, At);                                      // At[m][row] = Dinv_i[row][m]
     __syncthreads();
-    if (ib + 1 < nb) tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)max(kb, ib + 1 - bw) * kNB, ld, regs);
+    const int jn = max(kb, ib + 1 - bw);                               // first slice of the next block row
+    if (ib + 1 < nb) {
+      tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)jn * kNB, ld, regs);
+      if (jn < ib) slice_fetch(jn, wregs);                             // (slice ib itself is only being computed)
+    }
     v4f64 o = {0.0, 0.0, 0.0, 0.0};
     o = product(S, o);
 #pragma unroll
@@ -507,6 +530,10 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
       const int row = 16 * wv + lk + 4 * q;
       W[((size_t)ib * kNB + row) * ld + (size_t)kb * kNB + c0 + li] = (WT)(-o[q]);
       Wt[((size_t)kb * kNB + c0 + li) * ld + (size_t)ib * kNB + row] = (WT)(-o[q]);
+    }
+    if (ib + 1 < nb && jn == ib) {                                     // band of one block: the slice just written
+      __syncthreads();
+      slice_fetch(ib, wregs);
     }
   }
 }
