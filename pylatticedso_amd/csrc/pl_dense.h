@@ -588,7 +588,10 @@ __device__ __forceinline__ double row_dot(const bf16_t *__restrict__ Wr, const d
   const uint4 *W8 = reinterpret_cast<const uint4 *>(Wr);                     // eight entries per 16-byte load
   const double2 *v2 = reinterpret_cast<const double2 *>(v);
   double s = 0.0;
-#pragma unroll 2
+#ifndef PL_BF16_UNROLL
+#define PL_BF16_UNROLL 1       // (100^3 BCC iteration with 1 / 2 / 4 / 8 trips in flight: 281.4 / 283.4 / 286.9 / 288.2 us)
+#endif
+#pragma unroll PL_BF16_UNROLL
   for (int j = (c_lo >> 3) + lane; j < ((c_hi + 7) >> 3); j += 64) {
     const uint4 w = W8[j];
     const double2 x0 = v2[4 * j], x1 = v2[4 * j + 1], x2 = v2[4 * j + 2], x3 = v2[4 * j + 3];
