@@ -67,7 +67,10 @@ typedef struct {
   double pen_coef;       /* radius multiplier of penalised segments, 1.5 (beam.py:71) */
   int32_t device;        /* HIP device ordinal */
   int32_t spmv_kernel;   /* 0 = auto (3 if reorder else 2), 1 = per-strut + f64 global atomics, 2 = per-node gather
-                            (sliced ELL), 3 = per-strut with LDS tile accumulators */
+                            (sliced ELL), 3 = per-strut with LDS tile accumulators (in its LDS-resident form - a tile's rows
+                            of x and the record / direction palette in LDS, one 32-bit word per strut visit - whenever the
+                            lattice has <= 256 distinct records or strut vectors; environment PL_TILE_LDS=0 keeps the form
+                            that gathers from global memory, for A/B runs) */
   int32_t precond;       /* 1 = Jacobi (diagonal); 2 = two-level: Jacobi + rigid-body-mode coarse space on brick
                             aggregates, dense solve; 3 = 2 plus a tile level (rigid-body modes of every K*p tile,
                             6 x 6 block solves); 4 = 3 plus a rank-LOCAL dense level (aggregates of this handle only,

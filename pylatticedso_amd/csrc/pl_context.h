@@ -114,7 +114,7 @@ struct pl_context {
   DevBuf<double> ubar, f;
   // solver state
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
-  DevBuf<double> xprev;               // previous solution (warm-start experiment)
+  DevBuf<double> xprev;               // previous converged solution (opts.warm_start)
   bool xprev_valid = false;
   DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
   int hist_cap = 0;

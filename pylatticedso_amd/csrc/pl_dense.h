@@ -574,7 +574,10 @@ __device__ __forceinline__ double row_dot(const float *__restrict__ Wr, const do
   double s = 0.0;
   // (tried: all loads of up to 8 trips of a row in flight at once, clamped or predicated - a row of the 1 536-dof operator in
   // ONE memory round trip instead of the 2 + 4 this loop compiles to: the PCG iteration got 1 us SLOWER both ways)
-#pragma unroll 4
+#ifndef PL_F32_UNROLL
+#define PL_F32_UNROLL 4
+#endif
+#pragma unroll PL_F32_UNROLL
   for (int j = (c_lo >> 2) + lane; j < ((c_hi + 3) >> 2); j += 64) {
     const float4 w = W4[j];
     const double2 x0 = v2[2 * j], x1 = v2[2 * j + 1];
