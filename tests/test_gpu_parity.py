@@ -115,6 +115,44 @@ def test_lds_resident_spmv_matches_oracle(golden_dir, name):
         assert _rel(np.load(os.path.join(tmp, "y.npy")), y_lds) < 1e-13
 
 
+ALL_CELLS = ["auxetic_2x2x2", "bcc_2x2x2", "bccz_2x2x2", "cubic_2x2x2", "diamond_2x2x2", "hybrid1_1x1x1_periodic",
+             "hybrid2_2x2x2", "hybrid3_2x2x2", "hybrid4_1x1x1_periodic", "hybrid5_2x2x2", "kelvin_2x2x2", "octahedron_2x2x2",
+             "octahedronyz_2x2x2", "octahedronz_2x2x2", "octet_2x2x2", "octetext_2x2x2", "original2_2x2x2", "original_2x2x2"]
+
+
+@pytest.mark.parametrize("name", ALL_CELLS)
+def test_tile_kernels_on_every_unit_cell(golden_dir, name):
+    """All 18 unit cells of the reference (reference-dumped 2 x 2 x 2 / periodic 1 x 1 x 1 lattices), small tiles: the
+    LDS-resident K*p in its palette form (palette = 1) and in its streaming form (palette = 0: records streamed, strut
+    vectors from the LDS direction table) against the per-node gather kernel (spmv_kernel = 2, none of the tile machinery),
+    plain and masked, and through a multi-level solve."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(6 * lat.n_nodes)
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == lat.node_xyz[:, 0].min()] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == lat.node_xyz[:, 0].max(), 2] = -1e-3
+    with _device(L, spmv_kernel=2) as dev:
+        dev.assemble()
+        y_ref = dev.spmv(x).ravel()
+        dev.set_bc(fixed, None, f)
+        yf_ref = dev.spmv_free(x).ravel()
+        dev.assemble()
+        u_ref, st = dev.solve(rtol=1e-11, max_iter=100000)
+        assert st["converged"] == 1
+    for palette in (1, 0):
+        with _device(L, spmv_kernel=3, palette=palette, tile_nodes=16, precond=3) as dev:
+            dev.assemble()
+            assert _rel(dev.spmv(x).ravel(), y_ref) < 1e-11
+            dev.set_bc(fixed, None, f)
+            assert _rel(dev.spmv_free(x).ravel(), yf_ref) < 1e-11
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=100000)
+            assert st["converged"] == 1 and _rel(u.ravel(), u_ref.ravel()) < 1e-7
+
+
 def test_irregular_lattice_takes_the_gather_kernel(golden_dir):
     """Node coordinates jittered at random: every strut has its own end-to-end vector and its own record, so neither the
     direction palette (<= 256 distinct vectors, compared bit for bit) nor the LDS record palette applies and the tile K*p
