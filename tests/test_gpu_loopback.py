@@ -93,7 +93,9 @@ CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dic
          "condense": dict(precond=3, condense=1), "condense_precision1": dict(precond=3, condense=1, precision=1),
          "condense_precond4": dict(precond=4, condense=1),
          # the default K*p of a multi-rank handle overlaps the neighbour exchange with the interior tiles; -1 = one launch
-         "no_overlap": dict(precond=3, overlap=-1), "condense_no_overlap": dict(precond=3, condense=1, overlap=-1)}
+         "no_overlap": dict(precond=3, overlap=-1), "condense_no_overlap": dict(precond=3, condense=1, overlap=-1),
+         # record palette: the palette form of the LDS-resident K*p over the interface / interior tile lists
+         "palette": dict(precond=3, palette=1), "condense_palette": dict(precond=3, condense=1, palette=1)}
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
