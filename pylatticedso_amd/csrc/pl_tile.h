@@ -1062,7 +1062,30 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(PL_LD
       takeA = (((w >> kVisCendShift) & 1u) != 0) == kToCondensed;
       takeB = (((w >> kVisCendShift) & 2u) != 0) == kToCondensed;
     }
-    if (takeA || takeB) {
+    if (ENDS == kEndsCondensedSolve && takeA != takeB) {
+      // first pass of the condensed operator, strut with ONE eliminated end (every strut of a bipartite lattice): that
+      // end's row counts as zero - it is neither read nor carried through the arithmetic, and only its force is wanted.
+      // (Visits are sorted by direction, so which end it is, is uniform over nearly every wave.)
+      const Record r = record_of((w >> kVisPidShift) & 0xFFu);
+      const V3 d = {r.dx, r.dy, r.dz};
+      V3 F, M;
+      if (takeA) {        // A eliminated: du = u_B, dth = th_B; force on A = -(F, M + d x F)
+        const double2 *pb = xs2 + 3 * lb;
+        const double2 b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const V3 du = {b0.x, b0.y, b1.x}, dth = {b1.y, b2.x, b2.y};
+        F = r.a * du + (r.e1 * dot(du, d)) * d + r.e2 * cross(d, dth);
+        M = r.c * dth + (r.e3 * dot(dth, d)) * d - r.e2 * cross(d, du);
+        lds_add6(ys + la, stride, (-1.0) * F, (-1.0) * M - cross(d, F));
+      } else {            // B eliminated: du = -u_A + d x th_A, dth = -th_A; force on B = (F, M)
+        const double2 *pa = xs2 + 3 * la;
+        const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+        const V3 uA = {a0.x, a0.y, a1.x}, tA = {a1.y, a2.x, a2.y};
+        const V3 du = cross(d, tA) - uA, dth = (-1.0) * tA;
+        F = r.a * du + (r.e1 * dot(du, d)) * d + r.e2 * cross(d, dth);
+        M = r.c * dth + (r.e3 * dot(dth, d)) * d - r.e2 * cross(d, du);
+        lds_add6(ys + lb, stride, F, M);
+      }
+    } else if (takeA || takeB) {
       const Record r = record_of((w >> kVisPidShift) & 0xFFu);
       const double2 *pa = xs2 + 3 * la, *pb = xs2 + 3 * lb;
       const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
