@@ -56,7 +56,7 @@ typedef struct {
  * stamps struct_size / abi_version, pl_create / pl_create_ddm check the stamp, and pl_solve checks stats->struct_size,
  * which the caller sets (= sizeof(pl_stats_t)) before the call.  pl_opts_size() / pl_stats_size() / pl_abi_version()
  * let a binding assert its layout when it loads the library. */
-#define PL_ABI_VERSION 4u
+#define PL_ABI_VERSION 5u
 
 typedef struct {
   uint32_t struct_size;  /* sizeof(pl_opts_t) as the caller sees it; written by pl_default_opts, checked by pl_create */
@@ -218,6 +218,14 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
 
 /* New radii, same topology/segment geometry (optimisation loop; Cell.change_beam_radius cell.py:896-917). */
 int pl_update_radii(pl_handle h, const double *beam_radius);
+/* Per-strut multiplicity: strut b stands for beam_mult[b] identical struts in parallel between its two nodes (its record,
+ * sensitivity and energy scale with it; the back-substitution of pl_node_mod gives every copy its share of the section
+ * force).  This is what the reference's own model is on lattices whose struts lie in cell faces or on cell edges (Octet,
+ * Cubic, Kelvin ...): LatticeSim.set_penalized_beams splits a strut shared by k cells once PER CELL and keeps every copy
+ * (lattice_sim.py:250-303; Beam hashes by identity, beam.py:78-82; the mesher de-duplicates by object,
+ * lattice_generation.py:152-160), and Lattice.check_hybrid_collision does the same to struts cut by another geometry's
+ * node (lattice.py:1111-1215).  NULL = 1 everywhere (the default).  The next pl_assemble picks it up. */
+int pl_set_multiplicity(pl_handle h, const double *beam_mult /*[n_beams] > 0, or NULL*/);
 /* New penalised-segment geometry (when the caller re-runs the angle search, lattice_sim.py:1421-1497). */
 int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_nsub);
 

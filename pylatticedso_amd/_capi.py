@@ -20,7 +20,7 @@ PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_N
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
            "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
-           "pl_update_radii", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
+           "pl_update_radii", "pl_set_multiplicity", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
            "pl_dist_unique_id", "pl_dist_loopback_id", "pl_dist_abort", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
@@ -85,7 +85,7 @@ def load_library(path: str | None = None):
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {"pl_default_opts": [V, C.c_uint32], "pl_opts_size": [], "pl_stats_size": [], "pl_abi_version": [], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
            "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
-           "pl_update_radii": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
+           "pl_update_radii": [V, V], "pl_set_multiplicity": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V], "pl_node_mod": [V, V, V],
@@ -227,7 +227,7 @@ class HipLattice:
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
                  pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=0, lanes_per_node=0, tile_nodes=0, precond=1,
                  coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0, precision=0, compact_records=0, condense=0, chol_persistent=0,
-                 cg_form=0, tile_modes=0, coarse_modes=0, overlap=0, coarse_storage=0, warm_start=0):
+                 cg_form=0, tile_modes=0, coarse_modes=0, overlap=0, coarse_storage=0, warm_start=0, beam_mult=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -263,6 +263,9 @@ class HipLattice:
             opts.grid_nodes = int(nn)
         _check(self._lib, self._lib.pl_create(C.byref(mesh), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
+        self._mult = None
+        if beam_mult is not None:
+            self.set_multiplicity(beam_mult)
 
     @classmethod
     def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0, mintol=0.0,
@@ -343,6 +346,12 @@ class HipLattice:
         self._changing("update_radii")
         self._radius = _f64(radius, self.n_beams)
         _check(self._lib, self._lib.pl_update_radii(self._h, _ptr(self._radius)))
+
+    def set_multiplicity(self, beam_mult):
+        """Strut b counts as beam_mult[b] identical struts in parallel (pl_set_multiplicity); None = 1 everywhere."""
+        self._changing("set_multiplicity")
+        self._mult = None if beam_mult is None else _f64(beam_mult, self.n_beams)
+        _check(self._lib, self._lib.pl_set_multiplicity(self._h, _ptr(self._mult)))
 
     def update_segments(self, seg_len, seg_nsub):
         self._changing("update_segments")

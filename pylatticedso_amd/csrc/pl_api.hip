@@ -709,6 +709,25 @@ int pl_update_radii(pl_handle h, const double *beam_radius) {
   return PL_OK;
 }
 
+int pl_set_multiplicity(pl_handle h, const double *beam_mult) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_set_multiplicity: null handle");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_set_multiplicity: not available on a DDM handle");
+  PL_HIP(hipSetDevice(h->opt.device));
+  if (!beam_mult) {
+    h->mult.release();
+  } else {
+    for (int64_t b = 0; b < h->B; ++b)
+      if (!(beam_mult[b] > 0.0)) return fail(PL_ERR_ARG, "pl_set_multiplicity: non-positive multiplicity");
+    std::vector<double> m(h->B);
+    for (int64_t b = 0; b < h->B; ++b) m[b] = beam_mult[h->bperm[b]];
+    if (!h->mult.p) PL_HIP(h->mult.alloc(h->B));
+    PL_HIP(hipMemcpy(h->mult.p, m.data(), h->B * sizeof(double), hipMemcpyHostToDevice));
+  }
+  h->assembled = false;
+  h->have_bsr = false;
+  return PL_OK;
+}
+
 int pl_update_segments(pl_handle h, const double *seg_len, const int32_t *seg_nsub) {
   if (!valid(h) || !seg_len || !seg_nsub) return fail(PL_ERR_ARG, "pl_update_segments: null argument");
   PL_HIP(hipSetDevice(h->opt.device));
@@ -999,7 +1018,7 @@ int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
   DevBuf<double> out;
   PL_HIP(out.alloc(h->B));
   hipLaunchKernelGGL(pl::k_sens, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
-                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mat, h->tmp.p, lam_dev, out.p);
+                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mult.p, h->mat, h->tmp.p, lam_dev, out.p);
   PL_HIP(hipGetLastError());
   std::vector<double> tmp(h->B);
   PL_HIP(hipMemcpyAsync(tmp.data(), out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1019,7 +1038,7 @@ int pl_node_mod(pl_handle h, const double *u, double *out) {
   DevBuf<double> dev;
   PL_HIP(dev.alloc((size_t)h->B * 12));
   hipLaunchKernelGGL(pl::k_node_mod, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
-                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mat, h->rec.p, h->tmp.p, dev.p);
+                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mult.p, h->mat, h->rec.p, h->tmp.p, dev.p);
   PL_HIP(hipGetLastError());
   std::vector<double> tmp((size_t)h->B * 12);
   PL_HIP(hipMemcpyAsync(tmp.data(), dev.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -7,7 +7,7 @@ namespace {
 
 int launch_records(pl_context *c) {
   hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
-                     c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mat, c->rec.p, c->rec5.p);
+                     c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mult.p, c->mat, c->rec.p, c->rec5.p);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }

@@ -93,6 +93,7 @@ struct pl_context {
 
   // geometry / topology (device numbering)
   DevBuf<double> xyz, radius, seg_len;
+  DevBuf<double> mult;   // per-strut stiffness multiplicity (pl_set_multiplicity); unallocated = 1 everywhere
   DevBuf<int32_t> conn, seg_nsub;
   DevBuf<pl::Record> rec;
   DevBuf<double> rec5;   // compact 5-scalar copy of the records for the streaming K*p (tile kernel, no palette)

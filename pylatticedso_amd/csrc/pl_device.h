@@ -18,6 +18,14 @@ struct Material {
   double E, G, kappa, pen;
 };
 
+// k identical struts in parallel between the same two nodes (the reference's per-cell copies of a strut shared by k cells,
+// lattice_sim.py:250-303) are one strut of a k times stiffer material: every flexibility is proportional to 1/E, 1/G.
+__device__ __forceinline__ Material scaled(Material m, double k) {
+  m.E *= k;
+  m.G *= k;
+  return m;
+}
+
 // Condensed stiffness scalars of one strut.
 struct Scalars {
   double ka, kt, a, b, c;

@@ -144,10 +144,12 @@ __global__ __launch_bounds__(kBlock) void k_build_records(int64_t B, const doubl
                                                           const int32_t *__restrict__ conn,
                                                           const double *__restrict__ radius,
                                                           const double *__restrict__ seg_len,
-                                                          const int32_t *__restrict__ seg_nsub, Material m,
+                                                          const int32_t *__restrict__ seg_nsub,
+                                                          const double *__restrict__ mult, Material m,
                                                           Record *__restrict__ rec, double *__restrict__ rec5) {
   const int64_t b = (int64_t)xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (b >= B) return;
+  if (mult) m = scaled(m, mult[b]);   // k identical chains in parallel (pl_set_multiplicity)
   const int ia = conn[2 * b], ib = conn[2 * b + 1];
   const V3 d = {xyz[3 * (int64_t)ib] - xyz[3 * (int64_t)ia], xyz[3 * (int64_t)ib + 1] - xyz[3 * (int64_t)ia + 1],
                 xyz[3 * (int64_t)ib + 2] - xyz[3 * (int64_t)ia + 2]};
@@ -608,11 +610,13 @@ __global__ __launch_bounds__(kBlock) void k_compose_solution(int64_t n6, const u
 __global__ __launch_bounds__(kBlock) void k_sens(int64_t B, const double *__restrict__ xyz,
                                                  const int32_t *__restrict__ conn, const double *__restrict__ radius,
                                                  const double *__restrict__ seg_len,
-                                                 const int32_t *__restrict__ seg_nsub, Material m,
+                                                 const int32_t *__restrict__ seg_nsub,
+                                                 const double *__restrict__ mult, Material m,
                                                  const double *__restrict__ u, const double *__restrict__ lam,
                                                  double *__restrict__ out) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
+  if (mult) m = scaled(m, mult[b]);
   const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
   const V3 d = {xyz[3 * ib] - xyz[3 * ia], xyz[3 * ib + 1] - xyz[3 * ia + 1], xyz[3 * ib + 2] - xyz[3 * ia + 2]};
   const double len[3] = {seg_len[3 * b], seg_len[3 * b + 1], seg_len[3 * b + 2]};
@@ -664,11 +668,13 @@ __global__ __launch_bounds__(kBlock) void k_node_mod(int64_t B, const double *__
                                                      const int32_t *__restrict__ conn,
                                                      const double *__restrict__ radius,
                                                      const double *__restrict__ seg_len,
-                                                     const int32_t *__restrict__ seg_nsub, Material m,
+                                                     const int32_t *__restrict__ seg_nsub,
+                                                     const double *__restrict__ mult, Material m,
                                                      const Record *__restrict__ rec, const double *__restrict__ u,
                                                      double *__restrict__ out) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
+  if (mult) m = scaled(m, mult[b]);   // the record's force is shared by the parallel chains: flexibility / k
   const int64_t ia = conn[2 * b], ib = conn[2 * b + 1];
   const Record r = load_record(rec, b);
   V3 uA, tA, uB, tB, F, M;
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void k_node_mod(int64_t B, const double *__
   if (seg_len[3 * b + 2] > 0.0) {
     s += l2;
     const V3 MQ = M + (L - s) * cross(t, F);               // moment about q2
-    segment_step(l2, seg_nsub[3 * b + 1], rr, m, t, F, MQ, uq, tq);
+    if (l2 > 0.0) segment_step(l2, seg_nsub[3 * b + 1], rr, m, t, F, MQ, uq, tq);
     o[6] = uq.x; o[7] = uq.y; o[8] = uq.z; o[9] = tq.x; o[10] = tq.y; o[11] = tq.z;
   } else {
     o[6] = uB.x; o[7] = uB.y; o[8] = uB.z; o[9] = tB.x; o[10] = tB.y; o[11] = tB.z;

@@ -8,9 +8,19 @@ Mirrors (same names, argument meaning and error behaviour) the parts of
 
     fixed_DOF, displacement_vector, applied_force, reaction_force_vector, index_boundary
 
-Documented deviation: the reference splits a strut shared by two cells once PER CELL
-(lattice_sim.py:250-303), leaving duplicate segments whose points carry no index (its gmsh model is then
-ill-defined for e.g. multi-cell Octet); here every strut is penalised exactly once.
+Struts shared by several cells (lattices with struts in cell faces or on cell edges: Octet, Cubic, Kelvin, Auxetic ...):
+the reference splits such a strut once PER OWNER CELL (lattice_sim.py:250-303) and keeps every copy, gives the
+penalisation points lying in a cell face a boundary index, boundary conditions and a place in ``xsol``
+(lattice_sim.py:405-458,502-563).  Two models are offered:
+
+* ``reference_compat=False`` (default): every strut is penalised exactly once and only design nodes carry boundary
+  data - the physical lattice;
+* ``reference_compat=True`` (or environment ``PYLATTICE_REFERENCE_COMPAT=1``): the reference's own state - strut
+  multiplicity = number of owner cells, every per-node array has one row per REFERENCE node (design nodes, then
+  penalisation points, in the reference's index order), boundary data and ``xsol`` entries on penalisation points.
+  Bit-exact against the states dumped from the running reference for all 29 golden lattices; the solve treats the
+  copies of a strut as parallel chains between the same points (see ``compat_device.py`` for the one thing that cannot
+  be pinned here: what the reference's gmsh model makes of them).
 """
 from __future__ import annotations
 
@@ -63,11 +73,15 @@ def material_properties(name):
 
 class LatticeSim(LatticeViews):
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0,
-                 enable_domain_decomposition_solver: bool = False, data_roots=None):
+                 enable_domain_decomposition_solver: bool = False, data_roots=None, reference_compat=None):
         """Same arguments as the reference (lattice_sim.py:44-47) plus ``data_roots``: extra directories in which the
-        reduced-basis files of the surrogate DDM modes are looked up (the reference finds them in its own checkout)."""
+        reduced-basis files of the surrogate DDM modes are looked up (the reference finds them in its own checkout), and
+        ``reference_compat`` (module docstring; None = environment PYLATTICE_REFERENCE_COMPAT, else False)."""
         if mesh_trimmer is not None:
             raise NotImplementedError("mesh_trimmer is outside the accelerated path")
+        if reference_compat is None:
+            reference_compat = os.environ.get("PYLATTICE_REFERENCE_COMPAT", "0") not in ("", "0")
+        self.reference_compat = bool(reference_compat)
         self._verbose = verbose
         self.data_roots = list(data_roots or [])
         self.used_schur_preconditioner = None
@@ -222,13 +236,9 @@ class LatticeSim(LatticeViews):
         if self._cell_radii_override is None:      # gradient factor of Cell.get_radius (cell.py:385-412), per cell
             self._cell_gfac = lat.cell_radii[:, 0] / self._base_radii[0]
         self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max = map(float, lat.bbox)
-        N = lat.n_nodes
-        self.fixed_DOF = np.zeros((N, 6), dtype=bool)
-        self.displacement_vector = np.zeros((N, 6))
-        self.applied_force = np.zeros((N, 6))
-        self.reaction_force_vector = np.zeros((N, 6))
         self.penalized = None
         self.is_penalized = False
+        self.beam_mult = None
         # lattice_sim.py:119-122: joints are penalised for the FEM path and for DDM with exact Schur complements;
         # with a surrogate the penalisation lives inside the stored Schur matrices
         if self.enable_simulation_properties and (not self.domain_decomposition_solver
@@ -238,6 +248,17 @@ class LatticeSim(LatticeViews):
         else:
             self.lzone = np.zeros((lat.n_beams, 2))
             self.penalized = LA.penalize(lat, None)
+        # rows of the per-node arrays: the design nodes; in reference_compat mode the reference's whole node list
+        # (design nodes, then the penalisation points in coordinate order = Point.index, lattice.py:687-696)
+        self._compat_rows = self.reference_compat and self.is_penalized
+        if self._compat_rows:
+            self._define_strut_multiplicity()
+        R = self.get_number_nodes() if self._compat_rows else lat.n_nodes
+        self.fixed_DOF = np.zeros((R, 6), dtype=bool)
+        self.displacement_vector = np.zeros((R, 6))
+        self.applied_force = np.zeros((R, 6))
+        self.reaction_force_vector = np.zeros((R, 6))
+        self._cell_points = None
         self.define_node_index_boundary()
         self.set_boundary_conditions()
 
@@ -265,6 +286,49 @@ class LatticeSim(LatticeViews):
         self.penalized = LA.penalize(self.lattice, self.lzone)
         self.is_penalized = True
 
+    def _define_strut_multiplicity(self):
+        """reference_compat: how many copies of every strut the reference's model holds.  set_penalized_beams loops
+        ``for cell: for beam in cell.beams_cell`` and replaces a strut with a penalised end by NEW segment objects in that
+        cell only (lattice_sim.py:250-303), so a strut shared by k cells ends up as k copies of each segment; a strut
+        without penalised ends stays one shared object.  (Copies made by check_hybrid_collision come on top:
+        ``lattice.extras["design_mult"]``.)"""
+        lat, pen = self.lattice, self.penalized
+        owners = np.bincount(lat.cell_beam_idx, minlength=lat.n_beams)
+        split = (pen.seg_len[:, 0] > 0) | (pen.seg_len[:, 2] > 0)
+        mult = np.where(split, owners, 1).astype(np.int64)
+        dm = lat.extras.get("design_mult")
+        if dm is not None:
+            # every design copy is a separate object in every owner cell's beams_cell (lattice.py:1188-1195): each is
+            # penalised once per owner cell
+            mult = np.where(split, owners * dm, dm)
+        self.beam_mult = mult
+
+    def cell_points(self):
+        """CSR cell -> rows of the per-node arrays: ``Cell.points_cell`` of the reference.  Design nodes of the cell; in
+        reference_compat mode also the penalisation points of the cell's struts (cell.add_point, lattice_sim.py:301)."""
+        if self._cell_points is None:
+            lat = self.lattice
+            if not self._compat_rows:
+                self._cell_points = (lat.cell_node_ptr, lat.cell_node_idx)
+            else:
+                from .views import _tables
+                t = _tables(self)
+                cell_of_b = np.repeat(np.arange(lat.n_cells), np.diff(lat.cell_beam_ptr))
+                pens = t.pen_id[lat.cell_beam_idx]                    # (n_pairs, 2)
+                ok = pens >= 0
+                rows = np.concatenate([np.repeat(np.arange(lat.n_cells), np.diff(lat.cell_node_ptr)),
+                                       np.repeat(cell_of_b, 2).reshape(-1, 2)[ok]])
+                cols = np.concatenate([lat.cell_node_idx, pens[ok]])
+                self._cell_points = LA._csr_from_pairs(rows, cols, lat.n_cells)
+        return self._cell_points
+
+    def node_coordinates(self):
+        """(rows, 3) coordinates of the rows of the per-node arrays."""
+        if self._compat_rows:
+            from .views import _tables
+            return _tables(self).node_xyz
+        return self.lattice.node_xyz
+
     def reset_penalized_beams(self) -> None:
         """lattice_sim.py:313-400: undo set_penalized_beams - every strut is one segment again, the penalisation points
         go away (the design struts and nodes were never replaced here, so nothing has to be rewired); a device handle
@@ -288,26 +352,31 @@ class LatticeSim(LatticeViews):
         """Boundary index of every node lying on the box of one of its cells (lattice_sim.py:546-563), numbered in
         the order get_global_displacement visits them (cells in order, nodes by rounded coordinates)."""
         lat = self.lattice
-        N = lat.n_nodes
-        if N >= 20000:       # large lattices: the same rule in multi-threaded C++ (pl_boundary_index, host code)
+        ptr, idx = self.cell_points()
+        node_xyz = self.node_coordinates()
+        N = len(node_xyz)
+        if N >= 20000 and not self._compat_rows:   # large lattices: the same rule in multi-threaded C++ (pl_boundary_index)
             from ._capi import boundary_index
-            self.index_boundary, visit = boundary_index(lat.cell_node_ptr, lat.cell_node_idx, lat.node_xyz,
-                                                        lat.cell_coord, lat.cell_size)
+            self.index_boundary, visit = boundary_index(ptr, idx, node_xyz, lat.cell_coord, lat.cell_size)
             self.max_index_boundary = len(visit) - 1
             self._boundary_visit_order = visit
             return
         self.index_boundary = np.full(N, -1, np.int64)
         on_box = np.zeros(N, bool)
-        ptr, idx = lat.cell_node_ptr, lat.cell_node_idx
         cell_of = np.repeat(np.arange(lat.n_cells), np.diff(ptr))
-        xyz = lat.node_xyz[idx]
+        xyz = node_xyz[idx]
         lo, hi = lat.cell_coord[cell_of], lat.cell_coord[cell_of] + lat.cell_size[cell_of]
         on = ((xyz == lo) | (xyz == hi)).any(axis=1)
         on_box[idx[on]] = True
         # visit order: cell-major, then (round(x,9), round(y,9), round(z,9), index); node index already sorts by xyz
         inside = np.ones(len(idx), bool)
         inside[ptr[1:-1]] = False                           # first entry of every cell but the first
-        if len(idx) > 1 and not np.all((np.diff(idx) > 0) | ~inside[1:]):
+        if self._compat_rows:
+            # rows inside a cell come in (round(x, 9), round(y, 9), round(z, 9), index) order (_sorted_nodes,
+            # lattice_sim.py:193-199): design nodes and penalisation points interleave
+            key = np.round(xyz, 9)
+            idx = idx[np.lexsort((idx, key[:, 2], key[:, 1], key[:, 0], cell_of))]
+        elif len(idx) > 1 and not np.all((np.diff(idx) > 0) | ~inside[1:]):
             idx = idx[np.lexsort((idx, cell_of))]           # rows not yet ascending inside their cell
         seq = idx[on_box[idx]]
         # first visit of every node, without sorting: of duplicate targets of a fancy assignment the last one written
@@ -350,10 +419,12 @@ class LatticeSim(LatticeViews):
         lat = self.lattice
         cells = self.get_cells_on_surfaces(surfaceNames)
         names = surface_cells if surface_cells is not None else surfaceNames
+        ptr, idx = self.cell_points()
+        node_xyz = self.node_coordinates()
         out = []
         for c in cells:
-            nodes = lat.cell_node_idx[lat.cell_node_ptr[c]:lat.cell_node_ptr[c + 1]]
-            xyz = lat.node_xyz[nodes]
+            nodes = idx[ptr[c]:ptr[c + 1]]
+            xyz = node_xyz[nodes]
             keep = np.ones(len(nodes), bool)
             for s in names:
                 ax = "XYZ".index(s[0])
@@ -444,6 +515,10 @@ class LatticeSim(LatticeViews):
                 # converge in a few hundred Jacobi iterations and have too few nodes per tile for the coarse levels
                 kw.setdefault("precond", 3)
                 kw.setdefault("palette", 1)
+            if self._compat_rows:
+                from .compat_device import CompatDevice
+                self._device = CompatDevice(self, **kw)
+                return self._device
             self._device = HipLattice(self.lattice.node_xyz, self.lattice.beam_conn, self.lattice.beam_radius,
                                       pen.seg_len, pen.seg_nsub, self.young_modulus, self.poisson_ratio,
                                       pen_coef=self.penalization_coefficient, **kw)

@@ -55,6 +55,8 @@ class FullScaleLatticeSimulation:
         (node_mod, FE vertices in the reference) are interior points of the condensed struts here and are recovered in
         closed form on the device (pl_node_mod) the first time one of them is looked at."""
         self.lattice.displacement_vector[:] = self.u
+        if getattr(self.lattice, "_compat_rows", False):
+            return                                   # reference_compat: the penalisation points are rows of u already
         if self.lattice.is_penalized:
             dev, u, lat = self.device, self._u_solver, self.lattice
             lat._node_mod_pending = lambda: dev.node_mod(u)
@@ -85,13 +87,12 @@ class FullScaleLatticeSimulation:
         nodes = self._fixed.any(axis=1)
         # the reference loops ``for cell: for node in cell.points_cell`` and Point.set_reaction_force ACCUMULATES
         # (point.py:368-380), so a node shared by k cells ends up with k times its reaction.  Kept for parity.
-        lat = self.lattice.lattice
-        mult = np.bincount(lat.cell_node_idx, minlength=lat.n_nodes).astype(float)
+        mult = np.bincount(self.lattice.cell_points()[1], minlength=len(self._fixed)).astype(float)
         self.lattice.reaction_force_vector[nodes] += mult[nodes, None] * R[nodes]
         self.reactions = R
 
     def calculate_reaction_force_and_moment_at_position(self, position, tol: float = 1e-8):
-        d = np.abs(self.lattice.lattice.node_xyz - np.asarray(position, float)).max(axis=1)
+        d = np.abs(self.lattice.node_coordinates() - np.asarray(position, float)).max(axis=1)
         i = int(np.argmin(d))
         if d[i] > tol:
             raise RuntimeError(f"No DOF found near point {position} with tol={tol}.")

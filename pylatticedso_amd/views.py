@@ -62,6 +62,15 @@ class _Tables:
         seg_conn = np.concatenate([np.c_[a[s1], pid[s1, 0]], np.c_[start[sm], stop[sm]], np.c_[pid[s3, 1], b[s3]]])
         seg_parent = np.concatenate([s1, sm, s3])
         seg_part = np.concatenate([np.zeros(len(s1), np.int8), np.ones(len(sm), np.int8), np.full(len(s3), 2, np.int8)])
+        # reference_compat: a split strut shared by k cells is k copies of every segment, copy j living in the beams_cell
+        # of its j-th owner cell only (lattice_sim.py:250-303)
+        mult = getattr(sim, "beam_mult", None) if getattr(sim, "_compat_rows", False) else None
+        seg_copy = np.zeros(len(seg_parent), np.int64)
+        if mult is not None and len(seg_parent) and (mult[seg_parent] > 1).any():
+            rep = mult[seg_parent]
+            seg_copy = np.arange(rep.sum()) - np.repeat(np.cumsum(rep) - rep, rep)
+            seg_conn, seg_parent, seg_part = (np.repeat(seg_conn, rep, axis=0), np.repeat(seg_parent, rep),
+                                              np.repeat(seg_part, rep))
         seg_mod = seg_part != 1
         pc = LA.PENALIZATION_COEFFICIENT
         seg_rad = lat.beam_radius[seg_parent] * np.where(seg_mod, pc, 1.0)
@@ -80,7 +89,9 @@ class _Tables:
         self.beam_mod = np.concatenate([np.zeros(len(keep), bool), seg_mod[so]])
         self.beam_radius = np.concatenate([lat.beam_radius[keep], seg_rad[so]])
         self.beam_index = np.concatenate([keep, B + np.arange(len(so))])                    # reference's Beam.index
+        self.beam_copy = np.concatenate([np.full(len(keep), -1, np.int64), seg_copy[so]])   # -1: one object for all cells
         self.n_beams = len(self.beam_conn)
+        self.has_copies = bool((self.beam_copy > 0).any())
         # strut -> its beams (views): CSR
         o = np.argsort(self.beam_parent, kind="stable")
         ptr = np.zeros(B + 1, np.int64)
@@ -168,7 +179,7 @@ class PointView:
     # -- simulation rows (point.py:68-72)
     def _row(self, name):
         t = _tables(self._sim)
-        if self._i < t.n_design_nodes:
+        if self._i < t.n_design_nodes or getattr(self._sim, "_compat_rows", False):
             return getattr(self._sim, name)[self._i]
         return self._sim._node_mod_rows(name)[self._i - t.n_design_nodes]
 
@@ -179,7 +190,7 @@ class PointView:
 
     @property
     def index_boundary(self):
-        if self.node_mod:
+        if self.node_mod and not getattr(self._sim, "_compat_rows", False):
             return None
         v = int(self._sim.index_boundary[self._i])
         return None if v < 0 else v
@@ -368,6 +379,12 @@ class CellView:
         struts = lat.cell_beam_idx[lat.cell_beam_ptr[self._i]:lat.cell_beam_ptr[self._i + 1]]
         ids = np.concatenate([t.strut_beam_idx[t.strut_beam_ptr[s]:t.strut_beam_ptr[s + 1]] for s in struts]) \
             if len(struts) else np.zeros(0, np.int64)
+        if t.has_copies and len(ids):
+            # copy j of a split strut belongs to the j-th owner cell of the strut (owner cells in ascending order)
+            par = t.beam_parent[ids]
+            rank = np.array([np.searchsorted(t.strut_cell_idx[t.strut_cell_ptr[s]:t.strut_cell_ptr[s + 1]], self._i)
+                             for s in par])
+            ids = ids[(t.beam_copy[ids] < 0) | (t.beam_copy[ids] == rank % np.maximum(1, self._sim.beam_mult[par]))]
         return [BeamView(self._sim, b) for b in np.sort(ids)]
 
     @property
@@ -471,6 +488,8 @@ class LatticeViews:
         """(P, 6) rows of the penalisation points: displacements come from the closed-form back-substitution of the
         last FEM solve (pl_node_mod), the other vectors are zero / free there."""
         t = _tables(self)
+        if getattr(self, "_compat_rows", False):
+            return getattr(self, name)[t.n_design_nodes:]
         store = getattr(self, "_node_mod_store", None)
         if store is None or store.get("tables") is not t:
             P = t.n_nodes - t.n_design_nodes
