@@ -162,6 +162,7 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
             native = None
         if native is None and backend == "native":
             raise RuntimeError("libpylattice_hip's host generator is not available for this lattice")
+    extras = {}
     if native is not None:
         node_xyz, beam_conn = native["node_xyz"], native["beam_conn"]
         beam_radius, beam_type, beam_cell0 = native["beam_radius"], native["beam_type"], native["beam_cell0"]
@@ -172,7 +173,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
             split = _hybrid_collision_split(node_xyz, tmpl, native["pid"].astype(np.int64), native["bid"].astype(np.int64),
                                             beam_conn, beam_radius, beam_type, beam_cell0)
             if split is not None:
-                beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx = split
+                beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx, dmult = split
+                extras["design_mult"] = dmult
                 pair_beam = native["bid"].astype(np.int64)
                 cnt = np.diff(new_of_old_ptr)[pair_beam]
                 start = new_of_old_ptr[pair_beam]
@@ -184,7 +186,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
         return LatticeArrays(node_xyz=node_xyz, beam_conn=beam_conn, beam_radius=beam_radius, beam_type=beam_type,
                              beam_cell0=beam_cell0, cell_pos=pos, cell_coord=coord, cell_size=size,
                              cell_radii=cell_radii, cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr,
-                             cell_node_idx=cn_idx, bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)))
+                             cell_node_idx=cn_idx, bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)),
+                             extras=extras)
 
     # end points of every (cell, template strut): frac*size + coordinate  (cell.py:300-305)
     P1 = tmpl[None, :, 0:3] * size[:, None, :] + coord[:, None, :]
@@ -227,7 +230,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     if len(geom_types) > 1:                                      # lattice.py:482-483
         split = _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, beam_type, beam_cell0)
         if split is not None:
-            beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx = split
+            beam_conn, beam_radius, beam_type, beam_cell0, new_of_old_ptr, new_of_old_idx, dmult = split
+            extras["design_mult"] = dmult
             # every (cell, strut) membership goes to all segments of that strut (per_cell_add, lattice.py:1188-1195)
             cnt = np.diff(new_of_old_ptr)[pair_beam]
             start = new_of_old_ptr[pair_beam]
@@ -243,14 +247,15 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
                          beam_type=beam_type, beam_cell0=beam_cell0,
                          cell_pos=pos, cell_coord=coord, cell_size=size, cell_radii=cell_radii,
                          cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr, cell_node_idx=cn_idx,
-                         bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)))
+                         bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)), extras=extras)
 
 
 def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, beam_type, beam_cell0):
     """Lattice.check_hybrid_collision (lattice.py:1111-1215): in a hybrid lattice a strut of one geometry that passes
     through a node of another geometry OF THE SAME CELL is replaced by the chain of segments between those nodes
     (same radius, type and owner cells; orientation of the original strut).  Returns None when nothing is cut, else the
-    re-indexed strut arrays (define_beam_node_index order, lattice.py:665-685) plus a CSR map old strut -> new struts.
+    re-indexed strut arrays (define_beam_node_index order, lattice.py:665-685), a CSR map old strut -> new struts and the
+    number of copies the reference holds of every new strut.
 
     Two passes: (1) on the unit-cell template, with a tolerance, the few (strut, template point) pairs that can
     collide at all; (2) for those pairs only, in every cell, the reference's exact floating-point tests on the actual
@@ -298,14 +303,20 @@ def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, be
     if not ok.any():
         return None
     cut_beam, cut_node, cut_t = beam_c[ok], node_q[ok], tt[ok]
-    # a strut shared by several cells is cut once per owner cell in the reference, which leaves every segment twice
-    # in the lattice (Beam objects hash by identity): an ill-defined model that is not reproduced here
-    ncell_of_beam = np.bincount(np.unique(np.stack([np.repeat(np.arange(C), nb), bid]), axis=1)[1],
-                                minlength=len(beam_conn))
-    if (ncell_of_beam[cut_beam] > 1).any():
+    # a strut shared by several cells is cut once per owner cell in the reference (the loop does not skip non-primary
+    # owners), and every owner gets ALL the copies (per_cell_add, lattice.py:1188-1195): k identical copies of each
+    # segment, k = number of cells in which the cut was found.  Here every segment exists once and carries that number
+    # (``design_mult``; used by LatticeSim(reference_compat=True) only).  Refused: owner cells that see different cutting
+    # nodes on the same strut (the copies would then be different chains).
+    cut_cell = np.nonzero(ok)[0]
+    per_cell = np.unique(np.stack([cut_cell, cut_beam]), axis=1)
+    ncut_cells = np.bincount(per_cell[1], minlength=len(beam_conn))
+    tri = np.unique(np.stack([cut_cell, cut_beam, cut_node]), axis=1)
+    pairs, cnt = np.unique(tri[1:], axis=1, return_counts=True)
+    if (cnt != ncut_cells[pairs[0]]).any():
         raise NotImplementedError(
-            "hybrid collision on a strut shared by several cells: the reference (lattice.py:1111-1215) splits it once "
-            "per owner cell and keeps every copy, i.e. duplicate struts; this lattice is outside the accelerated path")
+            "hybrid collision: the owner cells of a shared strut see different cutting nodes (lattice.py:1146-1180 would "
+            "leave different chains of segments side by side); this lattice is outside the accelerated path")
     key = np.unique(np.stack([cut_beam, cut_node]), axis=1, return_index=True)[1]
     cut_beam, cut_node, cut_t = cut_beam[key], cut_node[key], cut_t[key]
     order = np.lexsort((cut_t, cut_beam))                        # internal.sort(key=t), lattice.py:1176
@@ -326,6 +337,7 @@ def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, be
     conn = np.concatenate([beam_conn[keep].astype(np.int64), sconn])
     src = np.concatenate([keep, parent])                          # strut (old numbering) every new strut comes from
     rad, typ, cell0 = beam_radius[src], beam_type[src], beam_cell0[src]
+    dmult = np.concatenate([np.ones(len(keep), np.int64), ncut_cells[parent]])
     lo, hi = conn.min(axis=1), conn.max(axis=1)
     pair = lo * len(node_xyz) + hi
     if len(np.unique(pair)) != len(pair):
@@ -337,7 +349,7 @@ def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, be
     o = np.argsort(src, kind="stable")
     ptr = np.zeros(len(beam_conn) + 1, np.int64)
     np.add.at(ptr, src + 1, 1)
-    return (conn[border].astype(np.int32), rad[border], typ[border], cell0[border], np.cumsum(ptr), rank[o])
+    return (conn[border].astype(np.int32), rad[border], typ[border], cell0[border], np.cumsum(ptr), rank[o], dmult[border])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -31,15 +31,17 @@ _DOF = {"X": 0, "Y": 1, "Z": 2, "RX": 3, "RY": 4, "RZ": 5}
 
 class LatticeOpti(LatticeSim):
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0, convergence_plotting: bool = False,
-                 data_roots=None, reference_compat: bool = False):
-        """``reference_compat``: for the "linear" parameterisation return the gradient exactly as the reference computes
-        it (lattice_opti.py:787-841, 719-720) instead of the derivative of the objective (see calculate_gradient)."""
-        self.reference_compat = bool(reference_compat)
+                 data_roots=None, reference_compat=None):
+        """``reference_compat`` (one switch with LatticeSim's): the reference's behaviour where it differs from the consistent
+        one - its model of struts shared by several cells (lattice_sim.py docstring here), and for the "linear"
+        parameterisation its gradient exactly as it computes it (lattice_opti.py:787-841, 719-720) instead of the
+        derivative of the objective (see calculate_gradient)."""
         info = open_lattice_parameters(name_file).get("optimization_informations", {})
         # lattice_opti.py:96-103: simulation_type "DDM" runs every equilibrium through solve_DDM with the cell Schur
         # complements (exact or surrogate) and contracts their derivatives dS/dr for the gradient
         self._ddm_mode = info.get("simulation_type", None) == "DDM"
-        super().__init__(name_file, mesh_trimmer, verbose, self._ddm_mode, data_roots=data_roots)
+        super().__init__(name_file, mesh_trimmer, verbose, self._ddm_mode, data_roots=data_roots,
+                         reference_compat=reference_compat)
         self.solution = None
         self.actual_objective = None
         self.denorm_objective = None

@@ -380,11 +380,13 @@ class CellView:
         ids = np.concatenate([t.strut_beam_idx[t.strut_beam_ptr[s]:t.strut_beam_ptr[s + 1]] for s in struts]) \
             if len(struts) else np.zeros(0, np.int64)
         if t.has_copies and len(ids):
-            # copy j of a split strut belongs to the j-th owner cell of the strut (owner cells in ascending order)
+            # copy j of a split strut belongs to the (j mod owners)-th owner cell of the strut (owner cells in ascending
+            # order; more copies than owners: struts cut by check_hybrid_collision, every owner penalises every copy)
             par = t.beam_parent[ids]
+            own = t.strut_cell_ptr[par + 1] - t.strut_cell_ptr[par]
             rank = np.array([np.searchsorted(t.strut_cell_idx[t.strut_cell_ptr[s]:t.strut_cell_ptr[s + 1]], self._i)
                              for s in par])
-            ids = ids[(t.beam_copy[ids] < 0) | (t.beam_copy[ids] == rank % np.maximum(1, self._sim.beam_mult[par]))]
+            ids = ids[(t.beam_copy[ids] < 0) | (t.beam_copy[ids] % np.maximum(1, own) == rank)]
         return [BeamView(self._sim, b) for b in np.sort(ids)]
 
     @property

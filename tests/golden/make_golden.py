@@ -213,6 +213,9 @@ def gen_lattice_states():
         "bcchybrid1hybrid4_3x2x1_size": _preset(["BCC", "Hybrid1", "Hybrid4"], [0.05, 0.04, 0.03], (3, 2, 1),
                                                 cell_size=(1.5, 1.0, 0.7), bcs=CANTILEVER),
     }
+    # a strut shared by several cells AND cut by another geometry's node (cubic edges through Hybrid1's edge mid-points):
+    # check_hybrid_collision cuts it once per owner cell and gives every owner all copies (lattice.py:1146-1195)
+    cases["cubichybrid1_2x2x2"] = _preset(["Cubic", "Hybrid1"], [0.05, 0.03], (2, 2, 2), bcs=CANTILEVER)
     # one lattice per remaining unit cell of src/pyLatticeDesign/geometries/ (the cells above cover BCC, Octet, Hybrid1,
     # Hybrid4): pins the re-authored strut tables of pylatticedso_amd/geometries.py through the reference's own generator
     for cell, r in (("Auxetic", 0.03), ("BCCZ", 0.05), ("Cubic", 0.05), ("Diamond", 0.04), ("Hybrid2", 0.04),
@@ -488,8 +491,58 @@ def gen_greedy():
     print("greedy_bcc:", {k: v.shape for k, v in res.items()})
 
 
+def gen_gmsh_input():
+    """What the reference HANDS TO gmsh (latticeGeneration.generate_nodes / generate_beams, lattice_generation.py:104-175)
+    for a lattice without and one with struts shared by several cells: gmsh itself is absent, so a recording stand-in takes
+    the addPoint / addLine calls of the reference's own code.  ``line_pts``: the gmsh point ids each line was given;
+    ``line_xyz``: the coordinates of the Beam's OWN end points.  They differ wherever a copy of a shared strut ends on a
+    Point without an index (all of those are looked up as ``self.point[None]``)."""
+    from pyLatticeSim.lattice_generation import latticeGeneration
+
+    class _Geo:
+        def __init__(self):
+            self.pts, self.lines = [], []
+
+        def addPoint(self, x, y, z, meshSize=None):
+            self.pts.append((x, y, z))
+            return len(self.pts)
+
+        def addLine(self, a, b):
+            self.lines.append((a, b))
+            return len(self.lines)
+
+    for name, geom, r in (("bcc_2x2x2", "BCC", 0.05), ("octet_2x2x2", "Octet", 0.03), ("cubic_2x2x2", "Cubic", 0.05)):
+        L = _make(_preset([geom], [r], (2, 2, 2), bcs=CANTILEVER))
+        lg = latticeGeneration(L, None)
+        lg.find_mesh_size(0.05)
+        lg.geom = _Geo()
+        _quiet(lg.generate_nodes, None)
+        # generate_beams de-duplicates by Beam object and returns nothing about order: record the beams as it visits them
+        seen, beams = set(), []
+        for cell in L.cells:
+            for b in cell.beams_cell:
+                if b.radius > 0 and b not in seen:
+                    seen.add(b)
+                    beams.append(b)
+        _quiet(lg.generate_beams, None)
+        assert len(lg.geom.lines) == len(beams)
+        out = dict(points=np.array(lg.geom.pts), line_pts=np.array(lg.geom.lines, dtype=np.int64),
+                   line_xyz=np.array([[[b.point1.x, b.point1.y, b.point1.z], [b.point2.x, b.point2.y, b.point2.z]]
+                                      for b in beams]),
+                   line_radius=np.array([b.radius for b in beams]), line_mod=np.array([bool(b.beam_mod) for b in beams]),
+                   line_end_has_index=np.array([[b.point1.index is not None, b.point2.index is not None] for b in beams]),
+                   point_of_none=np.array(lg.point.get(None, -1)), mesh_size=np.array(lg._mesh_size))
+        np.savez_compressed(os.path.join(OUT, f"gmsh_input_{name}.npz"), **out)
+        print(f"gmsh_input_{name}: {len(out['points'])} points, {len(beams)} lines, "
+              f"{int((~out['line_end_has_index']).any(axis=1).sum())} lines with an end on point[None], "
+              f"{int((out['line_pts'][:, 0] == out['line_pts'][:, 1]).sum())} degenerate")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "opti", "opti_ratio", "surrogate", "greedy"]
+    which = sys.argv[1:] or ["lattice", "schur", "cg", "ddm", "ddm_precond", "opti", "opti_ratio", "surrogate", "greedy",
+                             "gmsh_input"]
+    if "gmsh_input" in which:
+        gen_gmsh_input()
     if "opti" in which:
         gen_opti()
     if "opti_ratio" in which:

