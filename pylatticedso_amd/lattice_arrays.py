@@ -98,7 +98,7 @@ def _csr_from_pairs(rows, cols, nrows):
 
 
 def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim=None, erased_blocks=None,
-             cell_radii_override=None, cell_range=None, backend="auto") -> LatticeArrays:
+             cell_radii_override=None, cell_range=None, backend="auto", want_creator=False) -> LatticeArrays:
     """Lattice.generate_lattice on arrays: cells in i,j,k order, struts of every geometry, nodes and struts
     de-duplicated through coordinates rounded to 9 decimals (first creator wins, cell.py:312-368).
 
@@ -107,7 +107,10 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
 
     ``backend``: "native" = the multi-threaded generator of libpylattice_hip (pl_generate_lattice, host code),
     "numpy" = the vectorised restatement below, "auto" = native when the library is there and accepts the lattice.
-    Both give the same arrays bit for bit (tests/test_host_lattice.py)."""
+    Both give the same arrays bit for bit (tests/test_host_lattice.py).
+
+    ``want_creator``: also return ``extras["node_creator"]``, the position (in the cell list) of the cell that first
+    created every node - the reference constructs a ``Point`` exactly there (cell.py:341-362)."""
     nx, ny, nz = num_cells
     csx, csy, csz = cell_size
     if grad_dim is None:
@@ -157,7 +160,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     if backend in ("auto", "native"):
         try:
             from ._capi import generate_lattice
-            native = generate_lattice(coord, size, cell_radii, tmpl, ttype, want_created=len(geom_types) > 1)
+            native = generate_lattice(coord, size, cell_radii, tmpl, ttype,
+                                      want_created=len(geom_types) > 1 or want_creator)
         except (OSError, FileNotFoundError, AttributeError):
             native = None
         if native is None and backend == "native":
@@ -168,6 +172,10 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
         beam_radius, beam_type, beam_cell0 = native["beam_radius"], native["beam_type"], native["beam_cell0"]
         cb_ptr, cb_idx = native["cell_beam_ptr"], native["cell_beam_idx"]
         cn_ptr, cn_idx = native["cell_node_ptr"], native["cell_node_idx"]
+        if want_creator:
+            creator = np.full(len(node_xyz), C, np.int64)
+            np.minimum.at(creator, native["pid"].reshape(-1).astype(np.int64), np.repeat(np.arange(C), nb * 2))
+            extras["node_creator"] = creator
         if len(geom_types) > 1:                                  # lattice.py:482-483
             cell_of = np.repeat(np.arange(C), nb)
             split = _hybrid_collision_split(node_xyz, tmpl, native["pid"].astype(np.int64), native["bid"].astype(np.int64),
@@ -205,6 +213,8 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
     inv = inv.ravel()
     node_xyz = pts[first]                                        # first creator's coordinates, sorted by (x,y,z)
     pid = inv.reshape(C, nb, 2)
+    if want_creator:
+        extras["node_creator"] = first // (2 * nb)
 
     N = len(node_xyz)
     lo = np.minimum(pid[..., 0], pid[..., 1]).ravel()
@@ -248,6 +258,31 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
                          cell_pos=pos, cell_coord=coord, cell_size=size, cell_radii=cell_radii,
                          cell_beam_ptr=cb_ptr, cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr, cell_node_idx=cn_idx,
                          bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)), extras=extras)
+
+
+def random_cell_radii(node_creator, n_cells, n_geom, range_radius, hybrid, seed=44):
+    """Per-cell radii of ``enable_randomness`` (lattice.py:426,458-465) from the reference's own random stream.
+
+    generate_lattice seeds the MODULE-level generator (``random.seed(44)``) and draws, for every cell that is not erased,
+    ``random.uniform(lo, hi)`` once (or once per geometry with ``randomness_hybrid``).  The same stream is also consumed by
+    ``Point.__init__``, which adds ``random.gauss(0, node_uncertainty_SD)`` to each coordinate even when the deviation is
+    0 (point.py:55-57): three gauss calls for every NEW point a cell creates, between that cell's draw and the next one.
+    ``random.gauss`` produces values in pairs and caches the second, so the calls alternately consume two uniforms and
+    none.  Replayed here with ``random.Random(seed)`` and the number of points every cell creates first."""
+    import random
+    rng = random.Random(seed)
+    lo, hi = float(range_radius[0]), float(range_radius[1])
+    new_points = np.bincount(node_creator, minlength=n_cells)
+    out = np.empty((n_cells, n_geom))
+    gauss = rng.gauss
+    for c in range(n_cells):
+        if hybrid:
+            out[c] = [rng.uniform(lo, hi) for _ in range(n_geom)]
+        else:
+            out[c] = rng.uniform(lo, hi)
+        for _ in range(3 * int(new_points[c])):
+            gauss(0, 0.0)
+    return out
 
 
 def _hybrid_collision_split(node_xyz, tmpl, pid, bid, beam_conn, beam_radius, beam_type, beam_cell0):

@@ -133,8 +133,10 @@ class LatticeSim(LatticeViews):
         if None in [self.cell_size_x, self.cell_size_y, self.cell_size_z, self.num_cells_x, self.num_cells_y,
                     self.num_cells_z, self.radii, self.geom_types]:
             raise ValueError("Missing geometry parameters in JSON file.")
-        if geometry.get("enable_randomness", False):
-            raise NotImplementedError("enable_randomness is outside the accelerated path")
+        # lattice.py:236-238
+        self.enable_randomness = bool(geometry.get("enable_randomness", False))
+        self.range_radius = geometry.get("range_radius", [0.01, 0.1])
+        self.randomness_hybrid = bool(geometry.get("randomness_hybrid", False))
         grad = p.get("gradient", {})
 
         def table(block, keys):
@@ -226,6 +228,18 @@ class LatticeSim(LatticeViews):
             if dev is not None:
                 dev.close()
         self._device = self._ddm_device = None
+        if self.enable_randomness and self._cell_radii_override is None:
+            # lattice.py:458-465: every cell draws its radii from the reference's seeded stream.  The position in that
+            # stream depends on how many points the earlier cells created (LA.random_cell_radii): a geometry-only pass
+            # first, then the lattice with those radii
+            geo = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
+                              (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
+                              self._base_radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,
+                              erased_blocks=self.eraser_blocks, want_creator=True)
+            self._cell_gfac = geo.cell_radii[:, 0] / self._base_radii[0]
+            self._cell_radii_override = LA.random_cell_radii(geo.extras["node_creator"], geo.n_cells,
+                                                             len(self._base_radii), self.range_radius,
+                                                             self.randomness_hybrid)
         self.lattice = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
                                    (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
                                    self._base_radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,

@@ -197,7 +197,19 @@ class PointView:
 
     @property
     def tag(self):
-        v = int(LA.point_tags(self._xyz()[None, :], self._sim.lattice.bbox)[0])
+        """Lattice.apply_tag_all_point (lattice.py:981-1000): tag relative to the lattice box - or, once blocks are erased,
+        relative to the 'continuity box' of the LAST cell that holds the point (get_relative_boundary_box, :1046-1086: per
+        axis the extent of all cells with the same index along that axis)."""
+        sim, box = self._sim, self._sim.lattice.bbox
+        if getattr(sim, "eraser_blocks", None) is not None and not self.node_mod:
+            t, lat = _tables(sim), sim.lattice
+            c = t.node_cell_idx[t.node_cell_ptr[self._i + 1] - 1]
+            box = []
+            for ax in range(3):
+                same = lat.cell_pos[:, ax] == lat.cell_pos[c, ax]
+                box += [lat.cell_coord[same, ax].min(), (lat.cell_coord[same, ax] + lat.cell_size[same, ax]).max()]
+            box = np.asarray(box)
+        v = int(LA.point_tags(self._xyz()[None, :], box)[0])
         return None if v < 0 else v
 
     @property

@@ -216,6 +216,19 @@ def gen_lattice_states():
     # a strut shared by several cells AND cut by another geometry's node (cubic edges through Hybrid1's edge mid-points):
     # check_hybrid_collision cuts it once per owner cell and gives every owner all copies (lattice.py:1146-1195)
     cases["cubichybrid1_2x2x2"] = _preset(["Cubic", "Hybrid1"], [0.05, 0.03], (2, 2, 2), bcs=CANTILEVER)
+    # enable_randomness (lattice.py:426,458-465): per-cell radii from random.seed(44); the stream is shared with
+    # Point.__init__'s random.gauss calls (point.py:55-57), so the draws depend on how many points every cell creates
+    for nm, geoms, radii, hyb, extra in (("random_bcc_3x2x2", ["BCC"], [0.05], False, {}),
+                                         ("random_bccoctet_2x2x3_hybrid", ["BCC", "Octet"], [0.04, 0.03], True, {}),
+                                         ("random_octet_3x3x2_erased", ["Octet"], [0.03], False,
+                                          {"supplementary": {"erased_blocks": {"b": {
+                                              "start_point": {"x": 1.0, "y": 1.0, "z": 0.0},
+                                              "dimensions_block": {"x": 0.5, "y": 0.5, "z": 0.5}}}}})):
+        nc = tuple(int(v) for v in nm.split("_")[2].split("x"))
+        pr = _preset(geoms, radii, nc, bcs=CANTILEVER)
+        pr["geometry"].update(enable_randomness=True, range_radius=[0.02, 0.08], randomness_hybrid=hyb)
+        pr.update(extra)
+        cases[nm] = pr
     # one lattice per remaining unit cell of src/pyLatticeDesign/geometries/ (the cells above cover BCC, Octet, Hybrid1,
     # Hybrid4): pins the re-authored strut tables of pylatticedso_amd/geometries.py through the reference's own generator
     for cell, r in (("Auxetic", 0.03), ("BCCZ", 0.05), ("Cubic", 0.05), ("Diamond", 0.04), ("Hybrid2", 0.04),
