@@ -260,6 +260,112 @@ def generate(cell_size, num_cells, geom_types, radii, grad_radius=None, grad_dim
                          bbox=bbox, cell_size_nominal=(float(csx), float(csy), float(csz)), extras=extras)
 
 
+def apply_symmetry(lat: LatticeArrays, geom_types, plane, reference_point) -> LatticeArrays:
+    """Lattice.apply_symmetry (lattice.py:497-580) on arrays: every cell gets a twin at the mirrored position - its box
+    reflected across the plane through ``reference_point`` (``x'min = 2 x_ref - (x_min + dx)`` for plane "YZ" / "X", and so
+    on), same grid position ``pos``, same size and radii, the SAME unit cell (translated, not reflected).
+
+    The reference builds the twins without the lattice's de-duplication tables: each creates its own Point and Beam objects.
+    Points hash by exact coordinates, so the node SET merges coincident ones (first object kept, re-indexed by coordinates);
+    Beam objects hash by identity, so a strut lying between two twins (or between a twin and its original, on the symmetry
+    plane) exists once per creating cell.  Here every strut exists once; ``extras["design_mult"]`` = number of Beam objects
+    the reference holds of it, ``extras["design_mult_kind"] = "per_cell"`` (each copy sits in ONE cell's beams_cell, unlike
+    the copies of check_hybrid_collision which every owner holds)."""
+    plane = plane.upper()
+    if plane not in {"XY", "XZ", "YZ", "X", "Y", "Z"}:
+        raise ValueError("Invalid symmetry plane. Choose from 'XY', 'XZ', 'YZ', 'X', 'Y', or 'Z'.")
+    ax = {"YZ": 0, "X": 0, "XZ": 1, "Y": 1, "XY": 2, "Z": 2}[plane]
+    if (np.asarray(lat.extras.get("design_mult", [1])) > 1).any():
+        raise NotImplementedError("symmetry of a lattice with struts cut by check_hybrid_collision in several cells")
+    C, G = lat.n_cells, lat.cell_radii.shape[1]
+    coord = lat.cell_coord.copy()
+    coord[:, ax] = 2 * float(reference_point[ax]) - (lat.cell_coord[:, ax] + lat.cell_size[:, ax])
+    tmpl, ttype = [], []
+    for g, name in enumerate(geom_types):
+        fr = get_beam_structure(name)
+        tmpl.append(fr)
+        ttype.append(np.full(len(fr), g, np.int32))
+    tmpl, ttype = np.concatenate(tmpl), np.concatenate(ttype)
+    use = lat.cell_radii[:, ttype] > 0.0                                    # (C, nb): geometries with radius > 0 only
+    P1 = tmpl[None, :, 0:3] * lat.cell_size[:, None, :] + coord[:, None, :]
+    P2 = tmpl[None, :, 3:6] * lat.cell_size[:, None, :] + coord[:, None, :]
+    ci, si = np.nonzero(use)
+    p1, p2 = P1[ci, si], P2[ci, si]
+    rad, typ = lat.cell_radii[ci, ttype[si]], ttype[si]
+    # node set: exact coordinates, originals and twins together, sorted by (x, y, z)  (lattice.py:687-696)
+    allpts = np.concatenate([lat.node_xyz, p1, p2]) + 0.0
+    node_xyz, inv = np.unique(allpts, axis=0, return_inverse=True)
+    inv = inv.ravel()
+    N0, M = lat.n_nodes, len(ci)
+    if len(geom_types) > 1:
+        # hybrid lattices were indexed once already (check_hybrid_collision ends with define_beam_node_index,
+        # lattice.py:1213) and indices are only handed to objects that have none (lattice.py:665-698): the original
+        # nodes and struts keep theirs, the new ones follow in sorted order
+        is_old = np.zeros(len(node_xyz), bool)
+        is_old[inv[:N0]] = True
+        rank = np.empty(len(node_xyz), np.int64)
+        rank[inv[:N0]] = np.arange(N0)
+        rank[~is_old] = N0 + np.arange((~is_old).sum())
+        perm = np.argsort(rank)
+        node_xyz, inv = node_xyz[perm], rank[inv]
+    old = inv[:N0]
+    a_new, b_new = inv[N0:N0 + M], inv[N0 + M:]
+    conn = np.concatenate([old[lat.beam_conn.astype(np.int64)], np.stack([a_new, b_new], axis=1)])
+    radius = np.concatenate([lat.beam_radius, rad])
+    btype = np.concatenate([lat.beam_type, typ])
+    cell0 = np.concatenate([lat.beam_cell0, C + ci])
+    lo, hi = conn.min(axis=1), conn.max(axis=1)
+    # struts that coincide (same two nodes, same radius, same geometry index): one entry, copies counted
+    key = np.stack([lo, hi, btype], axis=1)
+    if len(geom_types) > 1:
+        # beam_key compares COORDINATES; node numbers are no longer in coordinate order here
+        crank = np.empty(len(node_xyz), np.int64)
+        crank[np.lexsort((node_xyz[:, 2], node_xyz[:, 1], node_xyz[:, 0]))] = np.arange(len(node_xyz))
+        klo, khi = np.minimum(crank[lo], crank[hi]), np.maximum(crank[lo], crank[hi])
+    else:
+        klo, khi = lo, hi
+    order = np.lexsort((np.arange(len(conn)), radius, khi, klo))             # beam_key order; first creator first
+    key = np.stack([klo, khi, btype], axis=1)
+    ks, rs = key[order], radius[order]
+    newgrp = np.ones(len(order), bool)
+    newgrp[1:] = (ks[1:] != ks[:-1]).any(axis=1) | (rs[1:] != rs[:-1])
+    gid = np.cumsum(newgrp) - 1
+    first = order[newgrp]
+    dmult = np.bincount(gid)
+    copy_cell0 = cell0[order]
+    if len(geom_types) > 1:
+        # struts that hold an original keep the original's index; the purely new ones follow in key order
+        has_old = first < lat.n_beams
+        newrank = np.empty(len(first), np.int64)
+        newrank[has_old] = first[has_old]
+        newrank[~has_old] = lat.n_beams + np.arange((~has_old).sum())
+        gperm = np.argsort(newrank)
+        copy_cell0 = np.concatenate([copy_cell0[gid == g_] for g_ in gperm]) if len(gperm) else copy_cell0
+        first, dmult = first[gperm], dmult[gperm]
+        gid = newrank[gid]
+    uid = np.empty(len(conn), np.int64)
+    uid[order] = gid
+    B0 = lat.n_beams
+    pair_cell = np.concatenate([np.repeat(np.arange(C), np.diff(lat.cell_beam_ptr)), C + ci])
+    pair_beam = np.concatenate([uid[lat.cell_beam_idx], uid[B0:]])
+    cb_ptr, cb_idx = _csr_from_pairs(pair_cell, pair_beam, 2 * C)
+    pair_cn = np.concatenate([np.repeat(np.arange(C), np.diff(lat.cell_node_ptr)), C + ci, C + ci])
+    pair_n = np.concatenate([old[lat.cell_node_idx], a_new, b_new])
+    cn_ptr, cn_idx = _csr_from_pairs(pair_cn, pair_n, 2 * C)
+    bbox = np.array([node_xyz[:, 0].min(), node_xyz[:, 0].max(), node_xyz[:, 1].min(), node_xyz[:, 1].max(),
+                     node_xyz[:, 2].min(), node_xyz[:, 2].max()])
+    extras = dict(lat.extras)
+    # creating cell of every COPY, in strut order (copies of one strut next to each other, first creator first)
+    extras.update(design_mult=dmult, design_mult_kind="per_cell", n_original_cells=C, design_copy_cell0=copy_cell0)
+    return LatticeArrays(node_xyz=node_xyz, beam_conn=conn[first].astype(np.int32), beam_radius=radius[first],
+                         beam_type=btype[first].astype(np.int32), beam_cell0=cell0[first].astype(np.int32),
+                         cell_pos=np.concatenate([lat.cell_pos, lat.cell_pos]), cell_coord=np.concatenate([lat.cell_coord, coord]),
+                         cell_size=np.concatenate([lat.cell_size, lat.cell_size]),
+                         cell_radii=np.concatenate([lat.cell_radii, lat.cell_radii]), cell_beam_ptr=cb_ptr,
+                         cell_beam_idx=cb_idx, cell_node_ptr=cn_ptr, cell_node_idx=cn_idx, bbox=bbox,
+                         cell_size_nominal=lat.cell_size_nominal, extras=extras)
+
+
 def random_cell_radii(node_creator, n_cells, n_geom, range_radius, hybrid, seed=44):
     """Per-cell radii of ``enable_randomness`` (lattice.py:426,458-465) from the reference's own random stream.
 

@@ -156,8 +156,12 @@ class LatticeSim(LatticeViews):
             blocks.append([s.get("x", 0.0), s.get("y", 0.0), s.get("z", 0.0), d.get("x", 0.0), d.get("y", 0.0),
                            d.get("z", 0.0)])
         self.eraser_blocks = blocks or None
-        if sup.get("symmetries"):
-            raise NotImplementedError("symmetries are outside the accelerated path")
+        self.symmetry_lattice = None                    # lattice.py:294-303
+        sym = sup.get("symmetries", {})
+        if sym:
+            pt = sym.get("reference_point", {})
+            self.symmetry_lattice = {"sym_plane": sym.get("plane", None),
+                                     "sym_point": (pt.get("x", 0.0), pt.get("y", 0.0), pt.get("z", 0.0))}
 
     def define_simulation_parameters(self, name_file):
         """lattice_sim.py:201-238."""
@@ -246,9 +250,16 @@ class LatticeSim(LatticeViews):
                                    erased_blocks=self.eraser_blocks,
                                    cell_radii_override=(None if self._cell_radii_override is None else
                                                         self._cell_radii_override * self._cell_gfac[:, None]))
-        lat = self.lattice
         if self._cell_radii_override is None:      # gradient factor of Cell.get_radius (cell.py:385-412), per cell
-            self._cell_gfac = lat.cell_radii[:, 0] / self._base_radii[0]
+            self._cell_gfac = self.lattice.cell_radii[:, 0] / self._base_radii[0]
+        if self.symmetry_lattice is not None:      # lattice.py:90-91
+            plane, point = self.symmetry_lattice["sym_plane"], self.symmetry_lattice["sym_point"]
+            if plane is None or point is None:
+                raise ValueError("Both symmetry_plane and reference_point must be provided.")
+            self.lattice = LA.apply_symmetry(self.lattice, self.geom_types, plane, point)
+            if len(self._cell_gfac) != self.lattice.n_cells:
+                self._cell_gfac = np.concatenate([self._cell_gfac, self._cell_gfac])
+        lat = self.lattice
         self.x_min, self.x_max, self.y_min, self.y_max, self.z_min, self.z_max = map(float, lat.bbox)
         self.penalized = None
         self.is_penalized = False
@@ -311,7 +322,11 @@ class LatticeSim(LatticeViews):
         split = (pen.seg_len[:, 0] > 0) | (pen.seg_len[:, 2] > 0)
         mult = np.where(split, owners, 1).astype(np.int64)
         dm = lat.extras.get("design_mult")
-        if dm is not None:
+        if dm is not None and lat.extras.get("design_mult_kind") == "per_cell":
+            # twins of apply_symmetry: every copy sits in one cell's beams_cell and is penalised there once - as many
+            # segment copies as owner cells (counted by the cell -> strut table), dm objects when nothing is split
+            mult = np.where(split, owners, dm)
+        elif dm is not None:
             # every design copy is a separate object in every owner cell's beams_cell (lattice.py:1188-1195): each is
             # penalised once per owner cell
             mult = np.where(split, owners * dm, dm)

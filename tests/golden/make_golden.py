@@ -175,10 +175,13 @@ def _dump_angles(preset):
     _quiet(L.define_connected_beams_for_all_nodes)
     _quiet(L.define_angles_between_beams)
     nodes = sorted(L.nodes, key=lambda n: n.index)
-    beams = sorted(L.beams, key=lambda b: b.index)
+    beams = sorted(L.beams, key=lambda b: (b.index, id(b)))
+    # (end points through coordinates: the twins of apply_symmetry end on Point objects that never get an index)
+    by_xyz = {(n.x, n.y, n.z): n.index for n in nodes}
     return dict(
         base_node_xyz=np.array([[n.x, n.y, n.z] for n in nodes]),
-        base_beam_conn=np.array([[b.point1.index, b.point2.index] for b in beams], dtype=np.int64),
+        base_beam_conn=np.array([[by_xyz[(b.point1.x, b.point1.y, b.point1.z)], by_xyz[(b.point2.x, b.point2.y, b.point2.z)]]
+                                 for b in beams], dtype=np.int64),
         base_beam_radius=np.array([b.radius for b in beams]),
         base_beam_type=np.array([b.type_beam for b in beams], dtype=np.int64),
         base_beam_length=np.array([b.length for b in beams]),
@@ -228,6 +231,14 @@ def gen_lattice_states():
         pr = _preset(geoms, radii, nc, bcs=CANTILEVER)
         pr["geometry"].update(enable_randomness=True, range_radius=[0.02, 0.08], randomness_hybrid=hyb)
         pr.update(extra)
+        cases[nm] = pr
+    # symmetries (lattice.py:294-303,497-580): mirrored twins of every cell, built without the de-duplication tables
+    for nm, geoms, radii, plane, ref in (("sym_bcc_2x2x2_yz", ["BCC"], [0.05], "yz", (0.0, 0.0, 0.0)),
+                                         ("sym_octet_2x1x2_xz", ["Octet"], [0.03], "XZ", (0.0, 1.0, 0.0)),
+                                         ("sym_bcchybrid1_2x2x1_z", ["BCC", "Hybrid1"], [0.05, 0.03], "Z", (0.0, 0.0, 0.0))):
+        nc = tuple(int(v) for v in nm.split("_")[2].split("x"))
+        pr = _preset(geoms, radii, nc, enable=False)
+        pr["supplementary"] = {"symmetries": {"plane": plane, "reference_point": dict(zip("xyz", ref))}}
         cases[nm] = pr
     # one lattice per remaining unit cell of src/pyLatticeDesign/geometries/ (the cells above cover BCC, Octet, Hybrid1,
     # Hybrid4): pins the re-authored strut tables of pylatticedso_amd/geometries.py through the reference's own generator

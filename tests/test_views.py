@@ -44,13 +44,17 @@ def test_nodes_match_the_reference_object_graph(golden_dir, name, compat):
     # section 2, defect 1; design nodes are compared everywhere)
     m = slice(0, N) if g["beam_dup"].any() and not compat else slice(None)
     assert np.array_equal([p.index_boundary is not None for p in nodes][m], (g["node_index_boundary"] >= 0)[m])
-    assert np.array_equal([-1 if p.tag is None else p.tag for p in nodes[:N]], g["node_tag"][:N])
+    if not name.startswith("sym_"):      # (the reference tags a symmetric lattice before its twins exist)
+        assert np.array_equal([-1 if p.tag is None else p.tag for p in nodes[:N]], g["node_tag"][:N])
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_beams_and_cells_match_the_reference_object_graph(golden_dir, name):
     # struts shared by several cells: the reference keeps one penalised copy per owner cell - the
     # reference_compat model; the default model has every segment once
+    if name.startswith("sym_"):
+        pytest.skip("apply_symmetry's per-cell copies of un-penalised struts: one entry with a count here "
+                    "(lattice.extras['design_mult'], held to the reference's beam list by tests/test_host_lattice.py)")
     g, L = _load(golden_dir, name, reference_compat=bool(g_has_copies(golden_dir, name)))
     beams = L.beams
     assert len(beams) == L.get_number_beams() == len(g["beam_conn"])
