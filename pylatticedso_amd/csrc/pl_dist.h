@@ -344,11 +344,21 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
       g = new LoopGroup();
       g->world = world;
       g->device = dev;
-      for (int p = 0; p < 2; ++p)
-        for (int q = 0; q < world; ++q)
-          if (hipEventCreateWithFlags(&g->ready[p][q], hipEventDisableTiming) != hipSuccess ||
-              hipEventCreateWithFlags(&g->done[p][q], hipEventDisableTiming) != hipSuccess)
-            return 1;
+      bool ok = true;
+      for (int p = 0; p < 2 && ok; ++p)
+        for (int q = 0; q < world && ok; ++q)
+          ok = hipEventCreateWithFlags(&g->ready[p][q], hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&g->done[p][q], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {   // no half-built group stays registered (ranks attaching later would wait on null events)
+        for (int p = 0; p < 2; ++p)
+          for (int q = 0; q < world; ++q) {
+            if (g->ready[p][q]) (void)hipEventDestroy(g->ready[p][q]);
+            if (g->done[p][q]) (void)hipEventDestroy(g->done[p][q]);
+          }
+        delete g;
+        loop_registry().erase(key);
+        return 1;
+      }
     }
     if (g->world != world || g->device != dev || g->attached >= world) return 6;   // one device, world ranks, once each
     ++g->attached;
@@ -364,6 +374,18 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
   d.world = world;
   d.n_shared = n_shared;
   d.n_shared_global = n_shared_global;
+  // a rank that fails below never reaches the group's first collective: tell the peers now instead of after the timeout
+  struct BreakOnError {
+    Dist &d;
+    bool armed = true;
+    ~BreakOnError() {
+      if (armed && d.loop) {
+        std::lock_guard<std::mutex> lk(d.loop->m);
+        d.loop->broken = true;
+        d.loop->cv.notify_all();
+      }
+    }
+  } guard{d};
   if (d.local_idx.alloc(std::max(1, n_shared)) != hipSuccess) return 2;
   if (d.global_idx.alloc(std::max(1, n_shared)) != hipSuccess) return 2;
   if (d.pack.alloc((size_t)n_shared_global * 6 + 4 * kSlots) != hipSuccess) return 2;   // rows + scalar tail
@@ -387,6 +409,7 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
   if (dist_sum_shared(d, d.weight.p, s)) return 4;
   hipLaunchKernelGGL(k_recip, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, s, n6, d.weight.p);
   if (hipStreamSynchronize(s) != hipSuccess) return 5;
+  guard.armed = false;
   return 0;
 }
 

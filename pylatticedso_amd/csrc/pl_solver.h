@@ -236,8 +236,10 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   st->iterations = 0;
   st->converged = 0;
   st->rel_residual = 0.0;
-  if (!(bb > 0.0)) {   // zero right-hand side -> zero solution
+  if (!(bb > 0.0)) {   // zero right-hand side -> zero solution (a warm start above may have put the previous one into x)
     st->converged = 1;
+    PL_HIP(hipMemsetAsync(c->x.p, 0, n6 * sizeof(double), c->stream));
+    PL_HIP(hipStreamSynchronize(c->stream));
     return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
   }
   const double thresh = rtol * rtol * bb;

@@ -47,6 +47,14 @@ class LoopbackGroup:
         hi = tuple(float(max(s.node_xyz[:, k].max() for s in self.slabs)) for k in range(3))
         self.grid = (lo, hi, n_nodes_sum)
         self.devs = [None] * world
+        try:
+            self._build(young, poisson, device, p2p, opts)
+        except BaseException:
+            self.close()                   # a half-built group must not keep its handles (and their registry attachments)
+            raise
+
+    def _build(self, young, poisson, device, p2p, opts):
+        world = self.world
 
         def create(r):
             s = self.slabs[r]
@@ -76,9 +84,12 @@ class LoopbackGroup:
             except BaseException as e:     # noqa: BLE001 - re-raised below, on the caller's thread
                 with lock:
                     err.append(e)          # in the order the ranks failed
-                d = self.devs[r] if r < len(self.devs) else None
-                if d is not None:          # the other ranks may be waiting for this one at a collective: let them go
-                    d.dist_abort()
+                # the other ranks may be waiting for this one at a collective: let them go.  The broken flag belongs to
+                # the group, so any attached handle will do (this rank's own may not exist yet)
+                for d in [self.devs[r] if r < len(self.devs) else None] + list(self.devs):
+                    if d is not None:
+                        d.dist_abort()
+                        break
         th = [threading.Thread(target=run, args=(r,), name=f"pl-rank-{r}") for r in range(self.world)]
         for t in th:
             t.start()

@@ -218,6 +218,11 @@ def test_warm_start_of_a_design_loop(geom, condense):
             u3, st3 = dev.solve(rtol=1e-9, max_iter=20000)
             assert all(s["converged"] == 1 for s in (st1, st1b, st2, st3))
             assert np.all(u3[fixed2 != 0] == 0.0)
+            # zero right-hand side on a handle that holds a previous solution: the answer is zero, not that solution
+            # (round-3 advisor finding: the early return used to leave the warm start in x)
+            dev.set_bc(fixed2, None, np.zeros_like(f))
+            u0, st0 = dev.solve(rtol=1e-9, max_iter=20000)
+            assert st0["converged"] == 1 and st0["iterations"] == 0 and np.all(u0 == 0.0)
             res[warm] = (u1, u1b, u2, u3, st1["iterations"], st1b["iterations"], st2["iterations"], st3["iterations"])
     cold, warm = res[0], res[1]
     for k in range(4):

@@ -1,6 +1,6 @@
 # A/B of the LDS-resident K*p builds (build_exp/, tools/build_exp.sh) against the gather kernel (PL_TILE_LDS=0)
-R=$GRAFT_REPO_ROOT; cd $R
-run() { python3 tools/profile_kernels.py --reps 20 $ARGS 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', 'K*p %.1f us  iteration %.1f us' % (d['spmv_ms']*1e3, d['pcg_iter_ms']*1e3))"; }
+set -uo pipefail; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R" || exit 1
+run() { python3 tools/profile_kernels.py --reps 20 $ARGS | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', 'K*p %.1f us  iteration %.1f us' % (d['spmv_ms']*1e3, d['pcg_iter_ms']*1e3))"; }
 for i in 1 2; do
 PL_TILE_LDS=0 run old
 run lds_512

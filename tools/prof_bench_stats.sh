@@ -1,7 +1,7 @@
 # rocprofv3 kernel stats of one bench.py invocation.  usage: bash tools/prof_bench_stats.sh TAG <bench.py args...>
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+set -uo pipefail; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- python3 bench.py --cpu-cells 0 --no-e2e --no-streaming "$@" > $O/bench.json 2> $O/bench.log
 find $O/stats -name "*kernel_trace.csv" -delete
 python3 - $O <<'PY'

@@ -1,7 +1,7 @@
 # Round profile: full GPU tests, default bench line, kernel stats under rocprofv3, FETCH/WRITE PMC passes.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02_k}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+set -uo pipefail; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=${1:-r02_k}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || true
 tail -3 $O/tests.log
 python bench.py > $O/bench.json 2> $O/bench.log

@@ -5,7 +5,7 @@
 #   usage (on the GPU box):  bash tools/prof_round3.sh r03_c
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-r03_c}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+set -uo pipefail; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=${1:-r03_c}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python bench.py > $O/bench.json 2> $O/bench.log
 python tools/bench_line.py $TAG < $O/bench.json
 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- python3 bench.py --cpu-cells 0 --no-e2e --no-streaming --large-cells 0 > $O/bench_profiled.json 2> $O/bench_profiled.log

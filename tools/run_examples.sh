@@ -1,6 +1,6 @@
 # Every script of examples/ on the GPU box, non-interactive (MPLBACKEND=Agg); prints status, wall time and the last line.
 # (optimization_DDM_surrogate_chain.py first: it builds the reduced basis domain_decomposition_example.py reads.)
-R=$GRAFT_REPO_ROOT; cd $R; export MPLBACKEND=Agg
+set -uo pipefail; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R" || exit 1; export MPLBACKEND=Agg
 for f in examples/optimization/optimization_DDM_surrogate_chain.py examples/simulation/*.py examples/optimization/Simple_optimization_case.py examples/optimization/graded_bcc_adjoint.py; do
   log=gpurun_out/example_$(basename $f .py).log
   t0=$(date +%s)
