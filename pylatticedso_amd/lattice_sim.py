@@ -525,10 +525,10 @@ class LatticeSim(LatticeViews):
         else:                                     # every dof: 0 for unloaded free ones (no index entry for those)
             silent = ~fixed & (self.applied_force[V] == 0)
             disp, index = np.where(silent, 0.0, U).ravel(), idx6[~silent]
-        # (the reference returns a Python list; a 3 M-entry list costs 50 ms to build at 50^3 cells - small lattices keep the
-        # list, large ones get the int64 array, which every consumer here and in the reference indexes the same way)
-        if len(index) <= 100000:
-            index = index.tolist()
+        # a Python list, as in the reference, whatever the size (one type for every caller: `index + other`, `.index()`,
+        # JSON ...; 3 M entries cost ~50 ms at 50^3 cells); the int64 array stays available beside it
+        self.global_displacement_index_array = index if not OnlyImposed else getattr(self, "global_displacement_index_array", None)
+        index = index.tolist()
         if not OnlyImposed:
             self.global_displacement_index = index
         return np.asarray(disp, dtype=float), index
