@@ -372,8 +372,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     int rc = pl::build_tile_plan(c->tile, conn, N, B, tile_start, tile_of, xyz.data());
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the LDS tile plan failed (" + std::to_string(rc) + ")"));
   }
+  if (o->palette && c->tile.vis_ready && std::getenv("PL_ROWS")) {   // K*p by rows (pl_rows.h, opt-in): palette form only
+    int rc = pl::build_row_plan(c->rows, conn, N, B, tile_start, xyz.data());
+    if (rc) return bail(fail(PL_ERR_HIP, "pl_create: building the row plan failed (" + std::to_string(rc) + ")"));
+  }
   c->h_tile_start = tile_start;
-  stage.mark("tile plan");
+  stage.mark("tile + row plan");
   if (o->precond >= 2 && o->precond <= 4) {
     if (!c->reordered) return bail(fail(PL_ERR_ARG, "pl_create: precond = 2/3/4 (multi-level) needs reorder = 1"));
     c->coarse.tile_level = (o->precond >= 3);

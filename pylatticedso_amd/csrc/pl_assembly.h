@@ -17,6 +17,9 @@ int launch_records(pl_context *c) {
 // behind every palette build and whenever the set of eliminated nodes changes (needs the palette's dense ids: a no-op
 // before the first assembly, whose own palette build then picks the condensed-end bits up).
 void refresh_visit_words(pl_context *c, hipStream_t st) {
+  if (c->rword.p && c->pal_dense_of_slot.p)      // (the row words carry no condensed-end bits: rows are selected by node)
+    hipLaunchKernelGGL(pl::k_row_words, dim3(grid_for(c->rows.n_words)), dim3(pl::kBlock), 0, st, c->rows.n_words,
+                       c->rows.rloc.p, c->rows.rstrut.p, c->pal_id.p, c->pal_dense_of_slot.p, c->rword.p);
   if (!c->vword.p || !c->pal_dense_of_slot.p) return;
   hipLaunchKernelGGL(pl::k_visit_words, dim3(grid_for(c->tile.n_visits)), dim3(pl::kBlock), 0, st, c->tile.n_visits,
                      c->tile.vloc.p, c->tile.vstrut.p, c->pal_id.p, c->pal_dense_of_slot.p,
@@ -38,6 +41,7 @@ int refresh_visit_words_dir(pl_context *c, hipStream_t st) {
 int launch_palette(pl_context *c, hipStream_t st) {
   c->pal_ready = false;
   c->pal_lds = false;
+  c->pal_rows = false;
   c->pal_host_flags[0] = 1;
   c->pal_host_flags[1] = 0;
   if (!c->vword_dir_fresh) {      // (first assembly of a handle without node elimination)
@@ -54,6 +58,10 @@ int launch_palette(pl_context *c, hipStream_t st) {
     PL_HIP(c->pal_dense_of_slot.alloc(pl::kPalSize));
     PL_HIP(c->pal_dense.alloc(pl::kPalDenseMax));
     if (c->tile.vis_ready) PL_HIP(c->vword.alloc((size_t)c->tile.n_visits));
+    if (c->rows.ready) {
+      PL_HIP(c->rword.alloc((size_t)c->rows.n_words));
+      PL_HIP(c->pal_dense2.alloc((size_t)2 * pl::kPalDenseMax));
+    }
     void *pinned = nullptr;
     PL_HIP(hipHostMalloc(&pinned, 2 * sizeof(int), hipHostMallocDefault));
     c->pal_host_flags = static_cast<int *>(pinned);
@@ -71,6 +79,9 @@ int launch_palette(pl_context *c, hipStream_t st) {
   hipLaunchKernelGGL(pl::k_pal_verify, g, blk, 0, st, c->B, c->rec.p, c->pal_id.p, c->palette.p, c->pal_owner.p,
                      c->pal_flags.p, c->pal_dense_of_slot.p, c->pal_dense.p, pl::kPalDenseMax);
   refresh_visit_words(c, st);
+  if (c->pal_dense2.p)
+    hipLaunchKernelGGL(pl::k_pal_orient, dim3(1), dim3(pl::kPalDenseMax), 0, st, pl::kPalDenseMax, c->pal_dense.p,
+                       c->pal_dense2.p);
   PL_HIP(hipGetLastError());
   PL_HIP(hipMemcpyAsync(c->pal_host_flags, c->pal_flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   return PL_OK;
@@ -82,6 +93,10 @@ void finish_palette(pl_context *c) {
   // the LDS-resident K*p (pl_tile.h) when the whole palette fits its LDS table; PL_TILE_LDS=0 keeps the gather kernel (A/B)
   static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
   c->pal_lds = c->pal_ready && c->vword.p && c->pal_entries > 0 && c->pal_entries <= pl::kPalDenseMax && !lds_off;
+  // the row kernel (pl_rows.h): opt-in with PL_ROWS=1 (read at every assembly, so that one process can compare both) -
+  // measured slower than the tile kernel at 50^3 Octet (51 against 36 us: see the header of pl_rows.h)
+  const char *re = std::getenv("PL_ROWS");
+  c->pal_rows = c->pal_lds && c->rword.p && c->pal_dense2.p && re && re[0] == '1';
 }
 int build_palette(pl_context *c) {
   int rc = launch_palette(c, c->stream);

@@ -19,6 +19,7 @@
 #include "pl_kernels.h"
 #include "pl_parallel.h"
 #include "pl_tile.h"
+#include "pl_rows.h"
 #include "pl_dist.h"
 #include "pl_coarse.h"
 #include "pl_cg1.h"
@@ -150,6 +151,11 @@ struct pl_context {
   DevBuf<uint32_t> vword_dir;         // the same with the direction-palette entry (streaming form of the LDS-resident K*p)
   bool vword_dir_fresh = false;
   bool pal_lds = false;               // the LDS-resident K*p applies (palette holds, <= kPalDenseMax entries, visit plan)
+  // K*p by rows (pl_rows.h): plan, per-half-visit words (static bits | dense palette id), palette in both orientations
+  pl::RowPlan rows;
+  DevBuf<uint32_t> rword;
+  DevBuf<pl::Record> pal_dense2;
+  bool pal_rows = false;              // the row kernel applies (same conditions as pal_lds, plus the row plan)
   DevBuf<pl::Record> palette;
   bool pal_ready = false;
   int pal_entries = 0;

@@ -90,6 +90,10 @@ template <typename VT>
 void tile_launch(pl_context *c, const uint8_t *maskbits, const VT *x, VT *y, double *dot_dev, int ends, const uint8_t *cf,
                  const pl::CondSolve &cs, const int32_t *list = nullptr, int64_t n_list = 0) {
   static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
+  if (c->pal_rows &&
+      pl::launch_spmv_rows<VT>(c->rows, c->rword.p, c->pal_dense2.p, c->pal_entries, maskbits, x, y, dot_dev, c->stream,
+                               ends, cf, cs, list, n_list))
+    return;
   if (c->pal_lds &&
       pl::launch_tile_spmv_lds<VT>(c->tile, c->vword.p, c->pal_dense.p, c->pal_entries, nullptr, maskbits, x, y, dot_dev,
                                    c->stream, ends, cf, cs, list, n_list))

@@ -1124,3 +1124,44 @@ def test_device_lzone_large_and_errors():
     bad[0, 0] = 9
     with pytest.raises(_capi.PlError):
         _capi.lzone(xyz, bad, np.array([0.1, 0.2, 0.3]))
+
+
+@pytest.mark.parametrize("name", ["bcc_4x4x4", "octet_3x2x2_size", "bccoctet_2x2x2", "kelvin_2x2x2"])
+def test_row_form_of_the_operator_matches_oracle(golden_dir, name, monkeypatch):
+    """K*p by rows (pl_rows.h, opt-in with PL_ROWS=1: one lane per node, every strut evaluated once per end from a palette
+    that holds both orientations, records through scalar registers, no atomics) against the ORACLE's assembled K - plain,
+    masked with p.Ap, and through solves with and without node elimination (whose two passes are row selections there) -
+    and bit for bit against itself (fixed summation order)."""
+    monkeypatch.setenv("PL_ROWS", "1")
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal(6 * lat.n_nodes)
+    fixed = rng.random((lat.n_nodes, 6)) < 0.15
+    m = (~fixed).ravel().astype(float)
+    for tile_nodes in (0, 16):
+        with _device(L, spmv_kernel=3, palette=1, tile_nodes=tile_nodes) as dev:
+            dev.assemble()
+            y = dev.spmv(x).ravel()
+            assert _rel(y, K @ x) < 1e-11                     # (palette records are compared on 40 mantissa bits)
+            assert np.array_equal(y, dev.spmv(x).ravel())       # no atomics: the same bits every time
+            dev.set_bc(fixed)
+            assert _rel(dev.spmv_free(x).ravel(), m * (K @ (m * x))) < 1e-11
+    # solves: cantilever, Jacobi and multi-level, node elimination forced on and off
+    fx = np.zeros((lat.n_nodes, 6), np.uint8)
+    fx[lat.node_xyz[:, 0] == lat.node_xyz[:, 0].min()] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == lat.node_xyz[:, 0].max(), 2] = -1e-3
+    u_ref = O.solve_dirichlet(K, fx.astype(bool), np.zeros_like(f), f).ravel()
+    for kw in (dict(precond=1), dict(precond=3, tile_nodes=16, coarse_max_dofs=96, condense=1),
+               dict(precond=3, tile_nodes=16, coarse_max_dofs=96, condense=-1)):
+        with _device(L, palette=1, **kw) as dev:
+            dev.set_bc(fx, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st["converged"] == 1 and _rel(u.ravel(), u_ref) < 1e-7, kw
+    monkeypatch.setenv("PL_ROWS", "0")
+    with _device(L, spmv_kernel=3, palette=1) as dev:           # the tile kernel on the same handle settings
+        dev.assemble()
+        assert _rel(dev.spmv(x).ravel(), y) < 1e-12
