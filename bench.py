@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 E, NU = 1013.0, 0.3
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_CU, CLOCK_HZ = 256, 2.4e9   # MI355X_MICROARCH.md: 256 CUs in 8 XCDs, 2.4 GHz engine clock
 
 CONFIGS = {
     1: dict(cells=(50, 50, 50), geom=["Octet"], radii=[0.03], axis=1, scaling="weak", precision=0, tile_modes=0,
@@ -63,6 +64,34 @@ def cantilever_bc(xyz, x_max, n_targets_global=None):
     cnt = n_targets_global if n_targets_global is not None else int(tgt.sum())
     f[tgt, 2] = -0.1 / cnt
     return fixed, f, tgt
+
+
+def roofline_of(args, achieved, traffic, traffic_src, ab, ms_spmv, issue):
+    """The `roofline` object of the line.  With the record palette (the headline lattice) K*p is bound by the vector ALU and
+    the LDS pipe: frac = the busier of the two (issue-rate model, committed SQ counters, this run's kernel time), and the
+    SURVEY 8(d) byte figure is kept beside it as `algorithmic_equiv` (it is not a bound there: it exceeds 1 at 100^3).
+    Without the palette, or without counters for this kernel, the HBM form: algorithmic bytes / time / 8 TB/s."""
+    kname = "K*p: " + dev_kernel_name(args.kernel, args.reorder, args.palette)
+    real = (traffic / (ms_spmv * 1e-3) / 1e9) if traffic else None
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes": ab["spmv"]}
+    if issue is None:
+        return {"bound": "hbm", "kernel": kname, **hbm, "traffic": traffic, "traffic_source": traffic_src,
+                "real_frac": (real / HBM_PEAK_GBS) if real else None, "ms": ms_spmv}
+    frac = max(issue["valu_issue_frac"], issue["lds_active_frac"])
+    return {"bound": "valu+lds", "kernel": kname, "achieved": issue["valu_wave_instructions"] / issue["cu_clocks"],
+            "peak": 1.0, "unit": "vector wave-instructions / clock / CU", "frac": min(frac, 1.0),
+            "valu_issue_frac": issue["valu_issue_frac"], "lds_active_frac": issue["lds_active_frac"],
+            "valu_lane_utilisation": issue["valu_lane_utilisation"],
+            "lds_wait_share_of_wave_cycles": issue["lds_wait_share_of_wave_cycles"],
+            "counters_source": issue["counters_source"], "model": "a CU issues at most one vector instruction per clock "
+            "(4 SIMDs x 1 wave instruction / 4 clocks) and its LDS serves one access stream; frac = max(VALU issue share, "
+            "LDS-active share) over n_cu x clock x the K*p time of this run",
+            "traffic": traffic, "traffic_source": traffic_src, "hbm_real_frac": (real / HBM_PEAK_GBS) if real else None,
+            "algorithmic_equiv": {**hbm, "note": "SURVEY 8(d) bytes (a 64-byte record per strut) / time / 8 TB/s - what the "
+                                  "line carried as roofline.frac until round 3; not a bound for this kernel: the palette "
+                                  "turns the record into an 8-bit id (real traffic: hbm_real_frac)"},
+            "ms": ms_spmv}
 
 
 def dev_kernel_name(kernel, reorder, palette=0, streaming=False):
@@ -489,6 +518,27 @@ def main():
     traffic, traffic_src = committed_pmc("pmc_spmv_latest.json",
                                          spmv_kernel=dev_kernel_name(args.kernel, args.reorder, args.palette),
                                          record_palette=args.palette)
+    # What bounds the palette form of K*p is not HBM (its real traffic is 0.28 of the roofline, and at 100^3 the SURVEY 8(d)
+    # byte model gives MORE than the roofline): it is the vector ALU and the LDS pipe.  Issue-rate model from the committed
+    # SQ counter passes of the same workload / kernel (tools/prof_kp_sq.sh): a CU issues at most one vector instruction per
+    # clock (four SIMDs, one wave instruction every four clocks each) and its LDS is busy or not in every clock;
+    # frac = the busier of the two over the kernel's duration measured in THIS run.
+    issue = None
+    sq_path = os.path.join(ROOT, "profiles", "sq_spmv_latest.json")
+    if headline and os.path.exists(sq_path):
+        sq = json.load(open(sq_path))
+        if sq.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder, args.palette) and \
+                sq.get("record_palette") == args.palette:
+            cu_clocks = N_CU * CLOCK_HZ * ms_spmv * 1e-3
+            cnt = sq["counters"]
+            issue = {"valu_issue_frac": cnt["SQ_INSTS_VALU"] / cu_clocks, "lds_active_frac": cnt["SQ_LDS_IDX_ACTIVE"] / cu_clocks,
+                     "valu_lane_utilisation": cnt["SQ_THREAD_CYCLES_VALU"] / (64.0 * cnt["SQ_INSTS_VALU"]),
+                     "lds_wait_share_of_wave_cycles": cnt["SQ_WAIT_INST_LDS"] / cnt["SQ_WAVE_CYCLES"],
+                     "valu_wave_instructions": cnt["SQ_INSTS_VALU"], "lds_instructions": cnt["SQ_INSTS_LDS"],
+                     "cu_clocks": cu_clocks, "clock_hz": CLOCK_HZ, "n_cu": N_CU,
+                     "counters_source": {"file": "profiles/sq_spmv_latest.json", "measured_on": sq.get("build"),
+                                         "note": "rocprofv3 --pmc is a separate pass: the committed counters of this "
+                                                 "workload / kernel, priced with the kernel time of this run"}}
 
     # The same kernel on lattices whose records do NOT repeat (graded / optimised radii: what every pl_update_radii loop
     # runs): K*p then streams one 40-byte record per strut instead of 2-byte palette ids.  Measured on this lattice with
@@ -556,10 +606,15 @@ def main():
                 lab = dl.algorithmic_bytes()
                 ms = dl.time_kernel(0, 20)
                 t_l, src_l = committed_pmc(f"pmc_spmv_large_{tag}_latest.json")
-                large[tag] = {"ms": ms, "achieved": lab["spmv"] / (ms * 1e-3) / 1e9,
-                              "frac": lab["spmv"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t_l, "traffic_source": src_l,
+                ach = lab["spmv"] / (ms * 1e-3) / 1e9
+                large[tag] = {"ms": ms, "traffic": t_l, "traffic_source": src_l,
                               "real_frac": (t_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_l else None,
                               "pcg_iteration_ms": dl.time_kernel(3, 20)}
+                if pal:     # palette form: bound by the vector ALU / LDS (see `roofline`); the byte model is not a bound
+                    large[tag].update(bound="valu+lds", frac=None,
+                                      algorithmic_equiv={"achieved": ach, "frac": ach / HBM_PEAK_GBS, "unit": "GB/s"})
+                else:
+                    large[tag].update(bound="hbm", achieved=ach, frac=ach / HBM_PEAK_GBS)
                 large["algorithmic_bytes"] = lab["spmv"]
         del llat, lpen
 
@@ -603,18 +658,7 @@ def main():
                             "LatticeSim(reference_compat=True): same kernels with a per-strut multiplicity, timed once "
                             "through the drop-in call site in end_to_end_reference_compat_s"
                             if "Octet" in cfg["geom"] else None},
-        "roofline": {"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder, args.palette),
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "real_frac": (traffic / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "algorithmic_bytes": ab["spmv"], "ms": ms_spmv,
-                     "note": "frac prices the ALGORITHMIC bytes of SURVEY 8(d) (64-byte record per strut); on this "
-                             "single-radius lattice the record palette replaces them by an id inside one 32-bit word per "
-                             "strut visit (k_spmv_tile_lds: rows of x and the palette in LDS), so the bytes that really "
-                             "move (traffic, PMC) are a fraction of them and real_frac = traffic / time / peak is the honest HBM figure "
-                             "of this launch - and at 50^3 the working set fits the 256 MiB Infinity Cache, whose hits "
-                             "FETCH_SIZE counts: see roofline_large (far beyond that cache) and roofline_streaming (lattices "
-                             "with per-strut records, what every pl_update_radii loop runs)"},
+        "roofline": roofline_of(args, achieved, traffic, traffic_src, ab, ms_spmv, issue),
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
