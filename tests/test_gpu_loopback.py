@@ -3,6 +3,8 @@ pylatticedso_amd/loopback.py): the same pack / exchange / weight / coarse-band /
 device code an RCCL run executes, one host thread per rank, contributions summed through device buffers.  Every case is
 held to the single-handle solve of the un-partitioned lattice (which tests/test_gpu_parity.py holds to the oracle):
 1e-8 relative L2 on displacements, written at each assert."""
+import os
+
 import numpy as np
 import pytest
 
@@ -226,3 +228,56 @@ def test_config2_as_eight_slabs_full_size():
         # the clamped face does not move
         assert all(np.all(u[fx != 0] == 0.0) for u, fx in zip(us, fixed))
         assert min(float(u[:, 2].min()) for u in us) < 0.0
+
+
+def test_config4_as_eight_slabs_full_size():
+    """BASELINE.json configs[4] AS NAMED: the 200 x 200 x 50 BCC+Octet hybrid (64.2 M struts) cut into 8 x-slabs, fp32
+    matrix-free PCG with fp64 residual refinement (precision = 1), one handle per slab through the loopback transport - the
+    device code of the 8-GPU run on one GPU.  Every rank converges with the same count (330 measured in round 3, 324 on one
+    handle), the Dirichlet rows are exact, and the TRUE fp64 residual of the assembled solution through the partitioned
+    operator meets the tolerance."""
+    with LoopbackGroup((1, 1, 1), (200, 200, 50), ["BCC", "Octet"], [0.04, 0.03], 8, axis=0, young=E, poisson=NU, precond=3,
+                       palette=1, precision=1, tile_modes=6) as g:
+        assert g.n_beams > 64_000_000
+        fixed, f = g.cantilever(200.0)
+        g.set_bc(fixed, None, f)
+        g.assemble()
+        res = g.solve(rtol=1e-8, max_iter=5000)
+        stats = [st for _, st in res]
+        assert all(st["converged"] == 1 for st in stats)
+        assert all(st["precision_used"] == 1 for st in stats)
+        assert len({st["iterations"] for st in stats}) == 1 and stats[0]["iterations"] <= 420
+        us = [u for u, _ in res]
+        Ku = g.spmv_free(us)
+        num = sum(float((((1 - fx) * (ff - np.asarray(k).reshape(-1, 6))) ** 2).sum()) for fx, ff, k in zip(fixed, f, Ku))
+        den = sum(float((ff ** 2).sum()) for ff in f)
+        assert np.sqrt(num / den) < 1e-7
+        assert all(np.all(u[fx != 0] == 0.0) for u, fx in zip(us, fixed))
+        assert min(float(u[:, 2].min()) for u in us) < 0.0
+
+
+@pytest.mark.parametrize("config,cells,extra", [(1, ["12"], []), (2, ["16"], []), (4, ["16", "16", "8"], [])])
+def test_bench_force_dist_rehearsal(config, cells, extra):
+    """The code path `python -m torch.distributed.run ... bench.py --gpus N --config C` takes on every rank - slab build,
+    gloo bootstrap, RCCL communicator inside the library (pl_dist_init), collective pl_set_bc / pl_assemble / pl_solve,
+    pl_time_kernel of the two collectives - with ONE rank (--force-dist), on small cubes of the three configurations: so that
+    the launch the driver makes on an 8-GPU node cannot rot unseen.  The JSON line must carry the contract's keys and a
+    converged solve."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + config), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", str(config), "--force-dist",
+           "--steps", "2", "--warmup", "1", "--cells", *cells, "--cpu-cells", "0", "--no-e2e", "--no-streaming",
+           "--large-cells", "0", *extra]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["converged"] == 1
+    assert "collectives_ms" in line and set(line["collectives_ms"]) == {"interface_exchange", "coarse_allreduce"}
+    assert "RCCL" in line["config"]["partition"]
