@@ -527,6 +527,40 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
     std::stable_sort(order.begin(), order.end(), [&](int32_t l, int32_t r) { return cell_S[l] < cell_S[r]; });
     PL_HIPC(c->ddm_order.alloc(order.size()));
     PL_HIPC(hipMemcpy(c->ddm_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // tiles of 16 cells of one matrix class for the matrix-pipe product (k_ddm_cell_product_mfma)
+    std::vector<int32_t> tiles, tile_S;
+    for (size_t q = 0; q < order.size();) {
+      const int32_t id = cell_S[order[q]];
+      size_t e = q;
+      while (e < order.size() && cell_S[order[e]] == id) ++e;
+      for (size_t a = q; a < e; a += 16) {
+        for (size_t k = 0; k < 16; ++k) tiles.push_back(a + k < e ? order[a + k] : -1);
+        tile_S.push_back(id);
+      }
+      q = e;
+    }
+    c->ddm_n_tiles = (int64_t)tile_S.size();
+    if (m <= 48) {
+      const int KS = m <= 32 ? 8 : 12;
+      std::vector<int32_t> gidx((size_t)c->ddm_n_tiles * KS * 64, -1);
+      for (int64_t t = 0; t < c->ddm_n_tiles; ++t)
+        for (int kk = 0; kk < KS; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int32_t cell = tiles[16 * t + (lane & 15)];
+            const int k = 4 * kk + (lane >> 4);
+            if (cell >= 0 && k < m)
+              gidx[((size_t)t * KS + kk) * 64 + lane] = 6 * cell_nodes[(int64_t)cell * nb + k / 6] + k % 6;
+          }
+      PL_HIPC(c->ddm_tile_gidx.alloc(std::max<size_t>(1, gidx.size())));
+      if (!gidx.empty())
+        PL_HIPC(hipMemcpy(c->ddm_tile_gidx.p, gidx.data(), gidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    PL_HIPC(c->ddm_tiles.alloc(std::max<size_t>(1, tiles.size())));
+    PL_HIPC(c->ddm_tile_S.alloc(std::max<size_t>(1, tile_S.size())));
+    if (!tiles.empty()) {
+      PL_HIPC(hipMemcpy(c->ddm_tiles.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      PL_HIPC(hipMemcpy(c->ddm_tile_S.p, tile_S.data(), tile_S.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
   }
   const size_t n6 = (size_t)n_nodes * 6;
   PL_HIPC(c->fixed.alloc(n6));

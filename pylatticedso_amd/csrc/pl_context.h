@@ -132,6 +132,9 @@ struct pl_context {
   DevBuf<int32_t> ddm_node_ent;
   DevBuf<double> ddm_stage;           // [cells][6 nb] local products
   DevBuf<int32_t> ddm_order;          // cells sorted by matrix id (k_ddm_cell_product_lds)
+  DevBuf<int32_t> ddm_tiles, ddm_tile_S;   // tiles of 16 cells of one matrix class (-1 = padding), their class (k_ddm_cell_product_mfma)
+  int64_t ddm_n_tiles = 0;
+  DevBuf<int32_t> ddm_tile_gidx;     // [tiles][ceil(m / 4)][64]: position in x of every A-operand entry (-1: zero)
   // assembled-Schur preconditioner of the DDM operator (opt.precond = 2): optional palette of its own + dense factor
   DevBuf<int32_t> ddm_cell_P;
   DevBuf<double> ddm_Pt;

@@ -187,6 +187,90 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_reg(int64_t C, int 
   }
 }
 
+// The cell product on the fp64 matrix pipe (round 4; SURVEY.md 8(f1): "the one place a small MFMA / batched GEMV helps").
+// Cells of one matrix class form tiles of 16 (host-built list, -1 = padding): Y[16 cells x m] = U[16 x m] S^T[m x m] with
+// v_mfma_f64_16x16x4_f64 - per tile ceil(m / 4) x ceil(m / 16) instructions (36 for the BCC cell, m = 48).  S^T lives in
+// registers as the B operands (lane (k, j): rows k + 4 kk, columns j + 16 blk; 36 doubles per lane at m = 48), loaded
+// once per wave and kept while the class does not change; the A operand of a lane is its cell's gathered displacement
+// (cell i = lane & 15, components (lane >> 4) + 4 kk); D comes back as [cell (lane >> 4) + 4 r][column lane & 15], so a store
+// instruction writes 16 consecutive doubles of four staging rows.  The register-GEMV form (k_ddm_cell_product_reg) issued
+// two v_readlane per multiply-add and reloaded a lane's row of S every eight cells: 28.7 us at 32^3 cells against 12.8 us
+// here (profiles/r04_g_ddm32_*; one tile per wave: eight per wave left the chip with 256 waves and took 44.9 us).
+// Operand / result layout as in pl_dense.h.  The reference's skip rule (sum of a cell's displacements == 0 -> zero
+// reactions, lattice_sim.py:1239) is kept: the four lanes of a cell add their partial sums.
+typedef double v4f64_ddm __attribute__((ext_vector_type(4)));
+#ifndef PL_DDM_TPW
+#define PL_DDM_TPW 1
+#endif
+constexpr int kDdmTilesPerWave = PL_DDM_TPW;
+template <int KS, int NB16>
+__global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tiles, int nb, const int32_t *__restrict__ tiles,
+                                                                  const int32_t *__restrict__ tile_S,
+                                                                  const int32_t *__restrict__ gidx /* [n_tiles][KS][64] */,
+                                                                  const double *__restrict__ St,
+                                                                  const double *__restrict__ x,
+                                                                  double *__restrict__ stage) {
+  const int m = 6 * nb;
+  const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t t0 = w * kDdmTilesPerWave;
+  if (t0 >= n_tiles) return;
+  double Bs[KS][NB16];
+  int loaded = -1;
+  for (int q = 0; q < kDdmTilesPerWave; ++q) {
+    const int64_t t = t0 + q;
+    if (t >= n_tiles) break;                                   // (wave-uniform)
+    const int id = tile_S[t];
+    if (id != loaded) {
+      const double *S = St + (size_t)id * m * m;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int b = 0; b < NB16; ++b) {
+          const int k = 4 * kk + kq, j = 16 * b + i;
+          Bs[kk][b] = (k < m && j < m) ? S[(size_t)k * m + j] : 0.0;        // St[k][j] = S[j][k]
+        }
+      // (tried: S through LDS once per workgroup, B operands from there: 15.0 against 12.8 us - the barrier and the
+      // extra hop cost more than the L2 reads they save)
+      loaded = id;
+    }
+    const int32_t cell = tiles[16 * t + i];
+    // (the position in x of every operand entry was resolved on the host: one hop, the index loads coalesced)
+    int32_t gi[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) gi[kk] = gidx[((int64_t)t * KS + kk) * 64 + lane];
+    double Au[KS];
+    double part = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      Au[kk] = gi[kk] >= 0 ? x[gi[kk]] : 0.0;
+      part += Au[kk];
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    const int skip = (part == 0.0) ? 1 : 0;                     // of cell i, in all four lanes that hold it
+    v4f64_ddm acc[NB16];
+#pragma unroll
+    for (int b = 0; b < NB16; ++b) acc[b] = v4f64_ddm{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int b = 0; b < NB16; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[kk], Bs[kk][b], acc[b], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = kq + 4 * r;                               // D row = cell `row` of the tile
+      const int32_t crow = __shfl(cell, row);
+      const int srow = __shfl(skip, row);
+      if (crow < 0) continue;
+#pragma unroll
+      for (int b = 0; b < NB16; ++b) {
+        const int j = 16 * b + i;
+        if (j < m) stage[(int64_t)crow * m + j] = srow ? 0.0 : acc[b][r];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_ddm_node_gather(int64_t N, const int64_t *__restrict__ node_ptr,
                                                             const int32_t *__restrict__ node_ent,
                                                             const double *__restrict__ stage,

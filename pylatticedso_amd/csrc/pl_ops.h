@@ -155,7 +155,16 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     const int m = 6 * c->ddm_nb;
     const size_t lds = ((size_t)m * m + (size_t)(pl::kBlock / pl::kWave) * m) * sizeof(double);
     const unsigned gw = grid_for((c->ddm_cells + pl::kDdmWaveChunk - 1) / pl::kDdmWaveChunk, pl::kBlock / pl::kWave);
-    if (m <= 48)
+    static const bool mfma_off = [] { const char *e = std::getenv("PL_DDM_MFMA"); return e && e[0] == '0'; }();
+    const unsigned gm = grid_for((c->ddm_n_tiles + pl::kDdmTilesPerWave - 1) / pl::kDdmTilesPerWave, pl::kBlock / pl::kWave);
+#define PL_DM(KS, NB16)                                                                                                 \
+  hipLaunchKernelGGL((pl::k_ddm_cell_product_mfma<KS, NB16>), dim3(gm), dim3(pl::kBlock), 0, c->stream, c->ddm_n_tiles, \
+                     c->ddm_nb, c->ddm_tiles.p, c->ddm_tile_S.p, c->ddm_tile_gidx.p, c->ddm_St.p, x, c->ddm_stage.p)
+    if (!mfma_off && c->ddm_n_tiles > 0 && c->ddm_tile_gidx.p && m <= 32)
+      PL_DM(8, 2);
+    else if (!mfma_off && c->ddm_n_tiles > 0 && c->ddm_tile_gidx.p && m <= 48)
+      PL_DM(12, 3);
+    else if (m <= 48)
       hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<48>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
                          c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);
     else if (m <= 64)
@@ -169,6 +178,7 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
       hipLaunchKernelGGL(pl::k_ddm_cell_product, dim3(grid_for(c->ddm_cells, pl::kBlock / pl::kWave)), dim3(pl::kBlock),
                          0, c->stream, c->ddm_cells, c->ddm_nb, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x,
                          c->ddm_stage.p);
+#undef PL_DM
     hipLaunchKernelGGL(pl::k_ddm_node_gather, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
                        c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y);
     if (masked || dot_dev)
