@@ -83,13 +83,59 @@ class FullScaleLatticeSimulation:
 
     def set_reaction_force_on_lattice_with_FEM_results(self):
         """full_scale_lattice_simulation.py:111-120: R_i = v_i^T K u for the 6 dofs of every constrained node."""
-        R = self.device.reactions(self.u)
+        R = self.device.reactions(self.u) + self._loaded_constraint_correction()
         nodes = self._fixed.any(axis=1)
         # the reference loops ``for cell: for node in cell.points_cell`` and Point.set_reaction_force ACCUMULATES
         # (point.py:368-380), so a node shared by k cells ends up with k times its reaction.  Kept for parity.
         mult = np.bincount(self.lattice.cell_points()[1], minlength=len(self._fixed)).astype(float)
         self.lattice.reaction_force_vector[nodes] += mult[nodes, None] * R[nodes]
         self.reactions = R
+
+    def _loaded_constraint_correction(self):
+        """A point load on a CONSTRAINED dof (dolfinx adds loads after the Dirichlet rows: u_c = ubar_c + f_c,
+        simulation_base.py:494-498) enters the reference's reactions R = K u through the FIRST SUB-ELEMENT of every strut at
+        that node only - the sub-nodes behind it were solved with u_c = ubar_c - whereas the condensed strut here answers the
+        displaced end as a whole.  For the (rare) dofs concerned: remove the condensed struts' answer to f_c and put the first
+        sub-element's in (rows of the node itself, and of the segment's other end when the segment is one sub-element)."""
+        from .compat_device import _segment_stiffness
+        from .views import _tables
+        sim, fixed, f = self.lattice, self._fixed, self._f
+        hit = fixed & (f != 0)
+        out = np.zeros_like(self.u)
+        if not hit.any():
+            return out
+        delta = np.where(hit, f, 0.0)
+        out -= self.device.spmv(delta)                                    # what the condensed struts answered to f_c (K delta)
+        lat, pen, t = sim.lattice, sim.penalized, _tables(sim)
+        mult = sim.beam_mult if getattr(sim, "beam_mult", None) is not None else np.ones(lat.n_beams)
+        nodes = np.flatnonzero(hit.any(axis=1))
+        rows_n = len(self.u)
+        for end in (0, 1):
+            struts = np.flatnonzero(np.isin(lat.beam_conn[:, end], nodes))
+            if not len(struts):
+                continue
+            # first segment seen from this end: the penalised one if present, else the middle one
+            k = np.where(pen.seg_len[struts, 2 * end] > 0, 2 * end, 1)
+            L, n = pen.seg_len[struts, k], pen.seg_nsub[struts, k]
+            rad = lat.beam_radius[struts] * np.where(k == 1, 1.0, sim.penalization_coefficient)
+            a, b = lat.node_xyz[lat.beam_conn[struts, 0]], lat.node_xyz[lat.beam_conn[struts, 1]]
+            tdir = (b - a) / np.linalg.norm(b - a, axis=1)[:, None] * (1.0 if end == 0 else -1.0)   # away from this end
+            Ke = _segment_stiffness(L / n, np.ones(len(struts)), rad, tdir * (L / n)[:, None], sim.young_modulus,
+                                    sim.poisson_ratio)
+            i = lat.beam_conn[struts, end]
+            d = delta[i]                                                   # (S, 6)
+            np.add.at(out, i, mult[struts, None] * np.einsum("sij,sj->si", Ke[:, :6, :6], d))
+            # one sub-element: its other end is a row of the model (the penalisation point, or the strut's other node)
+            one = n == 1
+            if one.any():
+                other = np.where(k[one] == 1, lat.beam_conn[struts[one], 1 - end], t.pen_id[struts[one], end])
+                # (a middle segment that ends on the far penalisation point)
+                far_pen = t.pen_id[struts[one], 1 - end]
+                other = np.where((k[one] == 1) & (far_pen >= 0), far_pen, other)
+                ok = other < rows_n                                        # default model: penalisation points are no rows
+                np.add.at(out, other[ok], (mult[struts[one], None] *
+                                           np.einsum("sij,sj->si", Ke[one][:, 6:, :6], d[one]))[ok])
+        return out
 
     def calculate_reaction_force_and_moment_at_position(self, position, tol: float = 1e-8):
         d = np.abs(self.lattice.node_coordinates() - np.asarray(position, float)).max(axis=1)

@@ -216,6 +216,12 @@ def gen_lattice_states():
         "bcchybrid1hybrid4_3x2x1_size": _preset(["BCC", "Hybrid1", "Hybrid4"], [0.05, 0.04, 0.03], (3, 2, 1),
                                                 cell_size=(1.5, 1.0, 0.7), bcs=CANTILEVER),
     }
+    # a prescribed, non-zero displacement of one dof on a whole face: the penalisation points of the in-face struts get a
+    # Dirichlet value on that dof only (reference_compat promotes them to nodes of the device mesh)
+    cases["octet_2x2x2_pull"] = _preset(["Octet"], [0.03], (2, 2, 2), bcs={
+        "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"], "Value": [0, 0, 0, 0, 0, 0]},
+                         "Pull": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.01]}},
+        "Force": {"Side": {"Surface": ["Ymax"], "DOF": ["X"], "Value": [0.05]}}})
     # a strut shared by several cells AND cut by another geometry's node (cubic edges through Hybrid1's edge mid-points):
     # check_hybrid_collision cuts it once per owner cell and gives every owner all copies (lattice.py:1146-1195)
     cases["cubichybrid1_2x2x2"] = _preset(["Cubic", "Hybrid1"], [0.05, 0.03], (2, 2, 2), bcs=CANTILEVER)

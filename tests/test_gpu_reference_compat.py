@@ -22,7 +22,7 @@ from pylatticedso_amd.views import _tables   # noqa: E402
 
 E, NU = 1013.0, 0.3
 IN_FACE = ["octet_2x2x2", "octet_3x2x2_size", "cubic_2x2x2", "kelvin_2x2x2", "bccoctet_2x2x2", "auxetic_2x2x2",
-           "octetext_2x2x2", "original2_2x2x2"]
+           "octetext_2x2x2", "original2_2x2x2", "octet_2x2x2_pull"]
 
 
 def _rel(a, b):
@@ -76,7 +76,17 @@ def test_solve_matches_the_reference_model_with_strut_copies(golden_dir, name):
     if name in IN_FACE:
         assert (np.asarray(L._boundary_visit_order) >= N).any()
         dev = L._device
-        assert dev._promoted.sum() == (g["node_fixed"][N:].any(axis=1) | (g["node_force"][N:] != 0).any(axis=1)).sum()
+        # the three cases of compat_device.py: loaded points stay condensed (their load travels to the strut ends), the
+        # points of struts clamped as a whole need nothing, only other Dirichlet points become nodes of the device mesh
+        forced = (g["node_force"][N:, :3] != 0).any(axis=1)
+        fixed_any, fixed_all = (g["node_fixed"][N:] != 0).any(axis=1), (g["node_fixed"][N:] != 0).all(axis=1)
+        if name != "octet_2x2x2_pull":                                          # (clamped faces are clamped in all dofs)
+            assert dev._promoted.sum() == (fixed_any & ~fixed_all).sum()
+        assert (0 if dev._particular is None else len(dev._particular[0])) == (forced & ~dev._promoted).sum()
+        if name == "octet_2x2x2_pull":
+            assert dev._promoted.sum() > 0 and dev._particular is not None
+        elif "flexion" not in name:
+            assert dev._promoted.sum() == 0 and len(dev._parent) == L.lattice.n_beams    # the design mesh, uncut
     # reactions R = K u on constrained rows, times the number of cells that hold the point (point.py:368-380)
     Rref = (K @ uall.ravel()).reshape(-1, 6)[:n0]
     rows = L.fixed_DOF.any(axis=1)
