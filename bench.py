@@ -202,8 +202,10 @@ def end_to_end(cells, geom, radii, rtol, reference_compat=False):
     extra = {}
     if reference_compat:
         dev = L._device
-        extra = {"model": "reference_compat: strut multiplicity = owner cells (pl_set_multiplicity), boundary data and "
-                          "xsol entries on the penalisation points of the loaded faces (promoted to nodes of a cut mesh)",
+        extra = {"model": "reference_compat: strut multiplicity = owner cells (pl_set_multiplicity); boundary data and xsol "
+                          "entries on the penalisation points of the loaded faces (loads condensed onto the strut ends, "
+                          "clamped in-face struts inert, other Dirichlet points promoted to nodes of a cut mesh)",
+                 "beams_per_s_device": float(L.lattice.n_beams / ((model.stats["ms_solve"] + model.stats["ms_assembly"]) * 1e-3)),
                  "struts_with_copies": int((L.beam_mult > 1).sum()), "promoted_points": int(dev._promoted.sum()),
                  "device_struts": int(len(dev._parent)), "rows": int(dev.n_nodes), "len_xsol": int(len(xsol)),
                  "pcg_iterations": int(model.stats["iterations"]), "solve_ms": model.stats["ms_solve"],
