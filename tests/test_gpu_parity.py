@@ -40,9 +40,17 @@ def _rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_3x2x2_gradradius",
-                                  "hybrid4_1x1x1_periodic", "bcchybrid1_2x2x2", "bcchybrid4_1x1x1_periodic",
-                                  "bcchybrid1hybrid4_3x2x1_size"])
+# every unit cell of the reference sees the ORACLE's numbers directly (round-3 verdict: 14 of the 18 reached it only through
+# the gather kernel), plus the hybrids, the graded / sized lattices and the random-radius ones of round 4
+ORACLE_DIRECT = sorted(set(
+    ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_3x2x2_gradradius", "hybrid4_1x1x1_periodic", "bcchybrid1_2x2x2",
+     "bcchybrid4_1x1x1_periodic", "bcchybrid1hybrid4_3x2x1_size", "cubichybrid1_2x2x2", "random_bccoctet_2x2x3_hybrid",
+     "random_octet_3x3x2_erased", "auxetic_2x2x2", "bccz_2x2x2", "cubic_2x2x2", "diamond_2x2x2", "hybrid1_1x1x1_periodic",
+     "hybrid2_2x2x2", "hybrid3_2x2x2", "hybrid5_2x2x2", "kelvin_2x2x2", "octahedron_2x2x2", "octahedronyz_2x2x2",
+     "octahedronz_2x2x2", "octet_2x2x2", "octetext_2x2x2", "original2_2x2x2", "original_2x2x2"]))
+
+
+@pytest.mark.parametrize("name", ORACLE_DIRECT)
 def test_records_match_oracle(golden_dir, name):
     _, L = _sim(golden_dir, name)
     with _device(L) as dev:
@@ -61,6 +69,18 @@ def test_records_match_oracle(golden_dir, name):
 @pytest.mark.parametrize("name", ["bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size", "bcc_1x1x1_periodic",
                                   "bcchybrid1_2x2x2", "bcchybrid1hybrid4_3x2x1_size"])
 def test_spmv_matches_oracle(golden_dir, name, kernel, reorder):
+    _spmv_against_oracle(golden_dir, name, kernel, reorder)
+
+
+@pytest.mark.parametrize("name", [n for n in ORACLE_DIRECT if n not in ("bcc_2x2x2", "bccoctet_2x2x2", "octet_3x2x2_size",
+                                                                       "bcchybrid1_2x2x2", "bcchybrid1hybrid4_3x2x1_size")])
+def test_spmv_matches_oracle_on_every_unit_cell(golden_dir, name):
+    """The default kernel choice (LDS-tile K*p on the brick order) against the oracle's assembled K on the remaining unit
+    cells and lattices: 1e-13 on K x, the masked operator and the energy."""
+    _spmv_against_oracle(golden_dir, name, 0, 1)
+
+
+def _spmv_against_oracle(golden_dir, name, kernel, reorder):
     _, L = _sim(golden_dir, name)
     lat = L.lattice
     K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))

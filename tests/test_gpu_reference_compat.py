@@ -192,3 +192,33 @@ def test_default_model_is_unchanged_and_differs_only_where_struts_are_shared(gol
     _, ma = solve_FEM_FenicsX(A)
     _, mb = solve_FEM_FenicsX(B)
     assert _rel(ma.u, mb.u[:A.lattice.n_nodes]) > 1e-2          # face struts twice as stiff, loads spread over 45 rows
+
+
+def test_design_loop_on_the_reference_model(golden_dir):
+    """LatticeOpti(reference_compat=True) on an Octet lattice: the objective and its adjoint gradient go through the wrapper
+    (design struts in, multiplicities and condensed point loads inside) - the gradient is the derivative of the objective
+    (central differences on two parameters), and new radii reach the device through `update_radii`."""
+    from pylatticedso_amd.lattice_opti import LatticeOpti
+    g = np.load(os.path.join(golden_dir, "lattice_octet_3x2x2_size.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    preset["optimization_informations"] = {
+        "objective_function": "min", "objective_type": "compliance", "max_iterations": 5,
+        "optimization_parameters": {"type": "unit_cell", "hybrid": False},
+        "constraints": {"relative_density": {"value": 0.05}},
+        "enable_parameter_normalization": True, "enable_gradient_computing": True, "simulation_type": "FEM"}
+    L = LatticeOpti(preset, reference_compat=True)
+    L.fem_rtol = 1e-12
+    L._initialize_optimization_solver()
+    n = len(L.initial_parameters)
+    x = np.asarray(L.initial_parameters, dtype=float) + 0.1 * np.sin(np.arange(n))
+    x = np.clip(x, 0.05, 0.95)
+    L.objective(list(x))
+    assert L._device._mult is not None and L._device._mult.max() == 2
+    grad = np.asarray(L.gradient(list(x)))
+    h = 1e-5
+    for i in (0, n // 2):
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        fd = (L.objective(list(xp)) - L.objective(list(xm))) / (2 * h)
+        assert abs(grad[i] - fd) < 1e-4 * abs(fd) + 1e-9, (i, grad[i], fd)
