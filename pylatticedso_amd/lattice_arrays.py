@@ -92,8 +92,7 @@ def _csr_from_pairs(rows, cols, nrows):
     keep = np.ones(len(rows), bool)
     keep[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
     rows, cols = rows[keep], cols[keep]
-    ptr = np.zeros(nrows + 1, np.int64)
-    np.add.at(ptr, rows + 1, 1)
+    ptr = np.concatenate([[0], np.bincount(rows, minlength=nrows)]).astype(np.int64)
     return np.cumsum(ptr), cols.astype(np.int64)
 
 

@@ -50,8 +50,35 @@ class _Tables:
         self.pen_id = pid
         self.node_xyz = np.concatenate([lat.node_xyz, self.pen_xyz]) if len(order) else lat.node_xyz
         self.n_nodes = len(self.node_xyz)
+        self._sim_ref = (sim, has, pid, lat.beam_conn[:, 0].astype(np.int64), lat.beam_conn[:, 1].astype(np.int64))
+        # node -> cells (design nodes); penalisation points belong to the cells of their strut
+        cn_ptr, cn_idx = lat.cell_node_ptr, lat.cell_node_idx
+        cell_of = np.repeat(np.arange(lat.n_cells), np.diff(cn_ptr))
+        o3 = np.argsort(cn_idx, kind="stable")
+        ptr3 = np.concatenate([[0], np.bincount(cn_idx, minlength=N)]).astype(np.int64)
+        self.node_cell_ptr, self.node_cell_idx = np.cumsum(ptr3), cell_of[o3]
+        cb_ptr, cb_idx = lat.cell_beam_ptr, lat.cell_beam_idx
+        cell_of_b = np.repeat(np.arange(lat.n_cells), np.diff(cb_ptr))
+        o4 = np.argsort(cb_idx, kind="stable")
+        ptr4 = np.concatenate([[0], np.bincount(cb_idx, minlength=B)]).astype(np.int64)
+        self.strut_cell_ptr, self.strut_cell_idx = np.cumsum(ptr4), cell_of_b[o4]
+
+    # The beam (segment) tables are only built when somebody looks at beams: at 50^3 Octet they are 9 M segments sorted on
+    # seven keys (3 s), and the reference_compat bookkeeping needs the NODE tables only.
+    _BEAM_ATTRS = ("beam_conn", "beam_parent", "beam_part", "beam_mod", "beam_radius", "beam_index", "beam_copy", "n_beams",
+                   "has_copies", "strut_beam_ptr", "strut_beam_idx", "node_beam_ptr", "node_beam_idx")
+
+    def __getattr__(self, name):
+        if name in _Tables._BEAM_ATTRS and "_sim_ref" in self.__dict__:
+            self._build_beams()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def _build_beams(self):
+        sim, has, pid, a, b = self.__dict__.pop("_sim_ref")
+        lat, pen = sim.lattice, sim.penalized
+        N, B = lat.n_nodes, lat.n_beams
         # ---- beams: untouched design struts keep their index, the segments of the others follow
-        a, b = lat.beam_conn[:, 0].astype(np.int64), lat.beam_conn[:, 1].astype(np.int64)
         split = has.any(axis=1)
         keep = np.flatnonzero(~split)
         s1 = np.flatnonzero(has[:, 0])
@@ -94,28 +121,13 @@ class _Tables:
         self.has_copies = bool((self.beam_copy > 0).any())
         # strut -> its beams (views): CSR
         o = np.argsort(self.beam_parent, kind="stable")
-        ptr = np.zeros(B + 1, np.int64)
-        np.add.at(ptr, self.beam_parent + 1, 1)
+        ptr = np.concatenate([[0], np.bincount(self.beam_parent, minlength=B)]).astype(np.int64)
         self.strut_beam_ptr, self.strut_beam_idx = np.cumsum(ptr), o
         # node -> beams
         ends = self.beam_conn.ravel()
         o2 = np.argsort(ends, kind="stable")
-        ptr2 = np.zeros(self.n_nodes + 1, np.int64)
-        np.add.at(ptr2, ends + 1, 1)
+        ptr2 = np.concatenate([[0], np.bincount(ends, minlength=self.n_nodes)]).astype(np.int64)
         self.node_beam_ptr, self.node_beam_idx = np.cumsum(ptr2), o2 // 2
-        # node -> cells (design nodes); penalisation points belong to the cells of their strut
-        cn_ptr, cn_idx = lat.cell_node_ptr, lat.cell_node_idx
-        cell_of = np.repeat(np.arange(lat.n_cells), np.diff(cn_ptr))
-        o3 = np.argsort(cn_idx, kind="stable")
-        ptr3 = np.zeros(N + 1, np.int64)
-        np.add.at(ptr3, cn_idx + 1, 1)
-        self.node_cell_ptr, self.node_cell_idx = np.cumsum(ptr3), cell_of[o3]
-        cb_ptr, cb_idx = lat.cell_beam_ptr, lat.cell_beam_idx
-        cell_of_b = np.repeat(np.arange(lat.n_cells), np.diff(cb_ptr))
-        o4 = np.argsort(cb_idx, kind="stable")
-        ptr4 = np.zeros(B + 1, np.int64)
-        np.add.at(ptr4, cb_idx + 1, 1)
-        self.strut_cell_ptr, self.strut_cell_idx = np.cumsum(ptr4), cell_of_b[o4]
 
 
 def _tables(sim) -> _Tables:
