@@ -243,6 +243,11 @@ void k_spmv_rows(const RowDesc *__restrict__ rdesc, const uint32_t *__restrict__
   // a wave without a node has nothing left to do (a tile of 150 nodes fills three of the four waves; in the passes of the
   // condensed operator the eliminated / kept nodes are whole waves at the end / start of a tile)
   if ((int)(threadIdx.x & ~63u) >= nn) return;
+  if (ENDS != kEndsAll && nn <= kRowBlock) {
+    // a pass over one kind of rows: kept and eliminated nodes are whole runs of a tile, so a wave is usually all of one kind
+    const bool mine = i0 < nn && ((cflag[n0 + i0] != 0) == kToCondensed);
+    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
+  }
   double acc = 0.0;
   for (int base = 0; base < nn; base += kRowBlock) {                // (one pass: a tile has <= 256 nodes by default)
     const int i = base + i0;
