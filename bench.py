@@ -602,7 +602,7 @@ def main():
                  "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         for tag, pal in (("palette", 1), ("streaming", 0)):
             with _capi.HipLattice(llat.node_xyz, llat.beam_conn, llat.beam_radius, lpen.seg_len, lpen.seg_nsub, E, NU,
-                                  device=local_rank, precond=args.precond, palette=pal) as dl:
+                                  device=local_rank, precond=args.precond, palette=pal, precision=pal) as dl:
                 dl.set_bc(lfixed, None, lf)
                 dl.assemble()
                 lab = dl.algorithmic_bytes()
@@ -615,6 +615,14 @@ def main():
                 if pal:     # palette form: bound by the vector ALU / LDS (see `roofline`); the byte model is not a bound
                     large[tag].update(bound="valu+lds", frac=None,
                                       algorithmic_equiv={"achieved": ach, "frac": ach / HBM_PEAK_GBS, "unit": "GB/s"})
+                    # what LatticeSim.device_model picks from 2 M nodes: fp32-stored PCG vectors, fp64 refinement
+                    # (rtol on the TRUE fp64 residual) - the vector kernels stream half the bytes
+                    large[tag]["pcg_iteration_precision1_ms"] = dl.time_kernel(8, 20)
+                    dl.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+                    lst = dl.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+                    large[tag]["solve_precision1"] = {"ms": lst["ms_solve"], "pcg_iterations": lst["iterations"],
+                                                      "inner_solves": lst.get("restarts", 0.0),
+                                                      "converged": lst["converged"], "rel_residual": lst["rel_residual"]}
                 else:
                     large[tag].update(bound="hbm", achieved=ach, frac=ach / HBM_PEAK_GBS)
                 large["algorithmic_bytes"] = lab["spmv"]

@@ -557,6 +557,28 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
   // an fp32 residual recurrence is trustworthy over ~4 decades: restart from the true residual after that
   const double inner_drop = kAll32 ? 1e-8 : 0.0;      // on ||r||^2
   double rr_true = bb;
+  // warm start (mode 1, as pcg_solve): the refinement begins at the previous solution of this handle, masked with the
+  // CURRENT Dirichlet set - the first inner solve then works on its true residual like every later one
+  const bool warm = kAll32 && c->opt.warm_start == 1 && !c->dist.active;
+  if (warm && c->xprev.p && c->xprev_valid) {
+    PL_HIP(hipMemcpyAsync(c->x.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_warm_mask, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, (const uint8_t *)nullptr,
+                       (const uint8_t *)c->fixed.p, c->x.p);
+    rc = launch_spmv(c, c->x.p, c->tmp2.p, true, nullptr);
+    if (rc) return rc;
+    PL_HIP(hipMemsetAsync(aux, 0, pl::kSlots * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_mp_true_residual, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6, f_dev, Kubar_dev,
+                       (const double *)c->tmp2.p, c->fixed.p, w, c->r.p, aux);
+    PL_HIP(hipGetLastError());
+    rc = read_slots(c, aux, &rr_true);
+    if (rc) return rc;
+    if (std::isnan(rr_true) || std::isinf(rr_true)) return fail(PL_ERR_NAN, "NaN/Inf in the warm-start residual");
+    st->rel_residual = std::sqrt(rr_true / bb);
+    if (rr_true <= thresh) {       // (the previous solution already solves this system)
+      st->converged = 1;
+      return PL_OK;
+    }
+  }
   int k = 0;                      // iterations over all inner solves
   std::vector<double> h_hist(32);
   for (int outer = 0; outer < 40 && k < max_iter; ++outer) {
@@ -654,6 +676,11 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
     }
   }
   st->iterations = k;
+  if (warm && st->converged) {
+    if (!c->xprev.p) PL_HIP(c->xprev.alloc(n6));
+    PL_HIP(hipMemcpyAsync(c->xprev.p, c->x.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->xprev_valid = true;
+  }
   return PL_OK;
 }
 

@@ -544,6 +544,11 @@ class LatticeSim(LatticeViews):
                 # converge in a few hundred Jacobi iterations and have too few nodes per tile for the coarse levels
                 kw.setdefault("precond", 3)
                 kw.setdefault("palette", 1)
+            if self.lattice.n_nodes >= 2_000_000:
+                # from ~2 M nodes the PCG vectors no longer fit the caches and stream from HBM: fp32 inner solves with fp64
+                # refinement (rtol still refers to the TRUE fp64 residual).  Measured: 100^3 Octet 284 against 234 M
+                # beams/s, 100^3 BCC 80.8 against 76.3; 50^3 Octet (0.77 M nodes) 220 against 230 - hence the threshold
+                kw.setdefault("precision", 1)
             if self._compat_rows:
                 from .compat_device import CompatDevice
                 self._device = CompatDevice(self, **kw)

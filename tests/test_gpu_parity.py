@@ -204,12 +204,12 @@ def test_irregular_lattice_takes_the_gather_kernel(golden_dir):
             assert st["converged"] == 1 and _rel(u.ravel(), u_ref) < 1e-7
 
 
-@pytest.mark.parametrize("geom,condense", [("Octet", -1), ("BCC", 1)])
-def test_warm_start_of_a_design_loop(geom, condense):
+@pytest.mark.parametrize("geom,condense,precision", [("Octet", -1, 0), ("BCC", 1, 0), ("Octet", -1, 1), ("BCC", 1, 1)])
+def test_warm_start_of_a_design_loop(geom, condense, precision):
     """opts.warm_start = 1: the second solve of a handle starts from the first one's solution.  On a system changed by a few
     per cent (radii) it converges to the same displacements as a cold start (1e-7) in fewer iterations; on the identical
     system it needs none to speak of; a changed Dirichlet set is honoured (the old solution is masked); with and without node
-    elimination."""
+    elimination; in fp64 and with the fp32 inner solver (precision = 1: the refinement starts at the previous solution)."""
     from pylatticedso_amd import lattice_arrays as LA
     n = 12
     lat = LA.generate((1, 1, 1), (n, n, n), [geom], [0.05 if geom == "BCC" else 0.03])
@@ -223,10 +223,12 @@ def test_warm_start_of_a_design_loop(geom, condense):
     res = {}
     for warm in (0, 1):
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
-                              palette=1, tile_nodes=64, coarse_max_dofs=600, condense=condense, warm_start=warm) as dev:
+                              palette=1, tile_nodes=64, coarse_max_dofs=600, condense=condense, warm_start=warm,
+                              precision=precision) as dev:
             dev.set_bc(fixed, None, f)
             dev.assemble()
             u1, st1 = dev.solve(rtol=1e-9, max_iter=20000)
+            assert st1["precision_used"] == precision
             u1b, st1b = dev.solve(rtol=1e-9, max_iter=20000)          # the identical system again
             dev.update_radii(r2)
             dev.assemble()
@@ -247,8 +249,12 @@ def test_warm_start_of_a_design_loop(geom, condense):
     cold, warm = res[0], res[1]
     for k in range(4):
         assert _rel(warm[k], cold[k]) < 1e-7
-    assert warm[4] == cold[4]                      # the first solve of a handle has nothing to start from
-    assert warm[5] <= 2 and cold[5] == cold[4]     # identical system: the previous solution IS the solution
+    # the first solve of a handle has nothing to start from (precision = 1 counts whole check intervals of the inner
+    # solves, whose lengths follow the observed decay: a last-bit difference in a reduction can move one)
+    assert warm[4] == cold[4] if precision == 0 else abs(warm[4] - cold[4]) <= 0.2 * cold[4], (warm[4:], cold[4:])
+    assert warm[5] <= 2                            # identical system: the previous solution IS the solution
+    if precision == 0:
+        assert cold[5] == cold[4]
     assert warm[6] < 0.9 * cold[6]                 # perturbed radii: fewer iterations
     if condense == 1:
         assert cold[4] > 0
