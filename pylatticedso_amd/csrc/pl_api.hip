@@ -204,6 +204,26 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
   PL_HIPC(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+  {
+    // The explicit K (2.5 GB of traffic) is filled BESIDE the latency-bound factorisation chain, on a stream whose CU mask
+    // leaves k of every 8 CUs to the chain (next to an unmasked fill every link of the chain went from 44 to 57 us, which is
+    // why the fill used to wait for the chain's end: assembly 2.20 -> 1.93 ms at 50^3 Octet with k = 4 or 5, 1.97 with 1,
+    // 2.03 with 6).  The CUs are left out on a diagonal - bit i when (i / 8 + i) % 8 < k - which is k CUs of every XCD
+    // whether the mask bits run XCD-major or round-robin over the XCDs.  PL_BSR_CUMASK=0: the old order.
+    const char *e = std::getenv("PL_BSR_CUMASK");
+    const int k = e ? std::atoi(e) : 4;
+    if (k > 0 && k < 8) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) {
+        mask[w] = 0u;
+        for (int b = 0; b < 32; ++b) {
+          const int i = 32 * w + b;
+          if ((i / 8 + i) % 8 >= k) mask[w] |= 1u << b;
+        }
+      }
+      PL_HIPC(hipExtStreamCreateWithCUMask(&c->side_cu, 8, mask));
+    }
+  }
 
   // node ordering on the device
   const double global_grid[7] = {o->grid_lo[0], o->grid_lo[1], o->grid_lo[2], o->grid_hi[0], o->grid_hi[1],
@@ -846,22 +866,25 @@ int pl_assemble(pl_handle h) {
   // the single-launch inverse factor instead.
   int rc_fill = PL_OK;
   bool fill_queued = false;
-  auto queue_fill = [&]() {
+  hipStream_t fill_stream = h->side_cu ? h->side_cu : h->side;
+  auto queue_fill = [&](int phase) {
     if (!refresh_bsr || fill_queued) return;
+    if (phase == 0 && !h->side_cu) return;      // beside the chain only on the stream that leaves it CUs of its own
     fill_queued = true;
-    if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_chol, 0) != hipSuccess) {
+    if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(fill_stream, h->ev_chol, 0) != hipSuccess ||
+        hipStreamWaitEvent(fill_stream, h->ev_join, 0) != hipSuccess) {
       rc_fill = fail(PL_ERR_HIP, "pl_assemble: could not order the BSR fill behind the factorisation");
       return;
     }
-    rc_fill = launch_bsr_fill(h, h->bsr_with_bc, h->side);
-    if (hipEventRecord(h->ev_join, h->side) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
+    rc_fill = launch_bsr_fill(h, h->bsr_with_bc, fill_stream);
+    if (hipEventRecord(h->ev_join, fill_stream) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
   };
   // (round 3, tried: the fill queued HERE, beside the tile-block front of the assembly instead of behind the chain's last
   // link: assembly 2.27 -> 2.46 ms in two alternating pairs of runs - it slows the front and the first links)
   PL_HIP(hipEventRecord(h->ev_join, h->side));
-  rc = build_coarse(h, h->coarse.enabled && h->have_bc ? std::function<void()>(queue_fill) : std::function<void()>());
+  rc = build_coarse(h, h->coarse.enabled && h->have_bc ? std::function<void(int)>(queue_fill) : std::function<void(int)>());
   if (rc) return rc;
-  queue_fill();                                  // (no dense level: queue it now)
+  queue_fill(1);                                 // (no dense level: queue it now)
   if (rc_fill) return rc_fill;
   PL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   rc = launch_dinv32(h);

@@ -165,12 +165,17 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
   if (cs.cm == 12) return PL_OK;        // built inside build_coarse_level, which needs them first
   const uint8_t *fb = c->dist.active ? c->maskL.p : c->fixedbits.p;
   const bool twelve = tile_modes_now(c) == 12;
-  hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
-                     c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
-                     reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                     fb, cs.Bt_inv, twelve ? cs.Bt_raw : (double *)nullptr);
+  if (!twelve)
+    hipLaunchKernelGGL(pl::k_tile_blocks, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st, c->tile.tile_start.p,
+                       c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
+                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                       fb, cs.Bt_inv, (double *)nullptr);
   if (twelve) {
-    hipLaunchKernelGGL(pl::k_tile_blocks_strain, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st,
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain<true>, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st,
+                       c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
+                       reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, fb,
+                       cs.Bt_raw);
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain<false>, dim3((unsigned)cs.n_tiles), dim3(pl::kBlock), 0, st,
                        c->tile.tile_start.p, c->tile.home_ptr.p, c->tile.foreign_ptr.p, c->tile.foreign_idx.p,
                        reinterpret_cast<const int2 *>(c->conn.p), c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, fb,
                        cs.Bt_raw);
@@ -183,10 +188,10 @@ int launch_tile_blocks(pl_context *c, hipStream_t st) {
 
 // A_c = Z^T P K P Z on the device, then its Cholesky factor and W = L^-1 (pl_dense.h).
 int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool reduce,
-                       const std::function<void()> &after_chol = nullptr) {
+                       const std::function<void(int)> &after_chol = nullptr) {
   cs.ready = false;
   if (!cs.enabled || !c->have_bc) {
-    if (after_chol) after_chol();
+    if (after_chol) after_chol(1);
     return PL_OK;
   }
   bool tile_invert_pending = false;
@@ -207,26 +212,27 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     if (two_sets) {
       if (!cs.Bt_rawA && hipMalloc((void **)&cs.Bt_rawA, (size_t)cs.n_tiles * 144 * sizeof(double)) != hipSuccess)
         return fail(PL_ERR_HIP, "pl_assemble: out of device memory for the tile blocks");
-      hipLaunchKernelGGL(pl::k_tile_blocks, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+      hipLaunchKernelGGL(pl::k_tile_blocks_strain<true>, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
                          c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p,
-                         c->xyz.p, (const uint8_t *)c->maskL.p, cs.Bt_inv, cs.Bt_raw);
-      hipLaunchKernelGGL(pl::k_tile_blocks_strain, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+                         c->xyz.p, (const uint8_t *)c->maskL.p, cs.Bt_raw);
+      hipLaunchKernelGGL(pl::k_tile_blocks_strain<false>, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
                          c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p,
                          c->xyz.p, (const uint8_t *)c->maskL.p, cs.Bt_raw);
     }
     double *rawA = two_sets ? cs.Bt_rawA : cs.Bt_raw;
+    // (rigid x rigid part and the cross-tile struts on a second stream beside the strain rows)
     PL_HIP(hipEventRecord(c->ev_t0, c->stream));
     PL_HIP(hipStreamWaitEvent(c->side2, c->ev_t0, 0));
-    hipLaunchKernelGGL(pl::k_tile_blocks, gt, blk, 0, c->side2, c->tile.tile_start.p, c->tile.home_ptr.p,
-                       c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
-                       mask, cs.Bt_inv, rawA);
-    PL_HIP(hipEventRecord(c->ev_t1, c->side2));
-    hipLaunchKernelGGL(pl::k_tile_blocks_strain, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain<true>, gt, blk, 0, c->side2, c->tile.tile_start.p, c->tile.home_ptr.p,
                        c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
                        mask, rawA);
     if (cs.n_cross > 0)
-      hipLaunchKernelGGL(pl::k_coarse_cross12, dim3(grid_for(cs.n_cross)), blk, 0, c->stream, cs.n_cross,
+      hipLaunchKernelGGL(pl::k_coarse_cross12, dim3(grid_for(cs.n_cross)), blk, 0, c->side2, cs.n_cross,
                          cs.cross_idx.p, c->conn.p, c->rec.p, cs.agg_of_node.p, cs.cen.p, c->xyz.p, mask, n, cs.Ac);
+    PL_HIP(hipEventRecord(c->ev_t1, c->side2));
+    hipLaunchKernelGGL(pl::k_tile_blocks_strain<false>, gt, blk, 0, c->stream, c->tile.tile_start.p, c->tile.home_ptr.p,
+                       c->tile.foreign_ptr.p, c->tile.foreign_idx.p, conn2, c->rec.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p,
+                       mask, rawA);
     PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
     hipLaunchKernelGGL(pl::k_agg_add_tiles, dim3(grid_for(cs.n_tiles * 144)), blk, 0, c->stream, cs.n_tiles,
                        cs.agg_of_tile.p, (const double *)rawA, n, cs.Ac);
@@ -304,7 +310,7 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   return PL_OK;
 }
 
-int build_coarse(pl_context *c, const std::function<void()> &after_chol = nullptr) {
+int build_coarse(pl_context *c, const std::function<void(int)> &after_chol = nullptr) {
   int rc = build_coarse_level(c, c->coarse, c->fixedbits.p, true, after_chol);
   if (rc || !c->coarseL.enabled) return rc;
   // (mask = Dirichlet | shared, launch_local_mask: its modes live on this rank's own nodes only)

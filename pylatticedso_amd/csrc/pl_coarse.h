@@ -697,6 +697,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks(const int32_t *__restric
 // one): per strut six evaluations of the tip force under the masked strain displacements of its in-tile ends, restricted
 // back by the strain modes (S x S, 6 x 6 symmetric) and - only for struts that cross the tile boundary or touch a
 // Dirichlet dof: the others answer a strain with a self-equilibrated force pair - by the rigid modes (R x S).
+// RIGID = true: INSTEAD the rigid x rigid block (what k_tile_blocks(raw) computes from explicit 6 x 6 stiffness blocks and
+// two 6 x 6 x 6 products per strut end) in the same force form: struts that cross the tile boundary or touch a Dirichlet dof
+// take six tip forces under the masked rigid motions of their in-tile ends, restricted back by the rigid modes (symmetric,
+// 21 sums).  (Both parts in ONE walk hold 78 accumulators: 256 VGPRs + 58 AGPRs, one wave per SIMD, 592 us against
+// 517 || 226 us of the two kernels side by side.)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__restrict__ tile_start,
                                                                const int64_t *__restrict__ home_ptr,
                                                                const int64_t *__restrict__ foreign_ptr,
@@ -713,11 +719,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  double SS[21], RS[36];                     // [p][q]: restriction p of the force answering strain q (S x S: p <= q only)
+  double SS[21], RS[RIGID ? 1 : 36];         // [p][q]: restriction p of the force answering strain q (S x S: p <= q only)
+  double RR[RIGID ? 21 : 1];                 // R x R, p <= q, packed like SS
+#pragma unroll
+  for (int e = 0; e < (RIGID ? 21 : 1); ++e) RR[e] = 0.0;
 #pragma unroll
   for (int e = 0; e < 21; ++e) SS[e] = 0.0;
 #pragma unroll
-  for (int e = 0; e < 36; ++e) RS[e] = 0.0;
+  for (int e = 0; e < (RIGID ? 1 : 36); ++e) RS[e] = 0.0;
   const int64_t h0 = home_ptr[t], h1 = home_ptr[t + 1], f0 = foreign_ptr[t], f1 = foreign_ptr[t + 1];
   const int64_t total = (h1 - h0) + (f1 - f0);
   for (int64_t v = threadIdx.x; v < total; v += kBlock) {
@@ -727,12 +736,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
     if (!ina && !inb) continue;
     const unsigned fa = fixedbits ? fixedbits[cn.x] : 0u, fb = fixedbits ? fixedbits[cn.y] : 0u;
     const bool free_inside = ina && inb && fa == 0u && fb == 0u;
+    if (RIGID && free_inside) continue;      // rigid motion of the whole strut
     const Record r = load_record(rec, b);
     const double rela[3] = {xyz[3 * (int64_t)cn.x] - c0, xyz[3 * (int64_t)cn.x + 1] - c1, xyz[3 * (int64_t)cn.x + 2] - c2};
     const double relb[3] = {xyz[3 * (int64_t)cn.y] - c0, xyz[3 * (int64_t)cn.y + 1] - c1, xyz[3 * (int64_t)cn.y + 2] - c2};
     const V3 d = {r.dx, r.dy, r.dz}, zero = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < (RIGID ? 0 : 6); ++q) {
       const V3 uA = ina ? mask3(strain_disp(q, rela), fa) : zero, uB = inb ? mask3(strain_disp(q, relb), fb) : zero;
       V3 F, M;
       tip_force(r, uA, zero, uB, zero, F, M);                  // on B; on A: -F, -M - d x F
@@ -762,15 +772,74 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
         }
       }
     }
+    if (RIGID && !free_inside) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        V3 uA = zero, tA = zero, uB = zero, tB = zero;
+        if (ina) {
+          mode_disp(q, rela, uA, tA);
+          uA = mask3(uA, fa);
+          tA = mask3(tA, fa >> 3);
+        }
+        if (inb) {
+          mode_disp(q, relb, uB, tB);
+          uB = mask3(uB, fb);
+          tB = mask3(tB, fb >> 3);
+        }
+        V3 F, M;
+        tip_force(r, uA, tA, uB, tB, F, M);
+        double x6[6] = {0, 0, 0, 0, 0, 0};
+        if (inb) {
+          const V3 FB = mask3(F, fb), MB = mask3(M, fb >> 3);
+          x6[0] += FB.x;
+          x6[1] += FB.y;
+          x6[2] += FB.z;
+          x6[3] += MB.x + (relb[1] * FB.z - relb[2] * FB.y);
+          x6[4] += MB.y + (relb[2] * FB.x - relb[0] * FB.z);
+          x6[5] += MB.z + (relb[0] * FB.y - relb[1] * FB.x);
+        }
+        if (ina) {
+          const V3 FA = mask3((-1.0) * F, fa), MA = mask3((-1.0) * M - cross(d, F), fa >> 3);
+          x6[0] += FA.x;
+          x6[1] += FA.y;
+          x6[2] += FA.z;
+          x6[3] += MA.x + (rela[1] * FA.z - rela[2] * FA.y);
+          x6[4] += MA.y + (rela[2] * FA.x - rela[0] * FA.z);
+          x6[5] += MA.z + (rela[0] * FA.y - rela[1] * FA.x);
+        }
+#pragma unroll
+        for (int p = 0; p <= q; ++p) RR[q * (q + 1) / 2 + p] += x6[p];
+      }
+    }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *B = raw + (size_t)t * 144;
+  if (RIGID) {
+#pragma unroll
+    for (int e = 0; e < 21; ++e) {
+      const double s0 = wave_sum(RR[e]);
+      if (lane == 0) red[e][wv] = s0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 21) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < kBlock / kWave; ++q) v += red[threadIdx.x][q];
+      int q = 0;
+      while ((q + 1) * (q + 2) / 2 <= (int)threadIdx.x) ++q;     // column of the packed upper triangle
+      const int p = (int)threadIdx.x - q * (q + 1) / 2;
+      B[p * 12 + q] = v;                      // R x R, both halves
+      B[q * 12 + p] = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 21; ++e) {
     const double s1 = wave_sum(SS[e]);
     if (lane == 0) red[e][wv] = s1;
   }
 #pragma unroll
-  for (int e = 0; e < 36; ++e) {
+  for (int e = 0; e < (RIGID ? 1 : 36); ++e) {
     const double s2 = wave_sum(RS[e]);
     if (lane == 0) red[21 + e][wv] = s2;
   }
@@ -779,7 +848,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < kBlock / kWave; ++q) v += red[threadIdx.x][q];
-    double *B = raw + (size_t)t * 144;
     if (threadIdx.x < 21) {
       int q = 0;
       while ((q + 1) * (q + 2) / 2 <= (int)threadIdx.x) ++q;     // column of the packed upper triangle
@@ -843,7 +911,7 @@ __global__ __launch_bounds__(kInv12Block) void k_tile_invert12(int64_t T, const 
     }
 }
 // The dense level's factorisation and solve in whichever storage type the level uses.
-inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void()> &after_chol, unsigned *bar) {
+inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void(int)> &after_chol, unsigned *bar) {
   if (cs.w16)
     dense_factor_inverse(cs.Ac, cs.Lf, reinterpret_cast<bf16_t *>(cs.W), reinterpret_cast<bf16_t *>(cs.Wt), cs.Dinv, n, n,
                          cs.info, cs.bw_blocks, s, after_chol, bar);

@@ -80,6 +80,7 @@ struct pl_context {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipStream_t side2 = nullptr;   // tile blocks of the 12-mode dense level beside its strain rows
+  hipStream_t side_cu = nullptr; // bulk fills beside the factorisation chain: a stream that leaves some CUs of every XCD alone
   bool assembled = false, have_bc = false, have_bsr = false;
   int pal_fallback_flags[2] = {1, 0};
   int *pal_host_flags = pal_fallback_flags;   // pinned once the palette is in use: a D2H copy into pageable memory blocks the host
@@ -221,6 +222,7 @@ struct pl_context {
     if (ev_ov_x) (void)hipEventDestroy(ev_ov_x);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (side2) (void)hipStreamDestroy(side2);
+    if (side_cu) (void)hipStreamDestroy(side_cu);
     if (side) (void)hipStreamDestroy(side);
     if (stream) (void)hipStreamDestroy(stream);
   }

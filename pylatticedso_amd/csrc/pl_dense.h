@@ -659,10 +659,11 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const WT *__re
 // bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
 template <typename WT>
 inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *Dinv, int n, int ld, int *info,
-                                 int bw, hipStream_t s, const std::function<void()> &after_chol = nullptr,
+                                 int bw, hipStream_t s, const std::function<void(int)> &after_chol = nullptr,
                                  unsigned *bar = nullptr) {
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
+  if (after_chol) after_chol(0);       // (head of the chain: work that may run beside it on reserved CUs)
   hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, 0, Dinv, info);
   const int g = std::min(nb - 1, bw);
   if (bar && nb > 2 && g * g <= kChainMaxGrid) {   // the band fits the chip: one persistent launch for the whole chain
@@ -677,7 +678,7 @@ inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *D
   // after_chol: bulk work of the caller that should NOT run beside this latency-bound chain of dependent launches (every
   // link is slower next to a bandwidth-heavy kernel: measured 44 -> 57 us, also when released at 55 % of the chain) but
   // beside the single-launch inverse factor that follows
-  if (after_chol) after_chol();
+  if (after_chol) after_chol(1);
   if (bw + 1 <= kRing)
     hipLaunchKernelGGL((k_trtri_cols<WT, true>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
   else
