@@ -203,6 +203,8 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreateWithFlags(&c->ev_chol, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
   PL_HIPC(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   {
     // The explicit K (2.5 GB of traffic) is filled BESIDE the latency-bound factorisation chain, on a stream whose CU mask

@@ -299,7 +299,17 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     }
   }
   hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, cs.Ac);
-  pl::coarse_factor(cs, n, c->stream, after_chol, c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr);
+  // the inverse factor in row ranges behind the chain (second stream), so that only the last range runs after it
+  pl::TrtriPhases ph;
+  {
+    const int nb = n / pl::kNB;
+    const char *e = std::getenv("PL_TRTRI_ROWS");
+    ph.rows = e ? std::atoi(e) : (nb <= 32 ? 4 : nb / 8);
+    ph.stream = c->side2;     // (on a CU-masked stream beside the masked BSR fill: 1.75 -> 2.45 ms, configs[2] 7.7 -> 10.5)
+    ph.ev_go = c->ev_p0;
+    ph.ev_done = c->ev_p1;
+  }
+  pl::coarse_factor(cs, n, c->stream, after_chol, c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr, ph);
   if (tile_invert_pending) PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};

@@ -911,12 +911,13 @@ __global__ __launch_bounds__(kInv12Block) void k_tile_invert12(int64_t T, const 
     }
 }
 // The dense level's factorisation and solve in whichever storage type the level uses.
-inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void(int)> &after_chol, unsigned *bar) {
+inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void(int)> &after_chol, unsigned *bar,
+                          TrtriPhases ph = TrtriPhases()) {
   if (cs.w16)
     dense_factor_inverse(cs.Ac, cs.Lf, reinterpret_cast<bf16_t *>(cs.W), reinterpret_cast<bf16_t *>(cs.Wt), cs.Dinv, n, n,
-                         cs.info, cs.bw_blocks, s, after_chol, bar);
+                         cs.info, cs.bw_blocks, s, after_chol, bar, ph);
   else
-    dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, s, after_chol, bar);
+    dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, s, after_chol, bar, ph);
 }
 inline void coarse_apply(const Coarse &cs, const double *r, double *t, double *y, double *dot_out, const double *add0,
                          hipStream_t s) {

@@ -375,25 +375,44 @@ __global__ __launch_bounds__(kBlock) void k_chol_chain(double *__restrict__ A, d
 constexpr int kCw = 8;
 constexpr int kRing = 12;
 
+// PHASES: the walk can be cut into row ranges [row0, row1) launched one after the other, each as soon as the factorisation
+// chain has finished block row row1 - 1 (dense_factor_inverse), so that only the last range runs after the chain.  A later
+// range finds the last bw slices of its columns where the earlier one left them: in fp64, transposed, in the STRICTLY UPPER
+// blocks (kb, ib) of `scratch` = the matrix being factored, which the factorisation never touches (it works on the lower
+// triangle), so the result does not depend on where the walk was cut.
 template <typename WT, bool RING>
 __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict__ L, int ld, int nb, int bw,
                                                        const double *__restrict__ Dinv, WT *__restrict__ W,
-                                                       WT *__restrict__ Wt) {
+                                                       WT *__restrict__ Wt, int row0 = 0, int row1 = 1 << 30,
+                                                       double *__restrict__ scratch = nullptr) {
   __shared__ double At[kNB * kLdT];
   __shared__ double Ws[(RING ? kRing : 1) * kNB * kCw], S[kNB * kCw];
   constexpr int kSl = kNB / kCw;
   const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCw;
+  row1 = min(row1, nb);
+  if (kb >= row1) return;                                            // this column starts in a later range
   const int r = threadIdx.x & (kNB - 1), g = threadIdx.x / kNB;      // row, column pair (2g, 2g+1) of the slice
-  for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
-    const int row = e / kCw, c = e % kCw;
-    const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
-    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
-    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
-    if (RING) Ws[(kb % kRing) * kNB * kCw + e] = v;
-  }
+  const bool first = kb >= row0;                                     // the range that holds the diagonal block
+  const int ib0 = first ? kb + 1 : row0;
+  if (first || (RING && kb >= ib0 - bw))                             // (a later range: only if the band still reaches it)
+    for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
+      const int row = e / kCw, c = e % kCw;
+      const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
+      if (first) {
+        W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
+        Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
+      }
+      if (RING) Ws[(kb % kRing) * kNB * kCw + e] = v;
+    }
+  if (RING && !first)                                                // slices an earlier range computed (fp64 copies)
+    for (int jb = max(kb + 1, ib0 - bw); jb < ib0; ++jb)
+      for (int e = threadIdx.x; e < kNB * kCw; e += kBlock) {
+        const int c = e / kNB, row = e % kNB;
+        Ws[(jb % kRing) * kNB * kCw + row * kCw + c] = scratch[((size_t)kb * kNB + c0 + c) * ld + (size_t)jb * kNB + row];
+      }
   double regs[kNB * kNB / kBlock];
-  if (kb + 1 < nb) tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)max(kb, kb + 1 - bw) * kNB, ld, regs);
-  for (int ib = kb + 1; ib < nb; ++ib) {
+  if (ib0 < row1) tile_fetch(L + ((size_t)ib0 * kNB) * ld + (size_t)max(kb, ib0 - bw) * kNB, ld, regs);
+  for (int ib = ib0; ib < row1; ++ib) {
     double acc0 = 0.0, acc1 = 0.0;
     const int jlo = max(kb, ib - bw);
     for (int jb = jlo; jb < ib; ++jb) {
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
     S[r * kCw + 2 * g + 1] = acc1;
     tile_store_k_minor(regs, At);                                      // At[m][row] = Dinv_i[row][m]
     __syncthreads();
-    if (ib + 1 < nb) tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)max(kb, ib + 1 - bw) * kNB, ld, regs);
+    if (ib + 1 < row1) tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)max(kb, ib + 1 - bw) * kNB, ld, regs);
     double o0 = 0.0, o1 = 0.0;
 #pragma unroll 8
     for (int m = 0; m < kNB; ++m) {
@@ -434,6 +453,11 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols(const double *__restrict_
     WT *Wtki = Wt + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
     Wtki[0] = (WT)(-o0);
     Wtki[ld] = (WT)(-o1);
+    if (RING && scratch && row1 < nb && ib + bw >= row1) {             // a later range will want this slice
+      double *sc = scratch + ((size_t)kb * kNB + c0 + 2 * g) * ld + (size_t)ib * kNB + r;
+      sc[0] = -o0;
+      sc[ld] = -o1;
+    }
     if (RING) {
       double *slot = Ws + (ib % kRing) * kNB * kCw;                    // free: row ib + 1 needs slices ib+1-bw .. ib
       slot[r * kCw + 2 * g] = -o0;
@@ -454,20 +478,25 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <typename WT>
 __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__restrict__ L, int ld, int nb, int bw,
                                                             const double *__restrict__ Dinv, WT *__restrict__ W,
-                                                            WT *__restrict__ Wt) {
+                                                            WT *__restrict__ Wt, int row0 = 0, int row1 = 1 << 30) {
   __shared__ double At[kNB * kLdT];
   __shared__ double Ws[kNB * kCwM], S[kNB * kCwM];
   constexpr int kSl = kNB / kCwM;
   constexpr int kWr = kNB * kCwM / kBlock;                             // entries of a 64 x 16 slice per thread
   const int kb = blockIdx.x / kSl, c0 = (blockIdx.x % kSl) * kCwM;
+  row1 = min(row1, nb);
+  if (kb >= row1) return;                                              // (row ranges: see k_trtri_cols; the slices are
+  const bool first = kb >= row0;                                       // re-read as stored here, so nothing else is kept)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  for (int e = threadIdx.x; e < kNB * kCwM; e += kBlock) {
-    const int row = e / kCwM, c = e % kCwM;
-    const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
-    W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
-    Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
-  }
+  if (first)
+    for (int e = threadIdx.x; e < kNB * kCwM; e += kBlock) {
+      const int row = e / kCwM, c = e % kCwM;
+      const double v = Dinv[(size_t)kb * kNB * kNB + (size_t)row * kNB + c0 + c];
+      W[((size_t)kb * kNB + row) * ld + (size_t)kb * kNB + c0 + c] = (WT)v;
+      Wt[((size_t)kb * kNB + c0 + c) * ld + (size_t)kb * kNB + row] = (WT)v;
+    }
+  const int ib0 = first ? kb + 1 : row0;
   // slice jb of this workgroup's columns, as stored (the same workgroup wrote it, at least one barrier ago): requested one
   // product ahead, like the L tiles - a load inside the walk is a memory round trip per tile product
   auto slice_fetch = [&](int jb, WT wr[kWr]) {
@@ -480,9 +509,9 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
   double regs[kNB * kNB / kBlock];
   WT wregs[kWr];
   __syncthreads();                                                     // (the diagonal slice above is written)
-  if (kb + 1 < nb) {
-    const int j0 = max(kb, kb + 1 - bw);
-    tile_fetch(L + ((size_t)(kb + 1) * kNB) * ld + (size_t)j0 * kNB, ld, regs);
+  if (ib0 < row1) {
+    const int j0 = max(kb, ib0 - bw);
+    tile_fetch(L + ((size_t)ib0 * kNB) * ld + (size_t)j0 * kNB, ld, regs);
     slice_fetch(j0, wregs);
   }
   // one 64 x 64 (staged k-minor in At) times 64 x 16 (row-major in B) product into this wave's 16 x 16 block
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
     }
     return acc;
   };
-  for (int ib = kb + 1; ib < nb; ++ib) {
+  for (int ib = ib0; ib < row1; ++ib) {
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     const int jlo = max(kb, ib - bw);
     for (int jb = jlo; jb < ib; ++jb) {
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
     tile_store_k_minor(regs, At);                                      // At[m][row] = Dinv_i[row][m]
     __syncthreads();
     const int jn = max(kb, ib + 1 - bw);                               // first slice of the next block row
-    if (ib + 1 < nb) {
+    if (ib + 1 < row1) {
       tile_fetch(L + ((size_t)(ib + 1) * kNB) * ld + (size_t)jn * kNB, ld, regs);
       if (jn < ib) slice_fetch(jn, wregs);                             // (slice ib itself is only being computed)
     }
@@ -531,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_trtri_cols_mfma(const double *__rest
       W[((size_t)ib * kNB + row) * ld + (size_t)kb * kNB + c0 + li] = (WT)(-o[q]);
       Wt[((size_t)kb * kNB + c0 + li) * ld + (size_t)ib * kNB + row] = (WT)(-o[q]);
     }
-    if (ib + 1 < nb && jn == ib) {                                     // band of one block: the slice just written
+    if (ib + 1 < row1 && jn == ib) {                                   // band of one block: the slice just written
       __syncthreads();
       slice_fetch(ib, wregs);
     }
@@ -657,12 +686,29 @@ __global__ __launch_bounds__(kBlock) void k_tri_gemv_upper(int n, const WT *__re
 // Host driver: factor A (n x n, ld, n multiple of kNB; lower triangle used; its diagonal blocks end up holding
 // L_kk, the off-diagonal blocks of L go to Lf) and build W = L^-1.
 // bw: block bandwidth of A (blocks (i, j) with i - j > bw are zero), nb for a full matrix.
+// Row ranges of the inverse factor launched on a second stream while the chain is still running (rows = 0: one launch
+// after the chain, as until round 4).
+struct TrtriPhases {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_go = nullptr, ev_done = nullptr;
+  int rows = 0;
+};
 template <typename WT>
 inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *Dinv, int n, int ld, int *info,
                                  int bw, hipStream_t s, const std::function<void(int)> &after_chol = nullptr,
-                                 unsigned *bar = nullptr) {
+                                 unsigned *bar = nullptr, TrtriPhases ph = TrtriPhases()) {
   const int nb = n / kNB;
   if (bw <= 0 || bw > nb) bw = nb;
+  if (ph.rows <= 0 || !ph.ev_go || !ph.ev_done) ph.stream = nullptr;
+  int done = 0;                                                          // block rows of W already launched
+  auto trtri = [&](hipStream_t st, int row0, int row1) {
+    if (bw + 1 <= kRing)
+      hipLaunchKernelGGL((k_trtri_cols<WT, true>), dim3(std::min(nb, row1) * (kNB / kCw)), dim3(kBlock), 0, st, Lf, ld, nb, bw,
+                         Dinv, W, Wt, row0, row1, A);
+    else
+      hipLaunchKernelGGL((k_trtri_cols_mfma<WT>), dim3(std::min(nb, row1) * (kNB / kCwM)), dim3(kBlock), 0, st, Lf, ld, nb, bw,
+                         Dinv, W, Wt, row0, row1);
+  };
   if (after_chol) after_chol(0);       // (head of the chain: work that may run beside it on reserved CUs)
   hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(kBlock), 0, s, A, ld, 0, Dinv, info);
   const int g = std::min(nb - 1, bw);
@@ -673,16 +719,22 @@ inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *D
     for (int k = 0; k + 1 < nb; ++k) {
       const int rest = std::min(nb - k - 1, bw);                         // the fill stays inside the band
       hipLaunchKernelGGL(k_chol_step, dim3(rest, rest), dim3(kBlock), 0, s, A, Lf, ld, k, Dinv, info);
+      // the inverse factor walks BEHIND the chain: block rows [done, k + 2) of L and their diagonal inverses are final now
+      if (ph.stream && k + 2 < nb && (k + 2 - done) >= ph.rows && (nb - (k + 2)) >= ph.rows / 2) {
+        (void)hipEventRecord(ph.ev_go, s);
+        (void)hipStreamWaitEvent(ph.stream, ph.ev_go, 0);
+        trtri(ph.stream, done, k + 2);
+        (void)hipEventRecord(ph.ev_done, ph.stream);
+        done = k + 2;
+      }
     }
   }
   // after_chol: bulk work of the caller that should NOT run beside this latency-bound chain of dependent launches (every
   // link is slower next to a bandwidth-heavy kernel: measured 44 -> 57 us, also when released at 55 % of the chain) but
   // beside the single-launch inverse factor that follows
   if (after_chol) after_chol(1);
-  if (bw + 1 <= kRing)
-    hipLaunchKernelGGL((k_trtri_cols<WT, true>), dim3(nb * (kNB / kCw)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
-  else
-    hipLaunchKernelGGL((k_trtri_cols_mfma<WT>), dim3(nb * (kNB / kCwM)), dim3(kBlock), 0, s, Lf, ld, nb, bw, Dinv, W, Wt);
+  if (done > 0) (void)hipStreamWaitEvent(s, ph.ev_done, 0);
+  trtri(s, done, nb);
 }
 
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
