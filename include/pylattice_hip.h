@@ -123,7 +123,7 @@ typedef struct {
                           * Gear recurrences, the dense level's residual carried by recurrence): ONE all-reduce per iteration on
                           * several GPUs instead of three exchanges, for three more stored vectors.  0 = ordinary form. */
   int32_t tile_modes;    /* tile level of the multi-level PCG: 0 / 12 = rigid-body + uniform-strain modes per tile (12 x 12 blocks;
-                          * single-GPU handles, ordinary CG form), 6 = rigid-body modes only */
+                          * both CG forms, one or several GPUs), 6 = rigid-body modes only */
   int32_t coarse_modes;  /* dense level of the multi-level PCG: 0 = automatic (12 from 250 k nodes of the whole lattice), 12 =
                           * rigid-body + uniform-strain modes per aggregate (needs tile_modes = 12; fewer, larger aggregates),
                           * 6 = rigid-body modes */

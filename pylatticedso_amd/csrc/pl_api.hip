@@ -103,10 +103,9 @@ int check_opts_abi(const pl_opts_t *o, const char *who) {
   return PL_OK;
 }
 inline bool multi_rank_handle(const pl_opts_t *o) { return o->grid_nodes > 0; }
-// modes per aggregate of the dense level: 12 (rigid + strains) needs the 12-mode tile level, i.e. a single-GPU handle in
-// the ordinary CG form with precond = 3
+// modes per aggregate of the dense level: 12 (rigid + strains) needs the 12-mode tile level, i.e. precond = 3 (either CG form)
 inline int coarse_modes_of(const pl_opts_t *o, int64_t N = -1) {
-  const bool tile12 = o->precond == 3 && !(o->tile_modes == 6 || o->cg_form == 1);
+  const bool tile12 = o->precond == 3 && o->tile_modes != 6;
   if (!tile12 || o->coarse_modes == 6) return 6;
   if (multi_rank_handle(o)) N = o->grid_nodes;       // every rank must decide alike: the node count of the whole lattice
   // automatic: from a quarter of a million nodes on (below, the longer set-up of the richer level costs what its
@@ -405,7 +404,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     c->coarse.tile_level = (o->precond >= 3);
     // 12-mode tile level (rigid + uniform strains): single-GPU handles in the ordinary CG form; opts.tile_modes = 6 keeps
     // the rigid-body blocks
-    c->coarse.tile_modes = (o->tile_modes == 6 || o->precond == 4 || o->cg_form == 1) ? 6 : 12;
+    c->coarse.tile_modes = (o->tile_modes == 6 || o->precond == 4) ? 6 : 12;
     // default size of the dense level: its factorisation is a ~45 us-per-64-dofs latency chain in every assembly, its
     // benefit grows with the cost of an iteration - up to 1 M nodes on one GPU the optimum is ~2 000 dofs (measured on
     // 50^3 Octet: 7^3 aggregates 18.9 ms per step, 8^3 20.7 ms), beyond that and in multi-rank runs (collectives in

@@ -28,19 +28,23 @@ namespace pl {
 // offsets inside one reduction block
 __host__ __device__ inline int cg1_block_size(int ncp) { return ncp + 3 * kSlots; }
 
-// Z^T (weight o v) of every aggregate, one workgroup per tile, atomics into out[6 * agg + k] (~8 tiles per aggregate)
+// Z^T (weight o v) of every aggregate, one workgroup per tile, atomics into out[CM * agg + k] (~8 tiles per aggregate).
+// CM = modes per aggregate of the dense level: 6 rigid, or 12 = rigid + uniform strains (pl_coarse.h: strain_disp).
+template <int CM>
 __global__ __launch_bounds__(kBlock) void k_cg1_restrict(const int32_t *__restrict__ tile_start,
                                                          const int32_t *__restrict__ agg_of_tile,
                                                          const double *__restrict__ cen, const double *__restrict__ xyz,
                                                          const double *__restrict__ v,
                                                          const double *__restrict__ wt /* may be null */,
                                                          double *__restrict__ out) {
-  __shared__ double red[6][kBlock / kWave];
+  __shared__ double red[CM][kBlock / kWave];
   const int t = blockIdx.x;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double acc[CM];
+#pragma unroll
+  for (int k = 0; k < CM; ++k) acc[k] = 0.0;
   for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     double vv[6];
 #pragma unroll
@@ -60,24 +64,33 @@ __global__ __launch_bounds__(kBlock) void k_cg1_restrict(const int32_t *__restri
     acc[3] += vv[3] + (ry * vv[2] - rz * vv[1]);
     acc[4] += vv[4] + (rz * vv[0] - rx * vv[2]);
     acc[5] += vv[5] + (rx * vv[1] - ry * vv[0]);
+    if constexpr (CM == 12) {
+      acc[6] += rx * vv[0];
+      acc[7] += ry * vv[1];
+      acc[8] += rz * vv[2];
+      acc[9] += 0.5 * (ry * vv[0] + rx * vv[1]);
+      acc[10] += 0.5 * (rz * vv[1] + ry * vv[2]);
+      acc[11] += 0.5 * (rz * vv[0] + rx * vv[2]);
+    }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < CM; ++k) {
     const double s = wave_sum(acc[k]);
     if (lane == 0) red[k][wv] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < CM) {
     double s = 0.0;
     for (int q = 0; q < nw; ++q) s += red[threadIdx.x][q];
-    unsafeAtomicAdd(out + 6 * a + threadIdx.x, s);
+    unsafeAtomicAdd(out + CM * a + threadIdx.x, s);
   }
 }
 
 // INIT: the pass before iteration 0 - no vector update (alpha = beta = 0), only the tile level and the partial sums of
 // r0 (Z^T r0 itself comes from k_cg1_restrict).
-template <bool INIT>
+// TM = modes of the tile level (6, or 12 = rigid + uniform strains about the aggregate's reference point, B_t^-1 12 x 12).
+template <bool INIT, int TM>
 __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict__ tile_start,
                                                        const int32_t *__restrict__ agg_of_tile,
                                                        const double *__restrict__ cen, const double *__restrict__ xyz,
@@ -95,7 +108,8 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
                                                        const uint8_t *__restrict__ shared /* may be null */,
                                                        double *__restrict__ rc, double *__restrict__ sc, int ncp,
                                                        double *__restrict__ hist, int k) {
-  __shared__ double red[8][kBlock / kWave];
+  __shared__ double red[14][kBlock / kWave];
+  __shared__ double tot[16], ys[16];
   const int t = blockIdx.x;
   double alpha = 0.0, beta = 0.0;
   if (!INIT) {
@@ -127,12 +141,15 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
   const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
-  double bi[6] = {0, 0, 0, 0, 0, 0};   // row threadIdx.x of B_t^-1, fetched early: it is needed at the very end
-  if (Bt_inv && threadIdx.x < 6) {
+  double bi[TM];                        // row threadIdx.x of B_t^-1, fetched early: it is needed at the very end
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bi[j] = Bt_inv[(size_t)t * 36 + 6 * threadIdx.x + j];
+  for (int j = 0; j < TM; ++j) bi[j] = 0.0;
+  if (Bt_inv && threadIdx.x < TM) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) bi[j] = Bt_inv[(size_t)t * (TM * TM) + TM * threadIdx.x + j];
   }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0-5 tile restriction (nodes of this rank alone), 6 r.r, 7 r.D^-1 r
+  double accS[6] = {0, 0, 0, 0, 0, 0};        // TM = 12: the tile's strain restrictions (same nodes)
   for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     double rv[6], dv[6];
     const float2 *d2 = reinterpret_cast<const float2 *>(dinv32 + 6 * (int64_t)i);
@@ -176,6 +193,14 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
       acc[3] += rv[3] + (ry * rv[2] - rz * rv[1]);
       acc[4] += rv[4] + (rz * rv[0] - rx * rv[2]);
       acc[5] += rv[5] + (rx * rv[1] - ry * rv[0]);
+      if constexpr (TM == 12) {
+        accS[0] += rx * rv[0];
+        accS[1] += ry * rv[1];
+        accS[2] += rz * rv[2];
+        accS[3] += 0.5 * (ry * rv[0] + rx * rv[1]);
+        accS[4] += 0.5 * (rz * rv[1] + ry * rv[2]);
+        accS[5] += 0.5 * (rz * rv[0] + rx * rv[2]);
+      }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -184,33 +209,48 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
     const double v = wave_sum(acc[q]);
     if (lane == 0) red[q][wv] = v;
   }
+  if constexpr (TM == 12) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double v = wave_sum(accS[q]);
+      if (lane == 0) red[8 + q][wv] = v;
+    }
+  }
   __syncthreads();
-  if (threadIdx.x < 8) {
+  // first wave: tot[0..5] rigid restriction, 6 r.r, 7 r.D^-1 r, 8..13 strain restriction; then the tile level
+  // y_t = B_t^-1 (Z_t^T r), whose share r_t . y_t of r.u joins r.D^-1 r (one wave: its LDS operations are in order)
+  if (threadIdx.x < 16) {
     double *gam_slot = blk_nxt + ncp + kSlots + (blockIdx.x & (kSlots - 1)), *rr_slot = gam_slot + kSlots;
     double v = 0.0;
-    for (int q = 0; q < nw; ++q) v += red[threadIdx.x][q];
+    if (threadIdx.x < (TM == 12 ? 14 : 8))
+      for (int q = 0; q < nw; ++q) v += red[threadIdx.x][q];
+    tot[threadIdx.x] = v;
     if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, v);
     if (!Bt_inv) {
       if (threadIdx.x == 7) unsafeAtomicAdd(gam_slot, v);
-    } else {   // tile level: y_t = B_t^-1 (Z_t^T r); its share r_t . y_t of r.u joins r.D^-1 r
-      const double stv = threadIdx.x < 6 ? v : 0.0;
-      double tj[6];
+    } else {
+      // mode m of the tile level sits in tot[m] (m < 6) or tot[m + 2] (strains)
+      double y = 0.0, stv = 0.0;
+      if (threadIdx.x < TM) {
+        stv = tot[threadIdx.x < 6 ? threadIdx.x : threadIdx.x + 2];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) tj[j] = __shfl(stv, j, 8);
-      double y = 0.0;
+        for (int j = 0; j < TM; ++j) y += bi[j] * tot[j < 6 ? j : j + 2];
+        yt[TM * (size_t)t + threadIdx.x] = y;
+      }
+      ys[threadIdx.x] = threadIdx.x < TM ? y * stv : 0.0;
+      if (threadIdx.x == 0) {
+        double g = tot[7];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) y += bi[j] * tj[j];
-      if (threadIdx.x < 6) yt[6 * (size_t)t + threadIdx.x] = y;
-      double g = threadIdx.x < 6 ? y * stv : (threadIdx.x == 7 ? v : 0.0);
-      g += __shfl_xor(g, 1, 8);
-      g += __shfl_xor(g, 2, 8);
-      g += __shfl_xor(g, 4, 8);
-      if (threadIdx.x == 0) unsafeAtomicAdd(gam_slot, g);
+        for (int j = 0; j < 16; ++j) g += ys[j];
+        unsafeAtomicAdd(gam_slot, g);
+      }
     }
   }
 }
 
 // u = D^-1 r + P Z (y_c + y_t), stored; `clear` [n_clear] and `clear2` [kSlots] are zeroed for their next use.
+// TM / cm: modes of the tile level / per aggregate of the dense level (12 = rigid + uniform strains; cm = 12 needs TM = 12).
+template <int TM>
 __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restrict__ tile_start,
                                                         const double *__restrict__ r, const float *__restrict__ dinv32,
                                                         const double *__restrict__ xyz,
@@ -220,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restric
                                                         const uint8_t *__restrict__ fixedbits,
                                                         const uint8_t *__restrict__ shared /* may be null */,
                                                         double *__restrict__ u, double *__restrict__ clear, int n_clear,
-                                                        double *__restrict__ clear2) {
+                                                        double *__restrict__ clear2, int cm) {
   if (clear && (blockIdx.x == 1 || gridDim.x == 1))
     for (int e = threadIdx.x; e < n_clear; e += blockDim.x) clear[e] = 0.0;
   if (clear2 && blockIdx.x == 0)
@@ -228,15 +268,31 @@ __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restric
   const int t = blockIdx.x;
   const int n0 = tile_start[t], n1 = tile_start[t + 1];
   const int a = agg_of_tile[t];
-  const double *y = yc + 6 * a;
+  const double *y = yc + cm * a;
   double U0 = y[0], U1 = y[1], U2 = y[2], W0 = y[3], W1 = y[4], W2 = y[5];
-  double T[6] = {0, 0, 0, 0, 0, 0};
-  if (yt) {
-    const double *q = yt + 6 * (size_t)t;
+  double T[TM];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) T[k] = q[k];
+  for (int k = 0; k < TM; ++k) T[k] = 0.0;
+  if (yt) {
+    const double *q = yt + TM * (size_t)t;
+#pragma unroll
+    for (int k = 0; k < TM; ++k) T[k] = q[k];
     if (!shared) {   // one GPU: tile and aggregate use the same reference point, the two rigid motions just add
       U0 += T[0]; U1 += T[1]; U2 += T[2]; W0 += T[3]; W1 += T[4]; W2 += T[5];
+    }
+  }
+  double ED[6] = {0, 0, 0, 0, 0, 0};   // the aggregate's uniform strains (12-mode dense level)
+  if constexpr (TM == 12) {
+    if (cm == 12) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ED[k] = y[6 + k];
+      if (!shared) {   // one GPU: same reference point, same nodes - they add to the tile's
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          T[6 + k] += ED[k];
+          ED[k] = 0.0;
+        }
+      }
     }
   }
   const bool own_t = yt && shared;   // several GPUs: nodes shared with other ranks are left out of the tile level
@@ -244,6 +300,18 @@ __global__ __launch_bounds__(kBlock) void k_cg1_precond(const int32_t *__restric
   for (int64_t i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
     const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
+    if constexpr (TM == 12) {   // uniform strains: u += eps r (several GPUs: the aggregate's everywhere, the tile's on own nodes)
+      if (shared && cm == 12) {
+        zc[0] += ED[0] * rx + 0.5 * (ED[3] * ry + ED[5] * rz);
+        zc[1] += ED[1] * ry + 0.5 * (ED[3] * rx + ED[4] * rz);
+        zc[2] += ED[2] * rz + 0.5 * (ED[4] * ry + ED[5] * rx);
+      }
+      if (!(shared && shared[i])) {
+        zc[0] += T[6] * rx + 0.5 * (T[9] * ry + T[11] * rz);
+        zc[1] += T[7] * ry + 0.5 * (T[9] * rx + T[10] * rz);
+        zc[2] += T[8] * rz + 0.5 * (T[10] * ry + T[11] * rx);
+      }
+    }
     if (own_t && !shared[i]) {
       zc[0] += T[0] + (T[4] * rz - T[5] * ry);
       zc[1] += T[1] + (T[5] * rx - T[3] * rz);

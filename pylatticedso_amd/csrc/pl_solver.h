@@ -365,6 +365,15 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
   const double *Bt = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
   const double *yt = cs.tile_level ? (const double *)cs.yt : (const double *)nullptr;
   const dim3 gt((unsigned)cs.n_tiles), blkdim(cs.vblock);
+  const bool tm12 = tile_modes_now(c) == 12, cm12 = cs.cm == 12;     // (a 12-mode dense level needs the 12-mode tile level)
+  auto restrict_to = [&](const double *v, double *out) {
+    if (cm12)
+      hipLaunchKernelGGL(pl::k_cg1_restrict<12>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                         c->xyz.p, v, wt, out);
+    else
+      hipLaunchKernelGGL(pl::k_cg1_restrict<6>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
+                         c->xyz.p, v, wt, out);
+  };
 
   PL_HIP(hipMemsetAsync(c->scal.p, 0, 2 * pl::S_COUNT * pl::kSlots * sizeof(double), c->stream));
   PL_HIP(hipMemsetAsync(c->cg1.p, 0, need * sizeof(double), c->stream));
@@ -386,27 +395,32 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
   auto second_half = [&](int k) -> int {
     const int cur = k & 1, nxt = (k + 1) & 1;
     pl::coarse_apply(cs, cs.rc, cs.tv, cs.yc, gc[nxt], (const double *)nullptr, c->stream);
-    hipLaunchKernelGGL(pl::k_cg1_precond, gt, blkdim, 0, c->stream, c->tile.tile_start.p, (const double *)c->r.p,
-                       cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc, yt, c->fixedbits.p, shared, u,
-                       k >= 0 ? blk[cur] : (double *)nullptr, bs, k >= 0 ? gc[cur] : (double *)nullptr);
+#define PL_CG1_PRE(TM)                                                                                                  \
+  hipLaunchKernelGGL(pl::k_cg1_precond<TM>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, (const double *)c->r.p,     \
+                     cs.dinv32, c->xyz.p, cs.agg_of_tile.p, cs.cen.p, cs.yc, yt, c->fixedbits.p, shared, u,             \
+                     k >= 0 ? blk[cur] : (double *)nullptr, bs, k >= 0 ? gc[cur] : (double *)nullptr, cs.cm)
+    if (tm12) PL_CG1_PRE(12);
+    else PL_CG1_PRE(6);
+#undef PL_CG1_PRE
     int r2 = launch_spmv(c, u, w, true, blk[nxt] + ncp, nullptr, pl::kEndsAll, false);
     if (r2) return r2;
-    hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
-                       c->xyz.p, (const double *)w, wt, blk[nxt]);
+    restrict_to((const double *)w, blk[nxt]);
     if (c->dist.active && pl::dist_sum_scalars(c->dist, blk[nxt], bs, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the single-reduction PCG failed");
     PL_HIP(hipGetLastError());
     return PL_OK;
   };
   // Z^T r0 (summed over ranks once), tile level and partial sums of r0 into block 0, then u0, w0
-  hipLaunchKernelGGL(pl::k_cg1_restrict, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
-                     c->xyz.p, (const double *)c->r.p, wt, cs.rc);
+  restrict_to((const double *)c->r.p, cs.rc);
   if (c->dist.active && pl::dist_sum_scalars(c->dist, cs.rc, ncp, c->stream))
     return fail(PL_ERR_HIP, "RCCL all-reduce of the initial coarse residual failed");
-  hipLaunchKernelGGL(pl::k_cg1_update<true>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p,
-                     c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p, c->r.p,
-                     (const double *)blk[1], (const double *)gc[1], (const double *)stt[1], stt[0], blk[0], Bt, cs.yt,
-                     shared, cs.rc, sc, ncp, c->hist.p, -1);
+#define PL_CG1_UPD(INIT, TM, CUR, NXT, IT)                                                                                \
+  hipLaunchKernelGGL((pl::k_cg1_update<INIT, TM>), gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p,     \
+                     cs.cen.p, c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p, c->r.p, \
+                     (const double *)blk[CUR], (const double *)gc[CUR], (const double *)stt[CUR], stt[NXT], blk[NXT], Bt, \
+                     cs.yt, shared, cs.rc, sc, ncp, c->hist.p, IT)
+  if (tm12) PL_CG1_UPD(true, 12, 1, 0, -1);
+  else PL_CG1_UPD(true, 6, 1, 0, -1);
   rc = second_half(-1);
   if (rc) return rc;
 
@@ -435,10 +449,8 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
     const int todo = std::min(next, max_iter + 1 - k);
     for (int j = 0; j < todo; ++j) {
       const int it = k + j, cur = it & 1, nxt = (it + 1) & 1;
-      hipLaunchKernelGGL(pl::k_cg1_update<false>, gt, blkdim, 0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p,
-                         cs.cen.p, c->xyz.p, (const double *)u, (const double *)w, cs.dinv32, wt, c->p.p, s, c->x.p,
-                         c->r.p, (const double *)blk[cur], (const double *)gc[cur], (const double *)stt[cur], stt[nxt],
-                         blk[nxt], Bt, cs.yt, shared, cs.rc, sc, ncp, c->hist.p, it);
+      if (tm12) PL_CG1_UPD(false, 12, cur, nxt, it);
+      else PL_CG1_UPD(false, 6, cur, nxt, it);
       rc = second_half(it);
       if (rc) return rc;
     }
@@ -470,6 +482,7 @@ int pcg_solve_cg1(pl_context *c, const double *f_dev, const double *Kubar_dev, d
     }
   }
   if (!st->converged) st->iterations = std::min(k, max_iter);
+#undef PL_CG1_UPD
   return PL_OK;
 }
 

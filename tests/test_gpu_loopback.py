@@ -90,6 +90,9 @@ def test_partitioned_operator_equals_the_whole(name, world, p2p):
 
 CASES = {"precond3": dict(precond=3), "precond4": dict(precond=4), "jacobi": dict(precond=1),
          "cg_form1": dict(precond=3, cg_form=1), "precision1": dict(precond=3, precision=1),
+         # single-reduction form with rigid-body levels only / with strain modes on both levels (round 4)
+         "cg_form1_modes6": dict(precond=3, cg_form=1, tile_modes=6),
+         "cg_form1_modes12": dict(precond=3, cg_form=1, tile_modes=12, coarse_modes=12),
          "precond4_precision1": dict(precond=4, precision=1), "precision2": dict(precond=3, precision=2),
          # node elimination on multi-rank handles (nodes shared with another rank stay unknowns)
          "condense": dict(precond=3, condense=1), "condense_precision1": dict(precond=3, condense=1, precision=1),
@@ -123,7 +126,7 @@ def test_partitioned_solve_equals_single_handle(name, world, case):
             u0 = _body_load_reference(name)
             assert all(st["condensed_nodes"] > 0 for st in stats)
         assert _rel(u, u0) < 1e-8
-        if case == "cg_form1":
+        if case.startswith("cg_form1"):
             assert all(int(st["cg_form_used"]) == 1 for st in stats)
         if case.startswith("precision") or case.endswith("precision1"):
             assert all(int(st["precision_used"]) == CASES[case]["precision"] for st in stats)

@@ -951,13 +951,16 @@ def test_node_elimination_is_off_with_kernels_that_ignore_its_masks(golden_dir, 
         assert _rel(u, uref) < 1e-8
 
 
+@pytest.mark.parametrize("modes", [(6, 6), (12, 6), (12, 12)])
 @pytest.mark.parametrize("name", ["bccoctet_2x2x2", "bcc_6x3x3_flexion", "octet_3x2x2_size",
                                   "bcchybrid1hybrid4_3x2x1_size"])
-def test_single_reduction_pcg_matches_oracle(golden_dir, name):
+def test_single_reduction_pcg_matches_oracle(golden_dir, name, modes):
     """opts.cg_form = 1 (Chronopoulos-Gear recurrences, the dense level's residual carried by recurrence - one all-reduce
     per iteration on several GPUs): same solution as the oracle's direct solve and as the ordinary form, prescribed
-    displacements included; the iteration count may differ by the one-iteration lag of the residual norm."""
+    displacements included; the iteration count may differ by the one-iteration lag of the residual norm.  With rigid-body
+    levels and (round 4) with the uniform-strain modes on the tile level alone and on both levels."""
     _, L = _sim(golden_dir, name)
+    tile_modes, coarse_modes = modes
     lat = L.lattice
     f = np.zeros((lat.n_nodes, 6))
     f[:, :3] = L.applied_force[:, :3]
@@ -966,7 +969,8 @@ def test_single_reduction_pcg_matches_oracle(golden_dir, name):
     uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
     res = {}
     for form in (0, 1):
-        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=-1, cg_form=form, tile_modes=6) as dev:
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=-1, cg_form=form, tile_modes=tile_modes,
+                     coarse_modes=coarse_modes) as dev:
             dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
             dev.assemble()
             u, st = dev.solve(rtol=1e-11, max_iter=20000)
@@ -982,9 +986,11 @@ def test_single_reduction_pcg_matches_oracle(golden_dir, name):
     assert res[1][1] <= res[0][1] * 1.03 + 2
 
 
-def test_single_reduction_pcg_at_scale():
+@pytest.mark.parametrize("tile_modes", [6, 12])
+def test_single_reduction_pcg_at_scale(tile_modes):
     """24^3 Octet cantilever with the bench's solver settings: both CG forms reach the same displacements (1e-8) and
-    the single-reduction form needs at most 3 % + 1 more iterations."""
+    the single-reduction form needs at most 3 % + 1 more iterations - with rigid-body levels
+    and with the strain modes the ordinary form runs with by default (round 4: the single-reduction form has them too)."""
     from pylatticedso_amd import lattice_arrays as LA
     n = 24
     lat = LA.generate((1, 1, 1), (n, n, n), ["Octet"], [0.03])
@@ -997,7 +1003,7 @@ def test_single_reduction_pcg_at_scale():
     out = {}
     for form in (0, 1):
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
-                              precond=3, palette=1, cg_form=form, tile_modes=6) as dev:   # (cg_form 1 has 6-mode tiles)
+                              precond=3, palette=1, cg_form=form, tile_modes=tile_modes) as dev:
             dev.set_bc(fixed, None, f)
             dev.assemble()
             u, st = dev.solve(rtol=1e-10, max_iter=5000)
