@@ -192,8 +192,9 @@ void pl_destroy(pl_handle h);
  * Cell.define_node_order_to_simulate, cell.py:611-680) through the dense Schur complement S[cell_S[c]] ((6nb)^2,
  * row-major).  The handle then serves pl_set_bc / pl_assemble / pl_spmv / pl_spmv_free / pl_solve / pl_reactions with
  * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (opts->precond = 0, as the reference's default), Jacobi-CG
- * (opts->precond = 1) or CG preconditioned by the factorised assembled matrix (opts->precond = 2, below), with
- * opts->alpha_max. */
+ * (opts->precond = 1), CG preconditioned by the factorised assembled matrix (opts->precond = 2, below) or by the inverted
+ * 6 x 6 node blocks of the assembled matrix (opts->precond = 3: any size; built by pl_assemble for the current Dirichlet
+ * mask from the same matrices as precond = 2), with opts->alpha_max. */
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S, const double *S,
                   const int32_t *cell_S, const pl_opts_t *opts, pl_handle *out);
 

@@ -473,11 +473,11 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   c->opt = *o;
   // 0: the reference's plain CG; 1: Jacobi on the assembled Schur diagonal; 2: the reference's own preconditioner, the
   // factorised assembled Schur matrix (dense Cholesky on the device, hence the size limit)
-  c->opt.precond = (o->precond == 1 || o->precond == 2) ? o->precond : 0;
+  c->opt.precond = (o->precond >= 1 && o->precond <= 3) ? o->precond : 0;     // 3: node-block Jacobi (6 x 6 blocks of G)
   if (c->opt.precond == 2 && 6 * n_nodes > PL_DDM_DENSE_MAX) {
     delete c;
     return fail(PL_ERR_ARG, "pl_create_ddm: precond = 2 factorises a dense (6 n_nodes)^2 matrix; limit is " +
-                                std::to_string(PL_DDM_DENSE_MAX) + " dofs (use precond = 1)");
+                                std::to_string(PL_DDM_DENSE_MAX) + " dofs (use precond = 3 or 1)");
   }
   c->opkind = 1;
   c->N = n_nodes;
@@ -718,10 +718,12 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     if (rcs) return rcs;
   }
   if (h->assembled && h->opkind == 1) {
-    if (h->opt.precond == 2) {
-      // the factorised G was built for the old Dirichlet mask (and dinv must stay 0 next to it): build it again
+    if (h->opt.precond == 2 || h->opt.precond == 3) {
+      // the factorised G / the node blocks were built for the old Dirichlet mask (and dinv must stay 0 next to them):
+      // build them again
       h->assembled = false;
       h->dd_ready = false;
+      h->dd_blocks = false;
     } else {
       pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
       PL_HIP(hipStreamSynchronize(h->stream));
@@ -809,6 +811,28 @@ int pl_assemble(pl_handle h) {
   PL_HIP(hipSetDevice(h->opt.device));
   if (h->opkind == 1) {   // DDM operator: nothing to build; plain CG as the reference, Jacobi, or the factorised matrix
     h->dd_ready = false;
+    h->dd_blocks = false;
+    if (h->opt.precond == 3) {      // node-block Jacobi: the 6 x 6 diagonal blocks of the assembled matrix, inverted
+      PL_HIP(hipEventRecord(h->ev0, h->stream));
+      if (!h->dd_B.p) PL_HIP(h->dd_B.alloc((size_t)h->N * 36));
+      PL_HIP(hipMemsetAsync(h->dd_B.p, 0, (size_t)h->N * 36 * sizeof(double), h->stream));
+      const int64_t ne = (int64_t)h->ddm_cells * h->ddm_nb * 36;
+      hipLaunchKernelGGL(pl::k_ddm_node_blocks, dim3(grid_for(ne)), dim3(pl::kBlock), 0, h->stream, h->ddm_cells, h->ddm_nb,
+                         h->ddm_cell_nodes.p, h->ddm_have_P ? h->ddm_cell_P.p : h->ddm_cell_S.p,
+                         h->ddm_have_P ? h->ddm_Pt.p : h->ddm_St.p, h->dd_B.p);
+      hipLaunchKernelGGL(pl::k_ddm_node_blocks_invert, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N,
+                         h->have_bc ? (const uint8_t *)h->fixed.p : (const uint8_t *)nullptr, h->dd_B.p);
+      PL_HIP(hipMemsetAsync(h->dinv.p, 0, h->N * 6 * sizeof(double), h->stream));      // z comes from the node blocks
+      PL_HIP(hipEventRecord(h->ev1, h->stream));
+      PL_HIP(hipEventSynchronize(h->ev1));
+      PL_HIP(hipGetLastError());
+      float ms = 0.f;
+      PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      h->ms_assembly = ms;
+      h->dd_blocks = true;
+      h->assembled = true;
+      return PL_OK;
+    }
     if (h->opt.precond == 2) {
       PL_HIP(hipEventRecord(h->ev0, h->stream));
       int rcp = ddm_factor_preconditioner(h);
@@ -1050,7 +1074,7 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   st.ms_solve = ms;
   st.ms_assembly = h->ms_assembly;
-  st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->opt.precond >= 1 ? 1 : 0)
+  st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->dd_blocks ? 3 : h->opt.precond >= 1 ? 1 : 0)
                                    : (h->coarse.ready ? h->opt.precond : 1);
   if (u) {
     rc = download6(h, h->tmp2.p, u);

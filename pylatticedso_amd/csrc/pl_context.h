@@ -146,6 +146,8 @@ struct pl_context {
   int dd_n = 0;          // padded order of the dense matrix (0: not allocated)
   int dd_bw = 0;         // its block bandwidth in the caller's node numbering (from the cells' node spans)
   bool dd_ready = false;
+  DevBuf<double> dd_B;   // node-block Jacobi of the DDM operator (opt.precond = 3): inverted 6 x 6 blocks
+  bool dd_blocks = false;
   // record palette (pl_palette.h)
   DevBuf<unsigned long long> pal_keys;
   DevBuf<int> pal_owner, pal_flags;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pl_kernels.h"
+#include "pl_coarse.h"
 
 namespace pl {
 
@@ -296,6 +297,62 @@ __global__ __launch_bounds__(kBlock) void k_ddm_diag(int64_t C, int nb, const in
   const int i = (int)(e - c * m);
   const double *S = St + (size_t)cell_S[c] * m * m;
   unsafeAtomicAdd(diag + 6 * (int64_t)cell_nodes[c * nb + i / 6] + i % 6, S[(size_t)i * m + i]);
+}
+
+// Node-block Jacobi (opts.precond = 3 on a DDM handle; what LatticeSim.solve_DDM asks for above PL_DDM_DENSE_MAX dofs, where
+// the assembled matrix is not factorised): the 6 x 6 diagonal blocks of G = sum_c B_c^T Shat_c B_c, inverted per node.
+// Constrained dofs are taken out of the block before the inversion and get zero rows / columns in the inverse.  Measured on the
+// host (BCC cantilevers, r = 0.05, 1e-8): 20^3 cells 296 iterations against 384 with the diagonal alone, 12^3 175 against 254.
+__global__ __launch_bounds__(kBlock) void k_ddm_node_blocks(int64_t C, int nb, const int32_t *__restrict__ cell_nodes,
+                                                            const int32_t *__restrict__ cell_S,
+                                                            const double *__restrict__ St, double *__restrict__ B) {
+  const int m = 6 * nb;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= C * nb * 36) return;
+  const int64_t c = e / (nb * 36);
+  const int q = (int)(e - c * nb * 36), a = q / 36, ij = q - 36 * a, i = ij / 6, j = ij - 6 * i;
+  const double *S = St + (size_t)cell_S[c] * m * m;        // (stored transposed; the diagonal blocks are symmetric)
+  unsafeAtomicAdd(B + 36 * (int64_t)cell_nodes[c * nb + a] + ij, S[(size_t)(6 * a + i) * m + 6 * a + j]);
+}
+__global__ __launch_bounds__(kBlock) void k_ddm_node_blocks_invert(int64_t N, const uint8_t *__restrict__ fixed /* may be null */,
+                                                                   double *__restrict__ B) {
+  const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  double A[36];
+  bool fx[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fx[k] = fixed && fixed[6 * n + k];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double v = 0.5 * (B[36 * n + 6 * i + j] + B[36 * n + 6 * j + i]);
+      A[6 * i + j] = (fx[i] || fx[j]) ? 0.0 : v;           // (spd6_inverse drops modes without stiffness)
+    }
+  spd6_inverse(A);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) B[36 * n + 6 * i + j] = (fx[i] || fx[j]) ? 0.0 : A[6 * i + j];
+}
+// z = B^-1 r node by node, dot_out[slot] += r.z
+__global__ __launch_bounds__(kBlock) void k_ddm_node_blocks_apply(int64_t N, const double *__restrict__ B,
+                                                                  const double *__restrict__ r, double *__restrict__ z,
+                                                                  double *__restrict__ dot_out) {
+  __shared__ double red[kBlock / kWave];
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;     // one lane per row of a node block
+  double acc = 0.0;
+  if (t < 6 * N) {
+    const int64_t n = t / 6;
+    const double *row = B + 6 * t;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v += row[j] * r[6 * n + j];
+    z[t] = v;
+    acc = v * r[t];
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0 && dot_out) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
 }
 
 // The reference's CG preconditioner for this operator (LatticeSim.build_preconditioner, lattice_sim.py:1351-1415, with

@@ -93,6 +93,16 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
   return pcg_tail_coarse_t<double, double>(c, cur, nxt, hist_slot, c->p.p, (const double *)c->Ap.p, c->x.p, c->r.p);
 }
 
+// z = G^-1 r of a DDM handle (dense factor of the assembled matrix, or its inverted node blocks); dot[kSlots] += r.z
+inline void ddm_precondition(pl_context *c, double *dot) {
+  if (c->dd_ready)
+    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p, dot, (const double *)nullptr,
+                    c->stream);
+  else
+    hipLaunchKernelGGL(pl::k_ddm_node_blocks_apply, dim3(grid_for(c->N * 6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       (const double *)c->dd_B.p, (const double *)c->r.p, c->z.p, dot);
+}
+
 // One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
 int pcg_iteration(pl_context *c, int k) {
   const int64_t n6 = c->N * 6;
@@ -115,7 +125,7 @@ int pcg_iteration(pl_context *c, int k) {
   // on the PREVIOUS z (with a preconditioner; kept in tmp) or on the updated residual (without one: z aliases r there)
   const bool ref = ref_cg(c) && !c->dist.active;
   const bool restart = ref && c->opt.restart_every > 0 && k > 0 && (k % c->opt.restart_every) == 0;
-  const bool has_M = c->dd_ready || c->opt.precond >= 1;
+  const bool has_M = c->dd_ready || c->dd_blocks || c->opt.precond >= 1;
   const double *pn = c->p.p, *psrc = nullptr;
   if (restart) {
     if (has_M) {
@@ -127,15 +137,15 @@ int pcg_iteration(pl_context *c, int k) {
     }
   }
   const int hcap = ref ? c->hist_cap : 0;
-  if (c->dd_ready) {   // DDM with the factorised assembled matrix: update leaves z = 0, r.z = 0; then z = G^-1 r
+  if (c->dd_ready || c->dd_blocks) {   // DDM with the factorised assembled matrix / its node blocks: update leaves z = 0,
+                                       // r.z = 0; then z = G^-1 r
     if (ref)
       hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
                          c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
     else
       hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
                          c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
-    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
-                    cur + pl::S_RZ_NEW * pl::kSlots, (const double *)nullptr, c->stream);
+    ddm_precondition(c, cur + pl::S_RZ_NEW * pl::kSlots);
     hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
                        c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
     PL_HIP(hipGetLastError());
@@ -178,9 +188,8 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
         pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
   }
-  if (c->dd_ready) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
-    pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p,
-                    c->scal.p + pl::S_RZ_OLD * pl::kSlots, (const double *)nullptr, c->stream);
+  if (c->dd_ready || c->dd_blocks) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
+    ddm_precondition(c, c->scal.p + pl::S_RZ_OLD * pl::kSlots);
     PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   if (c->cond_use) {   // (decided by solver_plan: never with a K*p kernel that ignores the elimination masks)

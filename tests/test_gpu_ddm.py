@@ -125,7 +125,8 @@ def test_preconditioned_ddm_reproduces_reference(golden_dir, case, iters):
 def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeypatch):
     """preconditioner_type "mean" (what the reference's DDM presets name): its Schur_complement_mean_*.npz is not in
     the reference's checkout, so the mean of the radius dataset stands in.  Beyond the dense limit the device falls
-    back to Jacobi, says so once and lifts the iteration cap those presets carry (optimization_DDM_surrogate: 10)."""
+    back to the node blocks of the assembled matrix (block Jacobi), says so once and lifts the iteration cap those
+    presets carry (optimization_DDM_surrogate: 10)."""
     import pylatticedso_amd.lattice_sim as LS
     g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
     preset = json.loads(str(g["preset_json"]))
@@ -151,8 +152,9 @@ def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeyp
     L3 = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
     xsol3, info3, _, _ = L3.solve_DDM()
     L3.solve_DDM()
-    assert L3._ddm_precond == 1 and info3 == 0 and L3.iteration > 10 and _rel(xsol3, g["xsol"]) < 1e-5
-    assert L3.iteration < int(g["iterations"])            # Jacobi on the assembled diagonal beats the plain CG count
+    assert L3._ddm_precond == 3 and info3 == 0 and L3.iteration > 10 and _rel(xsol3, g["xsol"]) < 1e-5
+    assert int(L3.ddm_model().last_stats["precond_used"]) == 3
+    assert L3.iteration < int(g["iterations"])            # the node blocks of the assembled matrix beat the plain CG count
     assert capsys.readouterr().out.count("exceed") == 1
     ddm.pop("preconditioner_type")
     with pytest.raises(ValueError):
@@ -160,6 +162,44 @@ def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeyp
     ddm["preconditioner_type"] = "something"
     with pytest.raises(NotImplementedError):
         LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+
+
+def test_node_block_jacobi_of_the_ddm_operator(golden_dir):
+    """opts.precond = 3 on a DDM handle: CG preconditioned by the inverted 6 x 6 diagonal blocks of sum_c B^T S B (what
+    solve_DDM asks for above the dense limit).  Same solution as plain and Jacobi CG, fewer iterations than Jacobi, the blocks
+    follow a changed Dirichlet set, and the result equals numpy's block-preconditioned operator applied by hand."""
+    g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    preset["geometry"]["number_of_cells"] = dict(x=8, y=4, z=4)
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    L.set_cell_radii(0.034 + 0.03 * L.lattice.cell_pos[:, 0] / 7.0)
+    L.ddm_model()                                         # (fills schur_complements / index tables)
+    cb = L.cell_boundary_nodes()
+    n_nodes = L.max_index_boundary + 1
+    nodes = L.index_boundary[cb]
+    bn = L._boundary_nodes_by_index()
+    fixed = L.fixed_DOF[bn]
+    f = L.applied_force[bn]
+    out = {}
+    for pre in (0, 1, 3):
+        with _capi.HipLattice.ddm(n_nodes, nodes, L.schur_complements, L.cell_schur_index, precond=pre) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=20000)
+            assert st["converged"] == 1 and int(st["precond_used"]) == pre
+            out[pre] = (u, st["iterations"])
+            if pre == 3:
+                # a changed Dirichlet set: the blocks are rebuilt, constrained dofs stay where they are
+                fixed2 = fixed.copy()
+                fixed2[np.argmax(f[:, 2] != 0)] = 1
+                dev.set_bc(fixed2, None, f)
+                dev.assemble()
+                u2, st2 = dev.solve(rtol=1e-10, max_iter=20000)
+                assert st2["converged"] == 1 and np.all(u2[fixed2 != 0] == 0.0)
+                r2 = np.where(fixed2, 0.0, f - dev.spmv(u2))
+                assert np.linalg.norm(r2) <= 2e-10 * np.linalg.norm(np.where(fixed2, 0.0, f))
+    assert _rel(out[3][0], out[0][0]) < 1e-7 and _rel(out[1][0], out[0][0]) < 1e-7
+    assert out[3][1] < 0.9 * out[1][1] < 0.9 * out[0][1]
 
 
 @pytest.mark.parametrize("tag,kw", [
