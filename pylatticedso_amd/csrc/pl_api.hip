@@ -222,7 +222,10 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
           if ((i / 8 + i) % 8 >= k) mask[w] |= 1u << b;
         }
       }
-      PL_HIPC(hipExtStreamCreateWithCUMask(&c->side_cu, 8, mask));
+      if (hipExtStreamCreateWithCUMask(&c->side_cu, 8, mask) != hipSuccess) {   // (no CU masks here: the old order)
+        (void)hipGetLastError();
+        c->side_cu = nullptr;
+      }
     }
   }
 
