@@ -302,9 +302,9 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   // the inverse factor in row ranges behind the chain (second stream), so that only the last range runs after it
   pl::TrtriPhases ph;
   {
-    const int nb = n / pl::kNB;
     const char *e = std::getenv("PL_TRTRI_ROWS");
-    ph.rows = e ? std::atoi(e) : (nb <= 32 ? 4 : nb / 8);
+    ph.rows = e ? std::atoi(e) : 3;     // (measured: 50^3 Octet 1.81 / 1.77 / 1.75 ms with 8 / 4 / 2 block rows per range;
+                                         // configs[2], 96 blocks: 7.82 / 7.52 / 7.47 / 7.38 / 7.34 ms with 12 / 6 / 4 / 3 / 2)
     ph.stream = c->side2;     // (on a CU-masked stream beside the masked BSR fill: 1.75 -> 2.45 ms, configs[2] 7.7 -> 10.5)
     ph.ev_go = c->ev_p0;
     ph.ev_done = c->ev_p1;
