@@ -35,6 +35,10 @@ from .timing import timing
 from .views import LatticeViews
 
 DDM_DENSE_MAX = 16384      # PL_DDM_DENSE_MAX of include/pylattice_hip.h
+# device_model(): lattice sizes from which the handle is asked for the multi-level preconditioner + record palette, and for
+# fp32-stored PCG vectors with fp64 refinement (measured crossovers, DESIGN.md sections 7 / 7a)
+MULTILEVEL_MIN_NODES = 20000
+FP32_VECTORS_MIN_NODES = 2_000_000
 
 _ROOT = Path(__file__).resolve().parents[1]
 PRESET_DIR = _ROOT / "data" / "inputs" / "preset_lattice"
@@ -539,12 +543,12 @@ class LatticeSim(LatticeViews):
         from ._capi import HipLattice
         if self._device is None:
             pen = self.penalized
-            if self.lattice.n_nodes >= 20000:
+            if self.lattice.n_nodes >= MULTILEVEL_MIN_NODES:
                 # large lattices: multi-level preconditioner + record palette (what bench.py measures); small ones
                 # converge in a few hundred Jacobi iterations and have too few nodes per tile for the coarse levels
                 kw.setdefault("precond", 3)
                 kw.setdefault("palette", 1)
-            if self.lattice.n_nodes >= 2_000_000:
+            if self.lattice.n_nodes >= FP32_VECTORS_MIN_NODES:
                 # from ~2 M nodes the PCG vectors no longer fit the caches and stream from HBM: fp32 inner solves with fp64
                 # refinement (rtol still refers to the TRUE fp64 residual).  Measured: 100^3 Octet 284 against 234 M
                 # beams/s, 100^3 BCC 80.8 against 76.3; 50^3 Octet (0.77 M nodes) 220 against 230 - hence the threshold
