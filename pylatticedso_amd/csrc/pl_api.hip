@@ -204,6 +204,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming));
   PL_HIPC(hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
+  PL_HIPC(hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming));
   PL_HIPC(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   {
     // The explicit K (2.5 GB of traffic) is filled BESIDE the latency-bound factorisation chain, on a stream whose CU mask
@@ -894,18 +895,41 @@ int pl_assemble(pl_handle h) {
   // the single-launch inverse factor instead.
   int rc_fill = PL_OK;
   bool fill_queued = false;
-  hipStream_t fill_stream = h->side_cu ? h->side_cu : h->side;
+  // How much of the fill fits beside the chain: the masked stream fills 7 - 9 M blocks per millisecond (50^3 Octet: 6.6 M blocks in
+  // 0.72 ms; 100^3 BCC: 18 M in 2.6 ms), a link of the chain takes ~40 us.  What does not fit (200 x 200 x 50 BCC + Octet:
+  // 138 M blocks against a 3.8-ms chain - all of it on the masked half of the chip cost 7 ms) runs behind the chain on the
+  // plain side stream, on the whole chip, as until round 4.
+  int64_t split = 0;            // slices [0, split) beside the chain
+  if (refresh_bsr && h->side_cu && h->coarse.enabled && h->have_bc) {
+    const double chain_ms = 0.04 * std::max(0, h->coarse.ncp / pl::kNB - 1);
+    const double fit = chain_ms * 8.5e6 / std::max<double>(1.0, (double)h->nblk);
+    split = fit >= 1.0 ? h->n_slices : (int64_t)(fit * (double)h->n_slices);
+    if (split < h->n_slices / 16) split = 0;         // (not worth a launch)
+  }
+  bool part1_queued = false;
   auto queue_fill = [&](int phase) {
     if (!refresh_bsr || fill_queued) return;
-    if (phase == 0 && !h->side_cu) return;      // beside the chain only on the stream that leaves it CUs of its own
-    fill_queued = true;
-    if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(fill_stream, h->ev_chol, 0) != hipSuccess ||
-        hipStreamWaitEvent(fill_stream, h->ev_join, 0) != hipSuccess) {
+    if (phase == 0) {              // head of the chain: the part that fits beside it, on the stream that leaves it CUs
+      if (split <= 0 || part1_queued) return;
+      part1_queued = true;
+      if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(h->side_cu, h->ev_chol, 0) != hipSuccess ||
+          hipStreamWaitEvent(h->side_cu, h->ev_join, 0) != hipSuccess) {
+        rc_fill = fail(PL_ERR_HIP, "pl_assemble: could not order the BSR fill beside the factorisation");
+        return;
+      }
+      rc_fill = launch_bsr_fill(h, h->bsr_with_bc, h->side_cu, 0, split);
+      if (hipEventRecord(h->ev_fill1, h->side_cu) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
+      return;
+    }
+    fill_queued = true;            // behind the chain: the rest (everything without a masked stream), on the whole chip
+    if (hipEventRecord(h->ev_chol, h->stream) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_chol, 0) != hipSuccess) {
       rc_fill = fail(PL_ERR_HIP, "pl_assemble: could not order the BSR fill behind the factorisation");
       return;
     }
-    rc_fill = launch_bsr_fill(h, h->bsr_with_bc, fill_stream);
-    if (hipEventRecord(h->ev_join, fill_stream) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
+    if (!rc_fill) rc_fill = launch_bsr_fill(h, h->bsr_with_bc, h->side, part1_queued ? split : 0, -1);
+    if (part1_queued && hipStreamWaitEvent(h->side, h->ev_fill1, 0) != hipSuccess)
+      rc_fill = fail(PL_ERR_HIP, "pl_assemble: event wait failed");
+    if (hipEventRecord(h->ev_join, h->side) != hipSuccess) rc_fill = fail(PL_ERR_HIP, "pl_assemble: event record failed");
   };
   // (round 3, tried: the fill queued HERE, beside the tile-block front of the assembly instead of behind the chain's last
   // link: assembly 2.27 -> 2.46 ms in two alternating pairs of runs - it slows the front and the first links)

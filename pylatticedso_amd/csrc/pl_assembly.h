@@ -450,13 +450,16 @@ void finish_condensed_classes(pl_context *c) {
   if (c->cls_host_flag) *c->cls_host_flag = 1;
 }
 
-int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st) {
+// slices [slice0, slice1) of the sliced-ELL incidence (slice1 < 0: to the end)
+int launch_bsr_fill(pl_context *c, int with_bc, hipStream_t st, int64_t slice0 = 0, int64_t slice1 = -1) {
   const uint8_t *fb = c->have_bc ? c->fixedbits.p : (const uint8_t *)nullptr;
   const size_t lds = (size_t)(pl::kBsrBlock / pl::kWave) * 64 * pl::kBsrPitch * sizeof(double);   // 38 KB
-  const unsigned gb = grid_for(c->n_slices, pl::kBsrBlock / pl::kWave);
+  if (slice1 < 0 || slice1 > c->n_slices) slice1 = c->n_slices;
+  if (slice0 >= slice1) return PL_OK;
+  const unsigned gb = grid_for(slice1 - slice0, pl::kBsrBlock / pl::kWave);
 #define PL_B(L)                                                                                                  \
   hipLaunchKernelGGL((pl::k_bsr_fill<L>), dim3(gb), dim3(pl::kBsrBlock), lds, st, c->N, c->slice_ptr.p, c->ent.p,  \
-                     c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p, fb, with_bc, c->bsr_vals.p)
+                     c->rec.p, c->bsr_rowptr.p, c->ent_slot.p, c->diag_slot.p, fb, with_bc, c->bsr_vals.p, slice0, slice1)
   switch (c->lpn) { case 1: PL_B(1); break; case 2: PL_B(2); break; case 4: PL_B(4); break; case 8: PL_B(8); break;
                     default: PL_B(16); }
 #undef PL_B

@@ -80,6 +80,7 @@ struct pl_context {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chol = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // row ranges of the inverse factor behind the factorisation chain
+  hipEvent_t ev_fill1 = nullptr;                 // the part of the BSR fill that runs beside the chain
   hipStream_t side2 = nullptr;   // tile blocks of the 12-mode dense level beside its strain rows
   hipStream_t side_cu = nullptr; // bulk fills beside the factorisation chain: a stream that leaves some CUs of every XCD alone
   bool assembled = false, have_bc = false, have_bsr = false;
@@ -218,6 +219,7 @@ struct pl_context {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_chol) (void)hipEventDestroy(ev_chol);
+    if (ev_fill1) (void)hipEventDestroy(ev_fill1);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (ev_t0) (void)hipEventDestroy(ev_t0);

@@ -349,14 +349,15 @@ __global__ __launch_bounds__(kBsrBlock) void k_bsr_fill(int64_t N, const int64_t
                                                      const int32_t *__restrict__ ent_slot,
                                                      const int32_t *__restrict__ diag_slot,
                                                      const uint8_t *__restrict__ fixedbits, int with_bc,
-                                                     double *__restrict__ vals) {
+                                                     double *__restrict__ vals, int64_t slice0 = 0,
+                                                     int64_t slice1 = (int64_t)1 << 62) {
   extern __shared__ double bsr_lds[];                   // [kBsrBlock / kWave][64][kBsrPitch]
   constexpr int kSliceNodes = kWave / LPN;
   const int lane = threadIdx.x & 63, sub = lane / kSliceNodes, wv = threadIdx.x >> 6;
   double *stage = bsr_lds + (size_t)wv * 64 * kBsrPitch;
-  const int64_t slice = (int64_t)blockIdx.x * (kBsrBlock / kWave) + wv;
+  const int64_t slice = slice0 + (int64_t)blockIdx.x * (kBsrBlock / kWave) + wv;     // (a launch covers slices [slice0, slice1))
   const int64_t i = slice * kSliceNodes + (lane & (kSliceNodes - 1));
-  if (slice * kSliceNodes >= N) return;                 // wave-uniform
+  if (slice >= slice1 || slice * kSliceNodes >= N) return;                 // wave-uniform
   const bool live = i < N;
   double Kd[36];
 #pragma unroll
