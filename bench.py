@@ -43,9 +43,9 @@ N_CU, CLOCK_HZ = 256, 2.4e9   # MI355X_MICROARCH.md: 256 CUs in 8 XCDs, 2.4 GHz 
 CONFIGS = {
     1: dict(cells=(50, 50, 50), geom=["Octet"], radii=[0.03], axis=1, scaling="weak", precision=0, tile_modes=0,
             name="BASELINE.json configs[1]"),
-    # precision "auto": what LatticeSim.device_model asks for - fp32-stored PCG vectors with fp64 refinement from 2 M nodes
-    # on a handle (the whole 100^3 BCC lattice on one GPU has 2.03 M; a slab of it on one of several ranks does not)
-    2: dict(cells=(100, 100, 100), geom=["BCC"], radii=[0.05], axis=0, scaling="strong", precision="auto", tile_modes=0,
+    # (fp64 like configs[1]; LatticeSim.device_model would ask for fp32-stored PCG vectors with fp64 refinement at this size -
+    # `--precision 1`: 89 against 76 M beams/s on one GPU)
+    2: dict(cells=(100, 100, 100), geom=["BCC"], radii=[0.05], axis=0, scaling="strong", precision=0, tile_modes=0,
             name="BASELINE.json configs[2]"),
     4: dict(cells=(200, 200, 50), geom=["BCC", "Octet"], radii=[0.04, 0.03], axis=0, scaling="strong", precision=1,
             tile_modes=6, name="BASELINE.json configs[4]"),
@@ -370,9 +370,6 @@ def main():
         cfg["radii"] = [cfg["radii"][0]] * len(cfg["geom"])
     if args.precision < 0:
         args.precision = cfg["precision"]
-        if args.precision == "auto":
-            one_handle = world == 1 and not args.force_dist and args.loopback <= 1
-            args.precision = 1 if one_handle and int(np.prod(cfg["cells"])) >= 10 ** 6 else 0
     if args.tile_modes < 0:
         args.tile_modes = cfg["tile_modes"]
     loop = args.loopback if args.loopback > 1 else 0

@@ -577,7 +577,12 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
   }
   const double thresh = rtol * rtol * bb;
   // an fp32 residual recurrence is trustworthy over ~4 decades: restart from the true residual after that
-  const double inner_drop = kAll32 ? 1e-8 : 0.0;      // on ||r||^2
+  static const double drop_env = [] { const char *e = std::getenv("PL_MP_DROP"); return e ? std::atof(e) : 0.0; }();
+  const double inner_drop = kAll32 ? (drop_env > 0.0 ? drop_env : 1e-8) : 0.0;      // on ||r||^2
+  // (measured, tools/experiments/mp_drop_sweep.sh, iterations at 50^3 Octet / 100^3 Octet / configs[2] / configs[4]:
+  //  fixed 8 decades per stage 141 / 151 / 392 / 324;  equal stages of at most 5: 136 / 146 / 352 / 293,  6: 130 / 144 / 358 / 298,
+  //  7: 130 / 144 / 357 / 298,  8: 130 / 147 / 393 / 354;  fp64: 120 / 137 / 335 / -)
+  static const double stage_max = [] { const char *e = std::getenv("PL_MP_STAGE"); return e ? std::atof(e) : 6.0; }();
   double rr_true = bb;
   // warm start (mode 1, as pcg_solve): the refinement begins at the previous solution of this handle, masked with the
   // CURRENT Dirichlet set - the first inner solve then works on its true residual like every later one
@@ -624,7 +629,15 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
     PL_HIP(hipMemsetAsync(Ap32, 0, n6 * sizeof(float), c->stream));
     rc = pcg_tail_coarse_t<float, RT>(c, c->scal.p + set, c->scal.p, max_iter + 1, p32, (const float *)Ap32, xi, ri);
     if (rc) return rc;
-    const double stop = std::max(thresh, inner_drop * rr_true);
+    // Stages of EQUAL depth: what is left to the threshold (on ||r||^2) is cut into the fewest stages of at most
+    // `stage_max` decades - an fp32 residual recurrence that has dropped further has drifted from the true residual, and the
+    // iterations of a stage that ends below the threshold by accident are wasted (PL_MP_DROP: a fixed drop per stage instead)
+    double stop = std::max(thresh, inner_drop * rr_true);
+    if (kAll32 && !(drop_env > 0.0) && rr_true > thresh) {
+      const double left = std::log10(rr_true / thresh);
+      const int stages = std::max(1, (int)std::ceil(left / stage_max));
+      stop = stages == 1 ? thresh : std::max(thresh, rr_true * std::pow(10.0, -left / stages));
+    }
     bool inner_done = false;
     int j = 0, next = 32;
     double rr_prev = rr_true;

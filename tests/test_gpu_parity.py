@@ -249,13 +249,16 @@ def test_warm_start_of_a_design_loop(geom, condense, precision):
     cold, warm = res[0], res[1]
     for k in range(4):
         assert _rel(warm[k], cold[k]) < 1e-7
-    # the first solve of a handle has nothing to start from (precision = 1 counts whole check intervals of the inner
-    # solves, whose lengths follow the observed decay: a last-bit difference in a reduction can move one)
-    assert warm[4] == cold[4] if precision == 0 else abs(warm[4] - cold[4]) <= 0.2 * cold[4], (warm[4:], cold[4:])
+    # the first solve of a handle has nothing to start from.  (Two handles assemble the dense level with atomics in a
+    # different order: a residual that lands on the threshold can take one iteration more on one of them; precision = 1
+    # counts whole check intervals of the inner solves, whose lengths follow the observed decay.)
+    assert abs(warm[4] - cold[4]) <= (1 if precision == 0 else 0.2 * cold[4]), (warm[4:], cold[4:])
     assert warm[5] <= 2                            # identical system: the previous solution IS the solution
     if precision == 0:
-        assert cold[5] == cold[4]
-    assert warm[6] < 0.9 * cold[6]                 # perturbed radii: fewer iterations
+        assert cold[5] == cold[4]                  # (same handle, same assembled operator: the same count)
+    # perturbed radii: fewer iterations (the fp32 inner solver cuts what is left into stages of equal depth: a start two
+    # decades nearer shortens every stage a little instead of saving a whole one)
+    assert warm[6] < (0.9 if precision == 0 else 1.0) * cold[6], (warm[4:], cold[4:])
     if condense == 1:
         assert cold[4] > 0
 
