@@ -132,8 +132,9 @@ typedef struct {
                           * stream while the interior tiles run, -1 = one launch, then the exchange */
   int32_t coarse_storage; /* storage of the dense level's inverse factor W (the two triangular GEMVs of every iteration read it):
                            * 32 = fp32, 16 = bfloat16 (half the bytes; W16^T W16 is still symmetric positive definite and
-                           * fixed - measured iteration counts unchanged), 0 = automatic: bfloat16 from 3 072 dofs on, where
-                           * the GEMVs are bandwidth-bound (100^3 BCC: 2 x 22 us of a 354-us iteration) */
+                           * fixed - measured iteration counts unchanged), 0 = automatic: bfloat16 from 1 024 dofs on (round 4; from
+                           * 3 072 until then: 100^3 BCC 2 x 22 us of a 354-us iteration; at 1 536 dofs the GEMVs are
+                           * latency-bound and the step gains 1 - 2 %, iteration counts of five lattice types unchanged) */
   int32_t warm_start;    /* design loops (LatticeOpti.objective / gradient call the solver over and over on a slowly changing
                           * lattice, lattice_opti.py:569-570): 1 = pl_solve starts from the previous CONVERGED solution of this
                           * handle instead of from zero (one extra K*x; the stopping test is unchanged: ||r|| <= rtol ||b|| of the

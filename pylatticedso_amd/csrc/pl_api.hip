@@ -424,7 +424,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     if (rc) return bail(fail(PL_ERR_HIP, "pl_create: coarse-space setup failed (" + std::to_string(rc) + ")"));
     if (o->coarse_storage != 0 && o->coarse_storage != 16 && o->coarse_storage != 32)
       return bail(fail(PL_ERR_ARG, "pl_create: coarse_storage must be 0 (automatic), 16 (bfloat16) or 32 (fp32)"));
-    c->coarse.w16 = o->coarse_storage == 16 || (o->coarse_storage == 0 && c->coarse.ncp >= 3072);
+    c->coarse.w16 = o->coarse_storage == 16 || (o->coarse_storage == 0 && c->coarse.ncp >= 1024);
     PL_HIPC(c->sharedbits.alloc(N));
     PL_HIPC(c->maskL.alloc(N));
     PL_HIPC(hipMemset(c->sharedbits.p, 0, N));
@@ -433,7 +433,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
       rc = pl::coarse_setup(c->coarseL, tile_start, tile_brick, grid, xyz.data(), N, maxL, conn, true);
       if (rc) return bail(fail(PL_ERR_HIP, "pl_create: local coarse-space setup failed (" + std::to_string(rc) + ")"));
       c->coarseL.tile_level = false;
-      c->coarseL.w16 = o->coarse_storage == 16 || (o->coarse_storage == 0 && c->coarseL.ncp >= 3072);
+      c->coarseL.w16 = o->coarse_storage == 16 || (o->coarse_storage == 0 && c->coarseL.ncp >= 1024);
     }
   }
 

@@ -906,7 +906,7 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
 
 def test_bfloat16_storage_of_the_dense_level():
     """opts.coarse_storage = 16: the inverse factor of the dense level in bfloat16 (half the bytes of the two triangular
-    GEMVs per iteration; automatic from 3 072 dofs).  Same solution to the solver tolerance - the preconditioner only has
+    GEMVs per iteration; automatic from 1 024 dofs).  Same solution to the solver tolerance - the preconditioner only has
     to be a fixed SPD operator - and no more than a few per cent more iterations than with fp32 storage; BCC with node
     elimination and Octet."""
     for geom, radius, n in (("Octet", 0.03, 14), ("BCC", 0.05, 16)):
