@@ -289,10 +289,17 @@ int pl_get_records(pl_handle h, double *rec);
  * 2 = BSR fill, 3 = one full PCG iteration, 4 = BSR SpMV; on a multi-GPU handle also 5 = the interface all-reduce of
  * one K*p (staging kernels + RCCL) and 6 = the coarse-residual all-reduce - collective calls, every rank must make them.
  * With the multi-level PCG: 7 = K*p on fp32-stored vectors, 8 = one iteration of the fp32 inner PCG (precision 1),
- * 9 = one iteration of the mixed PCG (precision 2). */
+ * 9 = one iteration of the mixed PCG (precision 2); 10 = the operator exactly as the next pl_solve applies it (BOTH passes
+ * under node elimination, fp32-stored operands in the fp32 solver modes) - what a roofline of "K*p" must be priced with. */
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
-/* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr. */
+/* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr - with the
+ * storage widths the next pl_solve uses: strut records and the explicit K are fp64 in every mode, the PCG vectors are 4 bytes
+ * wide where opts.precision stores them in fp32 (precision 1: all of them; 2: p and K*p). */
 int pl_algorithmic_bytes(pl_handle h, double *out3);
+/* Forget what earlier solves taught this handle: the iteration count that places the first look at the residual history of
+ * the next solve (pl_solve) and the previous solution a warm start would begin from.  bench.py uses it
+ * to report the cold value of a loop of identical solves beside the ordinary one. */
+int pl_forget_history(pl_handle h);
 
 /* Test hook for the device dense SPD solver behind the two-level preconditioner (blocked Cholesky + inverse factor):
  * solves A x = b for a host SPD matrix A[n*n] (row-major) on `device`; quad (may be NULL) gets b^T A^-1 b.

@@ -22,7 +22,7 @@ EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version",
            "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
            "pl_update_radii", "pl_set_multiplicity", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
-           "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
+           "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_forget_history", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
            "pl_dist_unique_id", "pl_dist_loopback_id", "pl_dist_abort", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
            "pl_lattice_free", "pl_penalize", "pl_boundary_index"]
 
@@ -90,7 +90,7 @@ def load_library(path: str | None = None):
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
            "pl_reactions": [V, V, V], "pl_sens": [V, V, V, V], "pl_energy": [V, V, V], "pl_node_mod": [V, V, V],
            "pl_schur": [V, V, I32, D, I32, V], "pl_get_records": [V, V], "pl_time_kernel": [V, I32, I32, V],
-           "pl_algorithmic_bytes": [V, V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V], "pl_dist_loopback_id": [V], "pl_dist_abort": [V],
+           "pl_algorithmic_bytes": [V, V], "pl_forget_history": [V], "pl_debug_spd_solve": [I32, I32, V, V, V, V, I32], "pl_dist_unique_id_bytes": [], "pl_dist_unique_id": [V], "pl_dist_loopback_id": [V], "pl_dist_abort": [V],
            "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V],
            "pl_generate_lattice": [I64, V, V, V, I32, I32, V, V, V, V], "pl_lattice_fetch": [V] * 12,
            "pl_lattice_free": [V], "pl_penalize": [I64, V, V, V, D, V, V, V],
@@ -450,6 +450,10 @@ class HipLattice:
         out = (C.c_double * 3)()
         _check(self._lib, self._lib.pl_algorithmic_bytes(self._h, out))
         return {"spmv": out[0], "pcg_iter": out[1], "bsr": out[2]}
+
+    def forget_history(self):
+        """Drop the previous solve's iteration count (first look at the residual history) and the warm-start solution."""
+        _check(self._lib, self._lib.pl_forget_history(self._h))
 
     # -- multi-GPU --------------------------------------------------------------------------------------
     @staticmethod

@@ -212,9 +212,13 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
     // why the fill used to wait for the chain's end: assembly 2.20 -> 1.93 ms at 50^3 Octet with k = 4 or 5, 1.97 with 1,
     // 2.03 with 6).  The CUs are left out on a diagonal - bit i when (i / 8 + i) % 8 < k - which is k CUs of every XCD
     // whether the mask bits run XCD-major or round-robin over the XCDs.  PL_BSR_CUMASK=0: the old order.
+    // The mask (8 words = 256 CUs in 8 XCDs) and the two rates of the split heuristic in pl_assemble were tuned on MI355X:
+    // on a device with another CU count the masked stream is not created and the fill keeps the old order.
     const char *e = std::getenv("PL_BSR_CUMASK");
     const int k = e ? std::atoi(e) : 4;
-    if (k > 0 && k < 8) {
+    hipDeviceProp_t prop;
+    const bool tuned_layout = hipGetDeviceProperties(&prop, o->device) == hipSuccess && prop.multiProcessorCount == 256;
+    if (k > 0 && k < 8 && tuned_layout) {
       uint32_t mask[8];
       for (int w = 0; w < 8; ++w) {
         mask[w] = 0u;
@@ -901,8 +905,11 @@ int pl_assemble(pl_handle h) {
   // plain side stream, on the whole chip, as until round 4.
   int64_t split = 0;            // slices [0, split) beside the chain
   if (refresh_bsr && h->side_cu && h->coarse.enabled && h->have_bc) {
-    const double chain_ms = 0.04 * std::max(0, h->coarse.ncp / pl::kNB - 1);
-    const double fit = chain_ms * 8.5e6 / std::max<double>(1.0, (double)h->nblk);
+    // (PL_CHAIN_LINK_MS / PL_FILL_BLOCKS_PER_MS: the two measured rates, for A/B runs on another box)
+    static const double kChainLinkMs = [] { const char *e = std::getenv("PL_CHAIN_LINK_MS"); return e ? std::atof(e) : 0.04; }();
+    static const double kFillBlocksPerMs = [] { const char *e = std::getenv("PL_FILL_BLOCKS_PER_MS"); return e ? std::atof(e) : 8.5e6; }();
+    const double chain_ms = kChainLinkMs * std::max(0, h->coarse.ncp / pl::kNB - 1);
+    const double fit = chain_ms * kFillBlocksPerMs / std::max<double>(1.0, (double)h->nblk);
     split = fit >= 1.0 ? h->n_slices : (int64_t)(fit * (double)h->n_slices);
     if (split < h->n_slices / 16) split = 0;         // (not worth a launch)
   }
@@ -1225,18 +1232,30 @@ int pl_get_records(pl_handle h, double *rec) {
 
 int pl_algorithmic_bytes(pl_handle h, double *out3) {
   if (!valid(h) || !out3) return fail(PL_ERR_ARG, "pl_algorithmic_bytes: null argument");
+  // SURVEY.md 8(d) with the storage widths the next pl_solve really uses: records are fp64 in every mode (w = 8); the PCG
+  // vectors are fp32-stored in precision = 1 (x, r, p, K*p: wv = 4) and, for p and K*p only, in precision = 2.
   const double w = 8.0, B = (double)h->B, N = (double)h->N;
-  out3[0] = B * (8.0 + 8.0 * w) + N * 6.0 * w * 2.0;        // bytes_spmv
-  out3[1] = out3[0] + 10.0 * (6.0 * N * w);                 //                 bytes_pcg_iter
-  out3[2] = B * (8.0 + 8.0 * w) + (N + 2.0 * B) * (36.0 * w + 4.0);   //      bytes_assembly_bsr
+  const bool mp = h->assembled && mp_applies(h);
+  const double wv = mp ? 4.0 : 8.0;                                    // p and K*p
+  const double wx = (mp && h->opt.precision == 1) ? 4.0 : 8.0;         // x, r (and the other vector passes)
+  out3[0] = B * (8.0 + 8.0 * w) + N * 6.0 * wv * 2.0;       // bytes_spmv
+  out3[1] = out3[0] + 10.0 * (6.0 * N * wx);                // bytes_pcg_iter
+  out3[2] = B * (8.0 + 8.0 * w) + (N + 2.0 * B) * (36.0 * w + 4.0);   // bytes_assembly_bsr (the explicit K is fp64)
+  return PL_OK;
+}
+
+int pl_forget_history(pl_handle h) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_forget_history: null handle");
+  h->last_iterations = 0;       // the next solve looks at the residual history every 32 iterations again
+  h->xprev_valid = false;       // and starts from zero even with opts.warm_start
   return PL_OK;
 }
 
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   if (!valid(h) || !avg_ms || reps <= 0) return fail(PL_ERR_ARG, "pl_time_kernel: bad argument");
-  if (h->opkind != 0 && which != 0 && which != 3) return fail(PL_ERR_STATE, "pl_time_kernel: DDM handles time K*p / PCG only");
+  if (h->opkind != 0 && which != 0 && which != 3 && which != 10) return fail(PL_ERR_STATE, "pl_time_kernel: DDM handles time K*p / PCG only");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_assemble first");
-  if ((which == 0 || which == 3) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
+  if ((which == 0 || which == 3 || which == 10) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
   if ((which == 2 || which == 4) && !h->have_bsr) return fail(PL_ERR_STATE, "pl_time_kernel: needs pl_assemble_bsr");
   PL_HIP(hipSetDevice(h->opt.device));
   const int64_t n6 = h->N * 6;
@@ -1245,7 +1264,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   solver_plan(h);   // which == 3 times the iteration the next pl_solve would run, whatever was called before
   // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if (which >= 7 && which <= 9) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp
+  if ((which >= 7 && which <= 9) || which == 10) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp
     hipLaunchKernelGGL(pl::k_to_float, dim3(grid_for(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->dinv.p,
                        reinterpret_cast<float *>(h->z.p));
     PL_HIP(hipMemsetAsync(h->tmp.p, 0, n6 * sizeof(double), h->stream));
@@ -1285,6 +1304,22 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
           return pcg_tail_coarse_t<float, float>(h, cur, nxt, k, p32, (const float *)Ap32, x32, r32);
         }
         return pcg_tail_coarse_t<float, double>(h, cur, nxt, k, p32, (const float *)Ap32, h->x.p, h->r.p);
+      }
+      case 10: {   // the operator exactly as the next pl_solve applies it: both passes under node elimination, fp32-stored
+                   // operands in the fp32 solver modes
+        if (mp_applies(h)) {
+          float *p32 = reinterpret_cast<float *>(h->z.p), *Ap32 = p32 + n6;
+          if (h->cond_use) {
+            int r0 = launch_spmv_f32(h, p32, p32, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+            return r0 ? r0 : launch_spmv_f32(h, p32, Ap32, true, h->scal.p + pl::S_PAP * pl::kSlots, h->maskC.p, pl::kEndsOthers);
+          }
+          return launch_spmv_f32(h, p32, Ap32, true, h->scal.p + pl::S_PAP * pl::kSlots);
+        }
+        if (h->cond_use) {
+          int r0 = launch_spmv(h, h->p.p, h->p.p, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+          return r0 ? r0 : launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots, h->maskC.p, pl::kEndsOthers);
+        }
+        return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots);
       }
       default: return fail(PL_ERR_ARG, "pl_time_kernel: unknown kernel id");
     }

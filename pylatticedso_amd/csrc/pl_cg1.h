@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
                                                        double *__restrict__ rc, double *__restrict__ sc, int ncp,
                                                        double *__restrict__ hist, int k) {
   __shared__ double red[14][kBlock / kWave];
-  __shared__ double tot[16], ys[16];
+  __shared__ volatile double tot[16], ys[16];
   const int t = blockIdx.x;
   double alpha = 0.0, beta = 0.0;
   if (!INIT) {
@@ -218,13 +218,17 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
   }
   __syncthreads();
   // first wave: tot[0..5] rigid restriction, 6 r.r, 7 r.D^-1 r, 8..13 strain restriction; then the tile level
-  // y_t = B_t^-1 (Z_t^T r), whose share r_t . y_t of r.u joins r.D^-1 r (one wave: its LDS operations are in order)
+  // y_t = B_t^-1 (Z_t^T r), whose share r_t . y_t of r.u joins r.D^-1 r.  The 16 lanes belong to one wave; its cross-lane
+  // exchanges through tot[] / ys[] are volatile accesses ordered by a wavefront-scope release / acquire pair.
   if (threadIdx.x < 16) {
     double *gam_slot = blk_nxt + ncp + kSlots + (blockIdx.x & (kSlots - 1)), *rr_slot = gam_slot + kSlots;
     double v = 0.0;
     if (threadIdx.x < (TM == 12 ? 14 : 8))
       for (int q = 0; q < nw; ++q) v += red[threadIdx.x][q];
     tot[threadIdx.x] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, v);
     if (!Bt_inv) {
       if (threadIdx.x == 7) unsafeAtomicAdd(gam_slot, v);
@@ -238,6 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
         yt[TM * (size_t)t + threadIdx.x] = y;
       }
       ys[threadIdx.x] = threadIdx.x < TM ? y * stv : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (threadIdx.x == 0) {
         double g = tot[7];
 #pragma unroll

@@ -76,6 +76,8 @@ def material_properties(name):
 
 
 class LatticeSim(LatticeViews):
+    _design_mult_note_done = False      # the "strut copies" warning is given once per process
+
     def __init__(self, name_file, mesh_trimmer=None, verbose: int = 0,
                  enable_domain_decomposition_solver: bool = False, data_roots=None, reference_compat=None):
         """Same arguments as the reference (lattice_sim.py:44-47) plus ``data_roots``: extra directories in which the
@@ -282,6 +284,18 @@ class LatticeSim(LatticeViews):
         self._compat_rows = self.reference_compat and self.is_penalized
         if self._compat_rows:
             self._define_strut_multiplicity()
+        # Struts the reference would hold several copies of at DESIGN level (hybrid collision on a strut shared by several
+        # cells, apply_symmetry twins): the default model keeps each once - say so once, and leave a flag on the object
+        dm = lat.extras.get("design_mult")
+        self.differs_from_reference_by_strut_copies = bool(dm is not None and (np.asarray(dm) > 1).any()
+                                                           and not self.reference_compat)
+        if self.differs_from_reference_by_strut_copies and not LatticeSim._design_mult_note_done:
+            LatticeSim._design_mult_note_done = True
+            import warnings
+            warnings.warn(f"{int((np.asarray(dm) > 1).sum())} struts of this lattice exist in several copies in the reference's "
+                          "model (hybrid collision on struts shared by several cells / symmetry twins); the default "
+                          "LatticeSim keeps each strut once.  Pass reference_compat=True (or PYLATTICE_REFERENCE_COMPAT=1) "
+                          "for the reference's own model (INTEGRATION.md).", stacklevel=2)
         R = self.get_number_nodes() if self._compat_rows else lat.n_nodes
         self.fixed_DOF = np.zeros((R, 6), dtype=bool)
         self.displacement_vector = np.zeros((R, 6))
