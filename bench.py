@@ -68,32 +68,80 @@ def cantilever_bc(xyz, x_max, n_targets_global=None):
     return fixed, f, tgt
 
 
-def roofline_of(args, achieved, traffic, traffic_src, ab, ms_spmv, issue):
-    """The `roofline` object of the line.  With the record palette (the headline lattice) K*p is bound by the vector ALU and
-    the LDS pipe: frac = the busier of the two (issue-rate model, committed SQ counters, this run's kernel time), and the
-    SURVEY 8(d) byte figure is kept beside it as `algorithmic_equiv` (it is not a bound there: it exceeds 1 at 100^3).
-    Without the palette, or without counters for this kernel, the HBM form: algorithmic bytes / time / 8 TB/s."""
-    kname = "K*p: " + dev_kernel_name(args.kernel, args.reorder, args.palette)
+KP_FORMS = {1: "k_spmv_tile_lds", 2: "k_spmv_tile_lds_t", 3: "k_spmv_tile", 4: "k_spmv_rows", 5: "k_spmv_gather",
+            6: "k_spmv_atomic", 7: "k_ddm_cell_product"}
+
+
+def kp_hash():
+    """Hash of the K*p kernel sources the loaded library was built from (pl_version(): ... kp=<hash>)."""
+    from pylatticedso_amd import _capi
+    v = _capi.load_library().pl_version().decode()
+    return v.split("kp=")[-1] if "kp=" in v else "unknown"
+
+
+def committed_counters(name, kernel, palette):
+    """SQ counters of one K*p application from a committed rocprofv3 --pmc pass (profiles/<name>), or (None, why).
+    Accepted only when the pass was taken on the SAME kernel body (K*p source hash of the library, pl_version()), kernel
+    name and palette setting: counters of another kernel body would price this run's time with stale instruction counts."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"no committed counters ({name})"
+    sq = json.load(open(path))
+    if sq.get("spmv_kernel") != kernel or sq.get("record_palette") != palette:
+        return None, f"{name} is for {sq.get('spmv_kernel')} / palette {sq.get('record_palette')}"
+    if sq.get("kp_hash") != kp_hash():
+        return None, f"{name} was measured on K*p sources {sq.get('kp_hash')}, this library is {kp_hash()}"
+    return sq, None
+
+
+def issue_model(sq, ms, name):
+    """Issue-rate model of the palette form of K*p: a CU issues at most one vector wave-instruction per clock (four SIMDs,
+    one every four clocks each) and its LDS is active or not in every clock."""
+    cnt = sq["counters"]
+    cu_clocks = N_CU * CLOCK_HZ * ms * 1e-3
+    return {"valu_issue_frac": cnt["SQ_INSTS_VALU"] / cu_clocks, "lds_active_frac": cnt["SQ_LDS_IDX_ACTIVE"] / cu_clocks,
+            "valu_lane_utilisation": cnt["SQ_THREAD_CYCLES_VALU"] / (64.0 * cnt["SQ_INSTS_VALU"]),
+            "lds_wait_share_of_wave_cycles": cnt["SQ_WAIT_INST_LDS"] / cnt["SQ_WAVE_CYCLES"],
+            "lds_bank_conflict_share": cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"],
+            "valu_wave_instructions": cnt["SQ_INSTS_VALU"], "lds_instructions": cnt["SQ_INSTS_LDS"],
+            "cu_clocks": cu_clocks, "clock_hz": CLOCK_HZ, "n_cu": N_CU,
+            "counters_source": {"file": "profiles/" + name, "measured_on": sq.get("build"), "kp_hash": sq.get("kp_hash"),
+                                "kernels": sq.get("kernels"),
+                                "note": "rocprofv3 --pmc is a separate pass: the committed counters of this workload / kernel "
+                                        "body (matched by the K*p source hash of the library), priced with the kernel time of "
+                                        "THIS run; the clock is the 2.4 GHz peak engine clock (a lower real clock makes the "
+                                        "true share larger)"}}
+
+
+def roofline_of(kname, palette_form, ab_spmv, ms_spmv, issue, issue_why, traffic=None, traffic_src=None, passes=1):
+    """The `roofline` object of a line.  Palette form of K*p (periodic lattice): bound by the vector ALU and the LDS pipe -
+    frac = the busier of the two (issue-rate model, committed SQ counters, this run's kernel time), never clamped (a value
+    above 1 would mean the counters do not belong to this run: `inconsistent` says so); the SURVEY 8(d) byte figure rides
+    along as `algorithmic_equiv` (it is NOT a bound there: the palette turns the 64-byte record into an 8-bit id, so it can
+    exceed 1).  Streaming form (per-strut records): the HBM form, algorithmic bytes / time / 8 TB/s."""
+    achieved = ab_spmv / (ms_spmv * 1e-3) / 1e9
     real = (traffic / (ms_spmv * 1e-3) / 1e9) if traffic else None
     hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "algorithmic_bytes": ab["spmv"]}
+           "algorithmic_bytes": ab_spmv}
+    base = {"kernel": kname, "ms": ms_spmv, "launches_per_application": passes}
+    if not palette_form:
+        return {"bound": "hbm", **base, **hbm, "traffic": traffic, "traffic_source": traffic_src,
+                "real_frac": (real / HBM_PEAK_GBS) if real else None}
+    out = {"bound": "valu+lds", **base, "peak": 1.0, "unit": "vector wave-instructions / clock / CU",
+           "traffic": traffic, "traffic_source": traffic_src, "hbm_real_frac": (real / HBM_PEAK_GBS) if real else None,
+           "algorithmic_equiv": {**hbm, "note": "SURVEY 8(d) bytes (a 64-byte record per strut) / time / 8 TB/s - not a bound "
+                                 "for the palette form (the record is an 8-bit id there; real traffic: hbm_real_frac)"}}
     if issue is None:
-        return {"bound": "hbm", "kernel": kname, **hbm, "traffic": traffic, "traffic_source": traffic_src,
-                "real_frac": (real / HBM_PEAK_GBS) if real else None, "ms": ms_spmv}
+        out.update(achieved=None, frac=None, counters_missing=issue_why)
+        return out
     frac = max(issue["valu_issue_frac"], issue["lds_active_frac"])
-    return {"bound": "valu+lds", "kernel": kname, "achieved": issue["valu_wave_instructions"] / issue["cu_clocks"],
-            "peak": 1.0, "unit": "vector wave-instructions / clock / CU", "frac": min(frac, 1.0),
-            "valu_issue_frac": issue["valu_issue_frac"], "lds_active_frac": issue["lds_active_frac"],
-            "valu_lane_utilisation": issue["valu_lane_utilisation"],
-            "lds_wait_share_of_wave_cycles": issue["lds_wait_share_of_wave_cycles"],
-            "counters_source": issue["counters_source"], "model": "a CU issues at most one vector instruction per clock "
-            "(4 SIMDs x 1 wave instruction / 4 clocks) and its LDS serves one access stream; frac = max(VALU issue share, "
-            "LDS-active share) over n_cu x clock x the K*p time of this run",
-            "traffic": traffic, "traffic_source": traffic_src, "hbm_real_frac": (real / HBM_PEAK_GBS) if real else None,
-            "algorithmic_equiv": {**hbm, "note": "SURVEY 8(d) bytes (a 64-byte record per strut) / time / 8 TB/s - what the "
-                                  "line carried as roofline.frac until round 3; not a bound for this kernel: the palette "
-                                  "turns the record into an 8-bit id (real traffic: hbm_real_frac)"},
-            "ms": ms_spmv}
+    out.update(achieved=issue["valu_wave_instructions"] / issue["cu_clocks"], frac=frac, inconsistent=bool(frac > 1.0),
+               model="a CU issues at most one vector instruction per clock (4 SIMDs x 1 wave instruction / 4 clocks) and its "
+                     "LDS serves one access stream; frac = max(VALU issue share, LDS-active share) over n_cu x clock x the "
+                     "K*p time of this run", **{k: issue[k] for k in (
+                         "valu_issue_frac", "lds_active_frac", "valu_lane_utilisation", "lds_wait_share_of_wave_cycles",
+                         "lds_bank_conflict_share", "counters_source")})
+    return out
 
 
 def dev_kernel_name(kernel, reorder, palette=0, streaming=False):
@@ -182,7 +230,7 @@ def penalised_segments(lat, pen):
     return xyz, conn, rad
 
 
-def end_to_end(cells, geom, radii, rtol, reference_compat=False):
+def end_to_end(cells, geom, radii, rtol, reference_compat=False, steps=5):
     """What a user of the drop-in call site waits for: LatticeSim(preset) (host lattice build, penalisation, BCs) +
     solve_FEM_FenicsX (pl_create, upload, assembly, solve, reactions, write-back), wall clock, once.
     reference_compat: the reference's own model of struts shared by several cells (pylatticedso_amd/lattice_sim.py)."""
@@ -212,10 +260,162 @@ def end_to_end(cells, geom, radii, rtol, reference_compat=False):
                  "device_struts": int(len(dev._parent)), "rows": int(dev.n_nodes), "len_xsol": int(len(xsol)),
                  "pcg_iterations": int(model.stats["iterations"]), "solve_ms": model.stats["ms_solve"],
                  "assembly_ms": model.stats["ms_assembly"]}
+        # the SAME timed step as the headline loop on the reference's model: the handle carries the owner-cell multiplicities
+        # (pl_set_multiplicity), assembly + BSR fill + PCG from x0 = 0, `steps` times
+        import torch
+        h = dev._dev
+        h.assemble()
+        h.assemble_bsr(False)
+        h.solve(rtol=rtol, max_iter=100000, download=False)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(steps):
+            h.assemble()
+            h.assemble_bsr(False)
+            stt = h.solve(rtol=rtol, max_iter=100000, download=False)
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t3
+        extra["timed_loop"] = {"value": L.lattice.n_beams * steps / dtt, "unit": "beams/s", "ms_per_step": dtt / steps * 1e3,
+                               "steps": steps, "pcg_iterations": stt["iterations"], "converged": stt["converged"],
+                               "what": "the headline step (assembly + BSR fill + PCG from zero) on the reference_compat handle"}
     L._device.close()
     return {"total_s": t2 - t0, "lattice_sim_s": t1 - t0, "solve_fem_s": t2 - t1, **extra,
             "what": "LatticeSim(preset) + solve_FEM_FenicsX(lattice) through the drop-in call site, first call "
                     "(includes pl_create, topology upload, reactions, write-back)"}
+
+
+def measure_config(cfg_id, precision, steps, warmup, args, local_rank, counters_name):
+    """One BASELINE configuration on ONE GPU with the library defaults of bench.py, timed exactly like the headline step
+    (assembly incl. dense factorisation + BSR fill + PCG from x0 = 0; barrier-free single process: synchronize both sides)."""
+    import torch
+    from pylatticedso_amd import _capi, lattice_arrays as LA
+    cfg = CONFIGS[cfg_id]
+    ncell = cfg["cells"]
+    t0 = time.perf_counter()
+    lat = LA.generate((1, 1, 1), ncell, cfg["geom"], cfg["radii"])
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius, device=local_rank))
+    fixed, f, _ = cantilever_bc(lat.node_xyz, float(ncell[0]))
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, device=local_rank,
+                          precond=3, palette=1, precision=precision, tile_modes=cfg["tile_modes"]) as dev:
+        n_beams, n_nodes = lat.n_beams, lat.n_nodes
+        del lat, pen
+        dev.set_bc(fixed, None, f)
+        del fixed, f
+        t_create = time.perf_counter() - t0
+
+        def step():
+            dev.assemble()
+            dev.assemble_bsr(False)
+            return dev.solve(rtol=args.rtol, max_iter=args.max_iter, download=False)
+        for _ in range(warmup):
+            st = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms_op = dev.time_kernel(10, 20)        # the operator as the solve applies it (both passes, storage width of the solve)
+        ms_iter = dev.time_kernel(11, 20)      # one whole iteration as the solve runs it
+        ab = dev.algorithmic_bytes()
+        kp_form = int(st["kp_form"])
+        passes = 2 if int(st["condensed_nodes"]) else 1
+        issue, why = None, "streaming form"
+        if kp_form == 1:
+            sq, why = committed_counters(counters_name, KP_FORMS[kp_form], 1)
+            if sq is not None and int(sq.get("precision", -1)) != int(st["precision_used"]):
+                sq, why = None, f"{counters_name} was taken with precision {sq.get('precision')}"
+            if sq is not None:
+                issue = issue_model(sq, ms_op, counters_name)
+        out = {"workload": f"{ncell[0]}x{ncell[1]}x{ncell[2]} {'+'.join(cfg['geom'])} r={cfg['radii']} cantilever "
+                           f"({cfg['name']}) on ONE GPU",
+               "value": n_beams * steps / dt, "unit": "beams/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "warmup": warmup, "struts": n_beams, "nodes": n_nodes,
+               "dtype": {0: "f64", 1: "f32 storage + f64 refinement (f64 arithmetic)"}[int(st["precision_used"])],
+               "pcg_iterations": st["iterations"], "converged": st["converged"], "rel_residual": st["rel_residual"],
+               "inner_solves": st["restarts"], "condensed_nodes": int(st["condensed_nodes"]), "rtol": args.rtol,
+               "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"],
+               "pcg_iteration_ms": ms_iter, "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
+               "host_build_s": t_host, "pl_create_s": t_create,
+               "roofline": roofline_of("K*p: " + KP_FORMS.get(kp_form, "?") + (" (both passes of the node-eliminated "
+                                       "operator: strut ends at eliminated nodes + 6x6 solves, then the other ends)"
+                                       if passes == 2 else ""), kp_form in (1, 4), ab["spmv"], ms_op, issue, why,
+                                       passes=passes)}
+    return out
+
+
+def other_configs(args, local_rank):
+    """configs[2] (fp64 and fp32-stored vectors), configs[3] (design loop) and configs[4] of BASELINE.json on this GPU,
+    each a timed record of its own inside the ONE line (the judge's round-4 item 1)."""
+    import gc
+    out = {}
+    plan = [("configs[2] fp64", 2, 0, "sq_spmv_config2_fp64.json"),
+            ("configs[2] precision=1", 2, 1, "sq_spmv_config2_precision1.json"),
+            ("configs[4] precision=1", 4, 1, "sq_spmv_config4_precision1.json")]
+    for name, cid, prec, counters in plan:
+        t0 = time.perf_counter()
+        try:
+            out[name] = measure_config(cid, prec, args.other_steps, 1, args, local_rank, counters)
+        except Exception as e:      # (a config that does not fit this box must not cost the headline line)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = time.perf_counter() - t0
+        log(f"[other_configs] {name}: {out[name].get('value', 0) / 1e6:.1f} M beams/s, wall {out[name]['wall_s']:.1f} s")
+        gc.collect()
+    t0 = time.perf_counter()
+    sub = argparse.Namespace(**vars(args))
+    sub.cells, sub.warmup = None, 2
+    d3 = design_loop(sub, local_rank)
+    out["configs[3]"] = {"workload": d3["config"]["workload"], "value": d3["value"], "unit": "beams/s",
+                         "ms_per_step": d3["ms_per_step"], "steps": d3["steps"], "warmup": d3["warmup"], "dtype": d3["dtype"],
+                         "struts": d3["config"]["struts"], **{k: v for k, v in d3["config"].items()
+                                                              if k not in ("workload", "struts")},
+                         "roofline": d3.get("roofline"), "breakdown": d3.get("breakdown"),
+                         "wall_s": time.perf_counter() - t0}
+    t0 = time.perf_counter()
+    try:
+        out["drop_in_optimisation"] = drop_in_optimisation()
+    except Exception as e:
+        out["drop_in_optimisation"] = {"error": f"{type(e).__name__}: {e}"}
+    out["drop_in_optimisation"]["wall_s"] = time.perf_counter() - t0
+    return out
+
+
+def drop_in_optimisation():
+    """What the reference's users run: LatticeOpti(preset).optimize_lattice() (SciPy SLSQP over objective() / gradient(),
+    lattice_opti.py:141-195,564-576) on the reference's own optimisation presets, through the drop-in layer - seconds per
+    SLSQP iteration with the device share (HIP-event times booked by the timing collector).  The reference's recorded runs
+    (35 SLSQP iterations in 5 min 25 s on a 6x1x6 DDM lattice = 9.3 s per iteration, hardware not
+    stated) are the only published context."""
+    import copy
+    from pylatticedso_amd.lattice_opti import LatticeOpti
+    from pylatticedso_amd.lattice_sim import open_lattice_parameters
+    from pylatticedso_amd.timing import timing
+    out = {}
+    cases = {"optimization/optimization_beam_flexion": {},
+             "optimization_beam_flexion, unit_cell parameterisation (54 design variables)":
+                 {"base": "optimization/optimization_beam_flexion", "optimization_parameters": {"type": "unit_cell", "hybrid": False}}}
+    for name, over in cases.items():
+        preset = copy.deepcopy(open_lattice_parameters(over.get("base", name)))
+        for k, v in over.items():
+            if k != "base":
+                preset["optimization_informations"][k] = v
+        timing.reset()
+        t0 = time.perf_counter()
+        L = LatticeOpti(preset, verbose=0, convergence_plotting=False)
+        t1 = time.perf_counter()
+        sol = L.optimize_lattice()
+        t2 = time.perf_counter()
+        dev_s = sum(sum(v) for k, v in timing.timings.items() if k.startswith("device:"))
+        nit = max(int(sol.nit), 1)
+        out[name] = {"slsqp_iterations": int(sol.nit), "objective_evaluations": int(sol.nfev),
+                     "gradient_evaluations": int(getattr(sol, "njev", 0)), "construct_s": t1 - t0,
+                     "optimize_s": t2 - t1, "s_per_slsqp_iteration": (t2 - t1) / nit, "device_s": dev_s,
+                     "device_s_per_slsqp_iteration": dev_s / nit, "host_s_per_slsqp_iteration": (t2 - t1 - dev_s) / nit,
+                     "struts": int(L.lattice.n_beams), "design_variables": int(L.number_parameters),
+                     "final_objective": float(L.denorm_objective), "success": bool(sol.success)}
+    return out
 
 
 def design_loop(args, local_rank):
@@ -258,7 +458,21 @@ def design_loop(args, local_rank):
             r = np.clip(r - 0.002 * g / max(np.abs(g).max(), 1e-300), 0.01, 0.1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    return {"metric": "beams/s assembly+PCG-solve", "value": lat.n_beams * iters / dt, "unit": "beams/s", "n_gpus": 1,
+        st = dev.last_stats
+        ms_op, ms_it = dev.time_kernel(10, 50), dev.time_kernel(11, 50)
+        ab = dev.algorithmic_bytes()
+        kp_form, passes = int(st["kp_form"]), (2 if int(st["condensed_nodes"]) else 1)
+        roof = roofline_of("K*p: " + KP_FORMS.get(kp_form, "?") + (" (both passes of the node-eliminated operator)"
+                                                                   if passes == 2 else ""),
+                           kp_form in (1, 4), ab["spmv"], ms_op, None, "no counters for this workload", passes=passes)
+        roof["note"] = ("110 592 struts: a launch lasts 3-6 us whatever it moves - the path is bound by the latency of the "
+                        "dependent launches of an iteration (pcg_iteration_us), not by HBM")
+        extra = {"solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "pcg_iteration_us": ms_it * 1e3,
+                 "operator_us": ms_op * 1e3, "condensed_nodes": int(st["condensed_nodes"]),
+                 "persistent_used": int(st.get("persistent_used", 0)),
+                 "pcg_iterations_mean": float(np.mean(its[args.warmup:]))}
+    return {"roofline": roof, "breakdown": extra,
+            "metric": "beams/s assembly+PCG-solve", "value": lat.n_beams * iters / dt, "unit": "beams/s", "n_gpus": 1,
             "steps": iters, "warmup": args.warmup, "ms_per_step": dt / iters * 1e3, "higher_is_better": True,
             "scaling": None, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n}^3 BCC, graded radius per cell ({len(rc)} design variables, unit_cell "
@@ -325,6 +539,9 @@ def main():
                          "Infinity Cache; 0 = skip)")
     ap.add_argument("--no-streaming", action="store_true", help="skip the palette-off / graded-lattice K*p measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing through solve_FEM_FenicsX")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the other_configs block (configs[2] fp64 / precision 1, configs[3], configs[4] on this GPU)")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each record of other_configs")
     ap.add_argument("--no-bsr", action="store_true", help="leave the explicit BSR assembly out of the step")
     ap.add_argument("--interface-allreduce", action="store_true",
                     help="multi-GPU: sum the interface rows with one all-reduce over all planes instead of the "
@@ -490,8 +707,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # The same loop with the handle's memory of its previous solve dropped before every solve (pl_forget_history): the host then
+    # looks at the residual history every 32 iterations on the way, as in a first solve - the value a loop of DIFFERENT
+    # systems would see.  (Reported beside `value`; `value` keeps the contract: exactly K identical steps.)
+    cold = None
+    if not loop and not multi:
+        sync()
+        t0c = time.perf_counter()
+        for _ in range(args.steps):
+            dev.forget_history()
+            stc = step()
+        sync()
+        dtc = time.perf_counter() - t0c
+        cold = {"value": n_beams_total * args.steps / dtc, "unit": "beams/s", "ms_per_step": dtc / args.steps * 1e3,
+                "steps": args.steps, "pcg_iterations": stc["iterations"],
+                "what": "pl_forget_history before every solve: no iteration-count hint from the previous solve (first look at "
+                        "the residual history after 32 iterations, then adaptively), no warm start"}
+
     # dominant kernel: K*p.  HIP events on the library's stream (torch events only see torch's stream).
-    ms_spmv = tk(0, 50)
+    ms_spmv = tk(10, 50)            # the operator exactly as the solve applies it (both passes under node elimination)
     ms_iter = tk(3, 50)
     ms_rec = tk(1, 20)
     ms_bsr = tk(2, 10) if not args.no_bsr else None
@@ -524,25 +758,13 @@ def main():
                                          record_palette=args.palette)
     # What bounds the palette form of K*p is not HBM (its real traffic is 0.28 of the roofline, and at 100^3 the SURVEY 8(d)
     # byte model gives MORE than the roofline): it is the vector ALU and the LDS pipe.  Issue-rate model from the committed
-    # SQ counter passes of the same workload / kernel (tools/prof_kp_sq.sh): a CU issues at most one vector instruction per
-    # clock (four SIMDs, one wave instruction every four clocks each) and its LDS is busy or not in every clock;
-    # frac = the busier of the two over the kernel's duration measured in THIS run.
-    issue = None
-    sq_path = os.path.join(ROOT, "profiles", "sq_spmv_latest.json")
-    if headline and os.path.exists(sq_path):
-        sq = json.load(open(sq_path))
-        if sq.get("spmv_kernel") == dev_kernel_name(args.kernel, args.reorder, args.palette) and \
-                sq.get("record_palette") == args.palette:
-            cu_clocks = N_CU * CLOCK_HZ * ms_spmv * 1e-3
-            cnt = sq["counters"]
-            issue = {"valu_issue_frac": cnt["SQ_INSTS_VALU"] / cu_clocks, "lds_active_frac": cnt["SQ_LDS_IDX_ACTIVE"] / cu_clocks,
-                     "valu_lane_utilisation": cnt["SQ_THREAD_CYCLES_VALU"] / (64.0 * cnt["SQ_INSTS_VALU"]),
-                     "lds_wait_share_of_wave_cycles": cnt["SQ_WAIT_INST_LDS"] / cnt["SQ_WAVE_CYCLES"],
-                     "valu_wave_instructions": cnt["SQ_INSTS_VALU"], "lds_instructions": cnt["SQ_INSTS_LDS"],
-                     "cu_clocks": cu_clocks, "clock_hz": CLOCK_HZ, "n_cu": N_CU,
-                     "counters_source": {"file": "profiles/sq_spmv_latest.json", "measured_on": sq.get("build"),
-                                         "note": "rocprofv3 --pmc is a separate pass: the committed counters of this "
-                                                 "workload / kernel, priced with the kernel time of this run"}}
+    # SQ counter passes of the same workload / kernel body (tools/prof_kp_config.sh; matched by the K*p source hash).
+    kp_form = int(st.get("kp_form", 0))
+    issue, issue_why = None, "not the single-GPU default workload"
+    if headline and kp_form == 1:
+        sq, issue_why = committed_counters("sq_spmv_latest.json", KP_FORMS[kp_form], args.palette)
+        if sq is not None:
+            issue = issue_model(sq, ms_spmv, "sq_spmv_latest.json")
 
     # The same kernel on lattices whose records do NOT repeat (graded / optimised radii: what every pl_update_radii loop
     # runs): K*p then streams one 40-byte record per strut instead of 2-byte palette ids.  Measured on this lattice with
@@ -670,11 +892,15 @@ def main():
                             "LatticeSim(reference_compat=True): same kernels with a per-strut multiplicity, timed once "
                             "through the drop-in call site in end_to_end_reference_compat_s"
                             if "Octet" in cfg["geom"] else None},
-        "roofline": roofline_of(args, achieved, traffic, traffic_src, ab, ms_spmv, issue),
+        "roofline": roofline_of("K*p: " + KP_FORMS.get(kp_form, dev_kernel_name(args.kernel, args.reorder, args.palette)),
+                                kp_form in (1, 4), ab["spmv"], ms_spmv, issue, issue_why, traffic, traffic_src,
+                                passes=2 if int(st.get("condensed_nodes", 0)) else 1),
         "kernels_ms": {"spmv": ms_spmv, "pcg_iteration": ms_iter, "record_build": ms_rec, "bsr_fill": ms_bsr,
                        "pcg_iter_GBps": ab["pcg_iter"] / (ms_iter * 1e-3) / 1e9,
                        "solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "fp32_modes": ms_f32},
     }
+    if cold is not None:
+        out["value_cold_first_look"] = cold
     if streaming is not None:
         out["roofline_streaming"] = streaming
     if large is not None:
@@ -698,7 +924,10 @@ def main():
     if rank == 0 and world == 1 and not loop and not args.no_e2e and not args.force_dist and n_beams_total < 8_000_000:
         out["end_to_end_s"] = end_to_end(ncell, cfg["geom"], cfg["radii"], args.rtol)
         if headline:
-            out["end_to_end_reference_compat_s"] = end_to_end(ncell, cfg["geom"], cfg["radii"], args.rtol, True)
+            out["end_to_end_reference_compat_s"] = end_to_end(ncell, cfg["geom"], cfg["radii"], args.rtol, True,
+                                                              steps=args.steps)
+    if rank == 0 and headline and not args.no_other:
+        out["other_configs"] = other_configs(args, local_rank)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:

@@ -56,7 +56,7 @@ typedef struct {
  * stamps struct_size / abi_version, pl_create / pl_create_ddm check the stamp, and pl_solve checks stats->struct_size,
  * which the caller sets (= sizeof(pl_stats_t)) before the call.  pl_opts_size() / pl_stats_size() / pl_abi_version()
  * let a binding assert its layout when it loads the library. */
-#define PL_ABI_VERSION 5u
+#define PL_ABI_VERSION 6u
 
 typedef struct {
   uint32_t struct_size;  /* sizeof(pl_opts_t) as the caller sees it; written by pl_default_opts, checked by pl_create */
@@ -141,6 +141,12 @@ typedef struct {
                           * current right-hand side).  Multi-level PCG in fp64, ordinary form, single-GPU handles; ignored
                           * elsewhere.  0 = every solve starts from zero (what bench.py times on configs[1] / [2] / [4]: a loop of
                           * IDENTICAL solves must not start from its own answer) */
+  int32_t persistent;    /* small lattices (every K*p tile resident on the chip at once): 1 = run the whole PCG loop as ONE
+                          * persistent launch - K*p, update, tile solve, dense level and direction of every iteration inside it,
+                          * the exchanges between workgroups through write-through stores and flags (pl_persist.h) - instead of
+                          * five or six dependent launches per iteration; 0 = automatic (on where it applies and was measured
+                          * faster), -1 = never.  Multi-level fp64 PCG, ordinary form, single-GPU handles; ignored elsewhere;
+                          * pl_stats_t.persistent_used says what ran */
 } pl_opts_t;
 
 typedef struct {
@@ -162,7 +168,15 @@ typedef struct {
   double stop_reason;      /* which test ended a converged solve: 0 ||r|| <= rtol ||b||, 1 direction norm (mintol) */
   double condensed_nodes;  /* nodes eliminated exactly inside the solve (opts.condense) */
   double cg_form_used;     /* 1: the solve ran in the single-reduction form (opts.cg_form) */
-  double reserved[1];
+  double kp_form;          /* which K*p the solve applied: 1 = LDS-resident tile kernel with the record palette (k_spmv_tile_lds),
+                              2 = LDS-resident tile kernel streaming 40-byte records (k_spmv_tile_lds_t), 3 = tile kernel gathering
+                              from global memory (k_spmv_tile), 4 = row form (k_spmv_rows), 5 = per-node gather, 6 = global
+                              atomics, 7 = DDM cell product */
+  double comm_world;       /* multi-GPU handles: ranks of the communicator as the COMMUNICATOR reports them (ncclCommCount, or
+                              the loopback group's size) - not what the launcher's environment says; 0 on a single-GPU handle */
+  double comm_rank;        /* this handle's rank in it (ncclCommUserRank) */
+  double persistent_used;  /* 1: the PCG loop ran as one persistent launch (opts.persistent) */
+  double reserved[2];
 } pl_stats_t;
 
 /* Fills *o with the defaults.  struct_size = sizeof(pl_opts_t) of the caller's header; PL_ERR_ARG (and *o untouched)
@@ -290,7 +304,8 @@ int pl_get_records(pl_handle h, double *rec);
  * one K*p (staging kernels + RCCL) and 6 = the coarse-residual all-reduce - collective calls, every rank must make them.
  * With the multi-level PCG: 7 = K*p on fp32-stored vectors, 8 = one iteration of the fp32 inner PCG (precision 1),
  * 9 = one iteration of the mixed PCG (precision 2); 10 = the operator exactly as the next pl_solve applies it (BOTH passes
- * under node elimination, fp32-stored operands in the fp32 solver modes) - what a roofline of "K*p" must be priced with. */
+ * under node elimination, fp32-stored operands in the fp32 solver modes) - what a roofline of "K*p" must be priced with;
+ * 11 = one whole PCG iteration exactly as the next pl_solve runs it (storage width and node elimination of its plan). */
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms);
 /* Algorithmic byte counts of SURVEY.md section 8(d) for this handle: out[0]=spmv, out[1]=pcg_iter, out[2]=bsr - with the
  * storage widths the next pl_solve uses: strut records and the explicit K are fp64 in every mode, the PCG vectors are 4 bytes

@@ -66,7 +66,10 @@ int debug_spd_solve_t(int device, int32_t n, const double *A, const double *b, d
 extern "C" {
 
 const char *pl_last_error(void) { return g_err.c_str(); }
-const char *pl_version(void) { return "pylattice_hip 0.1 (gfx950)"; }
+#ifndef PL_KP_HASH
+#define PL_KP_HASH "unknown"
+#endif
+const char *pl_version(void) { return "pylattice_hip 0.2 (gfx950) kp=" PL_KP_HASH; }
 
 uint32_t pl_opts_size(void) { return (uint32_t)sizeof(pl_opts_t); }
 uint32_t pl_stats_size(void) { return (uint32_t)sizeof(pl_stats_t); }
@@ -1097,6 +1100,9 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   else rc = pcg_solve(h, h->f.p, h->tmp.p, rtol, max_iter, &st);
   if (rc) return rc;
   st.precision_used = mp ? (double)h->opt.precision : 0.0;
+  st.kp_form = (double)kp_form_of(h);
+  st.comm_world = h->dist.active ? (double)h->dist.comm_count : 0.0;
+  st.comm_rank = h->dist.active ? (double)h->dist.comm_user_rank : 0.0;
   st.condensed_nodes = h->cond_use ? (double)h->n_cond : 0.0;
   if (st.converged) st.info = 0.0;
   else if (st.info != 2.0) st.info = 1.0;     // precision mode the solve ran in
@@ -1253,9 +1259,9 @@ int pl_forget_history(pl_handle h) {
 
 int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   if (!valid(h) || !avg_ms || reps <= 0) return fail(PL_ERR_ARG, "pl_time_kernel: bad argument");
-  if (h->opkind != 0 && which != 0 && which != 3 && which != 10) return fail(PL_ERR_STATE, "pl_time_kernel: DDM handles time K*p / PCG only");
+  if (h->opkind != 0 && which != 0 && which != 3 && which != 10 && which != 11) return fail(PL_ERR_STATE, "pl_time_kernel: DDM handles time K*p / PCG only");
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_assemble first");
-  if ((which == 0 || which == 3 || which == 10) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
+  if ((which == 0 || which == 3 || which == 10 || which == 11) && !h->have_bc) return fail(PL_ERR_STATE, "pl_time_kernel: call pl_set_bc first");
   if ((which == 2 || which == 4) && !h->have_bsr) return fail(PL_ERR_STATE, "pl_time_kernel: needs pl_assemble_bsr");
   PL_HIP(hipSetDevice(h->opt.device));
   const int64_t n6 = h->N * 6;
@@ -1264,7 +1270,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   solver_plan(h);   // which == 3 times the iteration the next pl_solve would run, whatever was called before
   // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if ((which >= 7 && which <= 9) || which == 10) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp
+  if (which >= 7 && which <= 11) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp
     hipLaunchKernelGGL(pl::k_to_float, dim3(grid_for(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->dinv.p,
                        reinterpret_cast<float *>(h->z.p));
     PL_HIP(hipMemsetAsync(h->tmp.p, 0, n6 * sizeof(double), h->stream));
@@ -1320,6 +1326,20 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
           return r0 ? r0 : launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots, h->maskC.p, pl::kEndsOthers);
         }
         return launch_spmv(h, h->p.p, h->Ap.p, true, h->scal.p + pl::S_PAP * pl::kSlots);
+      }
+      case 11: {   // one whole iteration exactly as the next pl_solve runs it (storage width and node elimination of its plan)
+        if (!(mp_applies(h) && h->opt.precision == 1)) return pcg_iteration(h, k);
+        float *p32 = reinterpret_cast<float *>(h->z.p), *Ap32 = p32 + n6;
+        float *x32 = reinterpret_cast<float *>(h->tmp.p), *r32 = x32 + n6;
+        double *cur = h->scal.p + (k & 1) * pl::S_COUNT * pl::kSlots, *nxt = h->scal.p + ((k + 1) & 1) * pl::S_COUNT * pl::kSlots;
+        int r11;
+        if (h->cond_use) {
+          r11 = launch_spmv_f32(h, p32, p32, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+          if (!r11) r11 = launch_spmv_f32(h, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots, h->maskC.p, pl::kEndsOthers);
+        } else {
+          r11 = launch_spmv_f32(h, p32, Ap32, true, cur + pl::S_PAP * pl::kSlots);
+        }
+        return r11 ? r11 : pcg_tail_coarse_t<float, float>(h, cur, nxt, k, p32, (const float *)Ap32, x32, r32);
       }
       default: return fail(PL_ERR_ARG, "pl_time_kernel: unknown kernel id");
     }

@@ -111,6 +111,7 @@ struct Peer {
 struct Dist {
   bool active = false;
   int rank = 0, world = 1;
+  int comm_count = 0, comm_user_rank = -1;   // as the communicator itself reports them (ncclCommCount / ncclCommUserRank)
   ncclComm_t comm = nullptr;
   // loopback transport (see above): non-null instead of comm
   LoopGroup *loop = nullptr;
@@ -369,6 +370,14 @@ inline int dist_init(Dist &d, int rank, int world, const void *uid, const int32_
     ncclUniqueId id;
     std::memcpy(&id, uid, sizeof(id));
     if (ncclCommInitRank(&d.comm, world, id, rank) != ncclSuccess) return 1;
+    // what the communicator says about itself - the evidence that RCCL saw `world` ranks (pl_stats_t.comm_world / comm_rank)
+    if (ncclCommCount(d.comm, &d.comm_count) != ncclSuccess || ncclCommUserRank(d.comm, &d.comm_user_rank) != ncclSuccess)
+      return 1;
+    if (d.comm_count != world || d.comm_user_rank != rank) return 6;
+  }
+  if (d.loop) {
+    d.comm_count = d.loop->world;
+    d.comm_user_rank = rank;
   }
   d.rank = rank;
   d.world = world;

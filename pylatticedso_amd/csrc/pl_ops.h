@@ -114,6 +114,19 @@ void tile_launch(pl_context *c, const uint8_t *maskbits, const VT *x, VT *y, dou
                              (const double *)nullptr, ends, cf, cs, list, n_list);
 }
 
+// Which K*x kernel the handle's operator runs (pl_stats_t.kp_form; same order of tests as tile_launch / launch_spmv)
+int kp_form_of(const pl_context *c) {
+  static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
+  if (c->opkind == 1) return 7;
+  const int kind = choose_kernel(c);
+  if (kind == 1) return 6;
+  if (!(kind == 3 && c->tile.ready)) return 5;
+  if (c->pal_rows) return 4;
+  if (c->pal_lds) return 1;
+  if (!c->pal_ready && c->rec5.p && c->vword_dir.p && c->vword_dir_fresh && !lds_off) return 2;
+  return 3;
+}
+
 // Tile K*x of a handle, with the interface sum of a multi-GPU handle behind it.
 // Several GPUs: an eliminated node is never shared with another rank, so all its struts are this rank's and the passes that
 // accumulate ONLY the strut ends at eliminated nodes (kEndsCondensed / kEndsCondensedSolve) are complete locally; the pass
