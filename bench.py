@@ -469,7 +469,7 @@ def design_loop(args, local_rank):
                         "dependent launches of an iteration (pcg_iteration_us), not by HBM")
         extra = {"solve_ms_last": st["ms_solve"], "assembly_ms_last": st["ms_assembly"], "pcg_iteration_us": ms_it * 1e3,
                  "operator_us": ms_op * 1e3, "condensed_nodes": int(st["condensed_nodes"]),
-                 "persistent_used": int(st.get("persistent_used", 0)),
+                 "short_iteration_used": int(st.get("short_iteration_used", 0)),
                  "pcg_iterations_mean": float(np.mean(its[args.warmup:]))}
     return {"roofline": roof, "breakdown": extra,
             "metric": "beams/s assembly+PCG-solve", "value": lat.n_beams * iters / dt, "unit": "beams/s", "n_gpus": 1,

@@ -141,12 +141,13 @@ typedef struct {
                           * current right-hand side).  Multi-level PCG in fp64, ordinary form, single-GPU handles; ignored
                           * elsewhere.  0 = every solve starts from zero (what bench.py times on configs[1] / [2] / [4]: a loop of
                           * IDENTICAL solves must not start from its own answer) */
-  int32_t persistent;    /* small lattices (every K*p tile resident on the chip at once): 1 = run the whole PCG loop as ONE
-                          * persistent launch - K*p, update, tile solve, dense level and direction of every iteration inside it,
-                          * the exchanges between workgroups through write-through stores and flags (pl_persist.h) - instead of
-                          * five or six dependent launches per iteration; 0 = automatic (on where it applies and was measured
-                          * faster), -1 = never.  Multi-level fp64 PCG, ordinary form, single-GPU handles; ignored elsewhere;
-                          * pl_stats_t.persistent_used says what ran */
+  int32_t short_iteration; /* small lattices (few K*p tiles: the dense level's explicit inverse can be read once per tile and
+                          * iteration): 1 = the SHORT form of the multi-level PCG iteration (pl_small.h) - the dense level's
+                          * solve and the prolongation fused into one launch that writes z = M^-1 r and r.z, the search
+                          * direction p = z + beta p formed inside the next K*p launch: 3 dependent launches per iteration
+                          * instead of 5 (4 instead of 6 under node elimination); 0 = automatic (on where it applies: fp64,
+                          * ordinary CG form, single-GPU handle, n_tiles x modes x dense dofs small), -1 = never.
+                          * pl_stats_t.short_iteration_used says what ran */
 } pl_opts_t;
 
 typedef struct {
@@ -175,7 +176,7 @@ typedef struct {
   double comm_world;       /* multi-GPU handles: ranks of the communicator as the COMMUNICATOR reports them (ncclCommCount, or
                               the loopback group's size) - not what the launcher's environment says; 0 on a single-GPU handle */
   double comm_rank;        /* this handle's rank in it (ncclCommUserRank) */
-  double persistent_used;  /* 1: the PCG loop ran as one persistent launch (opts.persistent) */
+  double short_iteration_used;  /* 1: the solve ran the short form of the iteration (opts.short_iteration) */
   double reserved[2];
 } pl_stats_t;
 

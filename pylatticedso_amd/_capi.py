@@ -44,7 +44,7 @@ class PlOpts(C.Structure):
                 ("grid_nodes", C.c_int64), ("mintol", C.c_double), ("compact_records", C.c_int32),
                 ("condense", C.c_int32), ("chol_persistent", C.c_int32), ("cg_form", C.c_int32),
                 ("tile_modes", C.c_int32), ("coarse_modes", C.c_int32), ("overlap", C.c_int32),
-                ("coarse_storage", C.c_int32), ("warm_start", C.c_int32), ("persistent", C.c_int32)]
+                ("coarse_storage", C.c_int32), ("warm_start", C.c_int32), ("short_iteration", C.c_int32)]
 
 
 class PlStats(C.Structure):
@@ -54,7 +54,7 @@ class PlStats(C.Structure):
                 ("ms_spmv_avg", C.c_double), ("precond_used", C.c_double), ("restarts", C.c_double),
                 ("precision_used", C.c_double), ("info", C.c_double), ("stop_reason", C.c_double),
                 ("condensed_nodes", C.c_double), ("cg_form_used", C.c_double), ("kp_form", C.c_double),
-                ("comm_world", C.c_double), ("comm_rank", C.c_double), ("persistent_used", C.c_double),
+                ("comm_world", C.c_double), ("comm_rank", C.c_double), ("short_iteration_used", C.c_double),
                 ("reserved", C.c_double * 2)]
 
 
@@ -228,7 +228,7 @@ class HipLattice:
     def __init__(self, node_xyz, beam_conn, beam_radius, seg_len, seg_nsub, young, poisson, kappa=0.9,
                  pen_coef=1.5, device=0, spmv_kernel=0, reorder=1, check_every=0, lanes_per_node=0, tile_nodes=0, precond=1,
                  coarse_max_dofs=0, grid=None, palette=0, local_max_dofs=0, precision=0, compact_records=0, condense=0, chol_persistent=0,
-                 cg_form=0, tile_modes=0, coarse_modes=0, overlap=0, coarse_storage=0, warm_start=0, beam_mult=None, persistent=0):
+                 cg_form=0, tile_modes=0, coarse_modes=0, overlap=0, coarse_storage=0, warm_start=0, beam_mult=None, short_iteration=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.node_xyz = _f64(node_xyz).reshape(-1, 3)
@@ -256,7 +256,7 @@ class HipLattice:
         opts.overlap = overlap
         opts.coarse_storage = coarse_storage
         opts.warm_start = warm_start
-        opts.persistent = persistent
+        opts.short_iteration = short_iteration
         opts.precision = precision            # 0 fp64, 1 fp32 inner PCG + fp64 refinement, 2 fp32 p / K*p only
         if grid is not None:                       # (lo[3], hi[3], n_nodes) of the whole lattice (multi-GPU)
             lo, hi, nn = grid

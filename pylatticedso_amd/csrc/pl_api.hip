@@ -1268,6 +1268,10 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   int rc = ensure_hist(h, reps + 1);
   if (rc) return rc;
   solver_plan(h);   // which == 3 times the iteration the next pl_solve would run, whatever was called before
+  if (h->small_use && (which == 3 || which == 11)) {     // short form: its buffers (zeroed operands: the timing does not care)
+    rc = small_prepare(h);
+    if (rc) return rc;
+  }
   // a well-defined operand: p = dinv (free dofs) -> nonzero everywhere that matters
   PL_HIP(hipMemcpyAsync(h->p.p, h->dinv.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (which >= 7 && which <= 11) {   // the same operand, fp32-stored, in the z buffer; zeroed fp32 x / r in tmp

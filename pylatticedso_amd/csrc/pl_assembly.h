@@ -5,6 +5,21 @@
 
 namespace {
 
+// Short form of the PCG iteration (pl_small.h): what can be decided from the options and the sizes alone (the assembly
+// builds the explicit inverse of the dense level for it).  Every tile reads cm rows of A_c^-1 per iteration: automatic only
+// while that stays below ~16 MB per iteration (BASELINE configs[3]: 128 tiles x 12 x 1 536 x 4 B = 9.4 MB).
+inline bool small_wanted(const pl_context *c) {
+  const pl::Coarse &cs = c->coarse;
+  if (c->opt.short_iteration < 0 || c->opkind != 0 || c->dist.active || c->coarseL.enabled || c->opt.precision != 0 ||
+      c->opt.cg_form == 1 || !cs.enabled || !c->tile.ready || choose_kernel(c) != 3 || c->opt.mintol > 0.0 ||
+      c->opt.restart_every > 0)
+    return false;
+  if (c->opt.short_iteration == 1) return true;
+  static const double auto_mb = [] { const char *e = std::getenv("PL_SHORT_ITERATION_MB"); return e ? std::atof(e) : 16.0; }();
+  return (double)cs.n_tiles * cs.cm * cs.ncp * 4.0 <= auto_mb * 1048576.0;
+}
+
+
 int launch_records(pl_context *c) {
   hipLaunchKernelGGL(pl::k_build_records, dim3(grid_for(c->B)), dim3(pl::kBlock), 0, c->stream, c->B, c->xyz.p,
                      c->conn.p, c->radius.p, c->seg_len.p, c->seg_nsub.p, c->mult.p, c->mat, c->rec.p, c->rec5.p);
@@ -93,6 +108,12 @@ void finish_palette(pl_context *c) {
   // the LDS-resident K*p (pl_tile.h) when the whole palette fits its LDS table; PL_TILE_LDS=0 keeps the gather kernel (A/B)
   static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
   c->pal_lds = c->pal_ready && c->vword.p && c->pal_entries > 0 && c->pal_entries <= pl::kPalDenseMax && !lds_off;
+  // A palette too large for the LDS table would serve the gather kernel (2-byte ids: the faster form on LARGE lattices).  On a
+  // small lattice the launches count, not the bytes: keep the LDS-resident streaming form, which the short iteration
+  // (pl_small.h) needs - the design loops of LatticeOpti are exactly this case (a few hundred distinct radii).
+  if (c->pal_ready && !c->pal_lds && !lds_off && small_wanted(c) && c->rec5.p && c->vword_dir.p && c->tile.n_dir > 0 &&
+      c->tile.n_dir <= pl::kPalDenseMax)
+    c->pal_ready = false;
   // the row kernel (pl_rows.h): opt-in with PL_ROWS=1 (read at every assembly, so that one process can compare both) -
   // measured slower than the tile kernel at 50^3 Octet (51 against 36 us: see the header of pl_rows.h)
   const char *re = std::getenv("PL_ROWS");
@@ -310,6 +331,19 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
     ph.ev_done = c->ev_p1;
   }
   pl::coarse_factor(cs, n, c->stream, after_chol, c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr, ph);
+  cs.ainv_ready = false;
+  if (&cs == &c->coarse && small_wanted(c)) {    // explicit A_c^-1 for the short form of the iteration (pl_small.h)
+    if (!cs.Ainv && hipMalloc((void **)&cs.Ainv, (size_t)n * n * sizeof(float)) != hipSuccess)
+      return fail(PL_ERR_HIP, "pl_assemble: out of device memory for the explicit inverse of the dense level");
+    const long tiles = (long)(n / 32) * (n / 32 + 1) / 2;
+    if (cs.w16)
+      hipLaunchKernelGGL(pl::k_dense_explicit_inverse<pl::bf16_t>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, n,
+                         reinterpret_cast<const pl::bf16_t *>(cs.W), n, cs.Ainv);
+    else
+      hipLaunchKernelGGL(pl::k_dense_explicit_inverse<float>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, n,
+                         (const float *)cs.W, n, cs.Ainv);
+    cs.ainv_ready = true;
+  }
   if (tile_invert_pending) PL_HIP(hipStreamWaitEvent(c->stream, c->ev_t1, 0));
   PL_HIP(hipGetLastError());
   int info[2] = {0, 0};

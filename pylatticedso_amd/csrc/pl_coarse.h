@@ -47,6 +47,8 @@ struct Coarse {
   TBuf<double> cen;
   TBuf<int32_t> cross_idx;      // struts whose ends lie in different aggregates, sorted by (agg(a), agg(b))
   int64_t n_cross = 0;
+  float *Ainv = nullptr;               // explicit A_c^-1 = W^T W in fp32 (short form of the iteration on small lattices, pl_small.h)
+  bool ainv_ready = false;             // ... valid for the current factorisation
   float *W = nullptr, *Wt = nullptr;   // inverse Cholesky factor and its transpose, fp32 storage (pl_dense.h)
   bool w16 = false;                    // ... or bfloat16 in the same buffers (large levels: the GEMVs are bandwidth-bound)
   double *Ac = nullptr, *Lf = nullptr, *Dinv = nullptr, *rc = nullptr, *yc = nullptr, *tv = nullptr;
@@ -76,7 +78,7 @@ struct Coarse {
   ~Coarse() {
     for (void *q : {(void *)Ac, (void *)Lf, (void *)W, (void *)Wt, (void *)Dinv, (void *)rc, (void *)yc, (void *)tv,
                     (void *)info, (void *)Bt_inv, (void *)yt, (void *)fix_count, (void *)dinv32, (void *)bar,
-                    (void *)Bt_raw, (void *)Bt_rawA})
+                    (void *)Bt_raw, (void *)Bt_rawA, (void *)Ainv})
       if (q) (void)hipFree(q);
   }
 };
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const uint8_t *__restrict__ skip_rows /* may be null */,
                                                             int cm = 6 /* modes per aggregate of the dense level */) {
   __shared__ double red[32][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
-  __shared__ double sst[16], sv[16];
+  __shared__ volatile double sst[16], sv[16];      // cross-lane exchange of ONE wave: volatile + wavefront-scope fences
   if constexpr (!MULTI) {
     w = nullptr;
     shared = nullptr;
@@ -1145,7 +1147,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (!Bt_inv) {
         if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
       } else {
-        // the 12 x 12 product through LDS (one wave, its LDS operations are in order): 12 independent broadcast reads
+        // the 12 x 12 product through LDS (one wave; volatile accesses ordered by wavefront-scope fences): 12 independent broadcast reads
         // per lane instead of 24 dependent ds_bpermute
         double st = my_mode >= 0 ? s : 0.0;                // this lane's component of the tile restriction
         if (own_t && threadIdx.x < 6) {                    // several GPUs: the rigid part without the shared nodes
@@ -1153,11 +1155,17 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
           for (int q = 0; q < nw; ++q) st += red[14 + threadIdx.x][q];
         }
         sst[threadIdx.x] = st;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double y = 0.0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) y += sbi[threadIdx.x][j] * sst[j < 6 ? j : j + 2];
         if (my_mode >= 0) yt[12 * (size_t)t + my_mode] = y;
         sv[threadIdx.x] = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (threadIdx.x == 0) {
           double v = 0.0;
 #pragma unroll

@@ -23,6 +23,7 @@
 #include "pl_dist.h"
 #include "pl_coarse.h"
 #include "pl_cg1.h"
+#include "pl_small.h"
 #include "pl_palette.h"
 #include "pl_ddm.h"
 #include "pl_lzone.h"
@@ -191,6 +192,9 @@ struct pl_context {
   DevBuf<double> cls_table;
   int *cls_host_flag = nullptr;       // pinned
   bool cls_ready = false;
+  // short form of the iteration on small lattices (pl_small.h): second p buffer, ring of four scalar sets, two r_c buffers
+  DevBuf<double> p2, small_scal, small_rc;
+  bool small_use = false;    // the running solve takes the short form (solver_plan)
   int last_iterations = 0;   // of the previous converged pcg_solve on this handle (hint for the first convergence check)
   int64_t n_cond = 0;
   bool cond_ready = false;   // K_cc^-1 valid for the current records and mask

@@ -103,8 +103,104 @@ inline void ddm_precondition(pl_context *c, double *dot) {
                        (const double *)c->dd_B.p, (const double *)c->r.p, c->z.p, dot);
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// Short form of the iteration (pl_small.h): K*p with the direction formed in the kernel, update, z-kernel.
+// ----------------------------------------------------------------------------------------------------------
+inline int small_set_size() { return pl::S_COUNT * pl::kSlots; }
+inline double *small_set(pl_context *c, int k) { return c->small_scal.p + (size_t)((k + 4) & 3) * small_set_size(); }
+inline double *small_rc(pl_context *c, int parity) { return c->small_rc.p + (size_t)(parity & 1) * (c->coarse.ncp + 2 * pl::kSlots); }
+
+// buffers of the short form, zeroed: scalar ring, both r_c buffers, p_old of iteration 0
+int small_prepare(pl_context *c) {
+  const int64_t n6 = c->N * 6;
+  const size_t nrc = 2 * (size_t)(c->coarse.ncp + 2 * pl::kSlots);
+  if (!c->p2.p || c->p2.n < (size_t)n6) PL_HIP(c->p2.alloc((size_t)n6));
+  if (!c->small_scal.p) PL_HIP(c->small_scal.alloc(4 * (size_t)small_set_size()));
+  if (!c->small_rc.p || c->small_rc.n < nrc) PL_HIP(c->small_rc.alloc(nrc));
+  PL_HIP(hipMemsetAsync(c->small_scal.p, 0, 4 * (size_t)small_set_size() * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->small_rc.p, 0, nrc * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->p.p, 0, n6 * sizeof(double), c->stream));
+  PL_HIP(hipMemsetAsync(c->p2.p, 0, n6 * sizeof(double), c->stream));
+  return PL_OK;
+}
+
+// update (r -= alpha Ap with the scalars of set k, restriction into the r_c buffer of parity k + 1, tile solve) and the
+// z-kernel of iteration k (k = -1: the pass that prepares iteration 0, alpha = 0; its history entry goes to hist_slot)
+int small_tail(pl_context *c, int k, int hist_slot) {
+  pl::Coarse &cs = c->coarse;
+  const uint8_t *skip = c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+  const double *Bt = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
+  double *rc_new = small_rc(c, k + 1), *rc_old = small_rc(c, k);
+#define PL_SUPD(TM)                                                                                                         \
+  hipLaunchKernelGGL((pl::k_pcg_update_tile<double, double, TM, false, false>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock),  \
+                     0, c->stream, c->tile.tile_start.p, cs.agg_of_tile.p, cs.cen.p, c->xyz.p, (const double *)c->Ap.p,     \
+                     cs.dinv32, (const double *)nullptr, c->r.p, small_set(c, k), rc_new, Bt, cs.yt,                        \
+                     (const int32_t *)nullptr, (const double *)nullptr, (const uint8_t *)nullptr, (double *)nullptr, cs.ncp, \
+                     skip, cs.cm)
+#define PL_SZ(TM)                                                                                                           \
+  hipLaunchKernelGGL((pl::k_small_z<TM>), dim3((unsigned)cs.n_tiles), dim3(cs.vblock), 0, c->stream, c->tile.tile_start.p,  \
+                     cs.agg_of_tile.p, cs.cen.p, c->xyz.p, (const double *)c->r.p, cs.dinv32, c->fixedbits.p, skip,         \
+                     (const float *)cs.Ainv, cs.ncp, cs.cm, (const double *)rc_new, rc_old,                                 \
+                     cs.tile_level ? (const double *)cs.yt : (const double *)nullptr, c->z.p, small_set(c, k + 1),          \
+                     small_set(c, k + 2), c->hist.p, hist_slot)
+  if (tile_modes_now(c) == 12) {
+    PL_SUPD(12);
+    PL_SZ(12);
+  } else {
+    PL_SUPD(6);
+    PL_SZ(6);
+  }
+#undef PL_SUPD
+#undef PL_SZ
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
+// p_k = z_k + beta p_{k-1} is formed by the K*p launch of iteration k and stored in buffer k & 1 (p_{k-1} in the other one)
+inline double *small_p_of(pl_context *c, int k) { return (k & 1) ? c->p2.p : c->p.p; }
+
+int small_iteration(pl_context *c, int k) {
+  pl::Defer df;
+  df.z = c->z.p;
+  df.p_old = small_p_of(c, k - 1);
+  df.p_new = small_p_of(c, k);
+  df.xsol = c->x.p;
+  df.sc_prev = small_set(c, k - 1);
+  df.sc_cur = small_set(c, k);
+  double *dot = small_set(c, k) + pl::S_PAP * pl::kSlots;
+  const bool stream_form = !c->pal_lds;
+  const uint32_t *vw = stream_form ? c->vword_dir.p : c->vword.p;
+  const void *tab = stream_form ? (const void *)c->tile.dir_table.p : (const void *)c->pal_dense.p;
+  const int n_tab = stream_form ? c->tile.n_dir : c->pal_entries;
+  const pl::Rec5 *r5 = stream_form ? reinterpret_cast<const pl::Rec5 *>(c->rec5.p) : (const pl::Rec5 *)nullptr;
+  if (c->cond_use) {
+    const pl::CondSolve cs = cond_solve(c, pl::kEndsCondensedSolve);
+    if (!pl::launch_tile_spmv_lds_defer(c->tile, vw, tab, n_tab, r5, nullptr, df.p_new, nullptr, c->stream,
+                                        pl::kEndsCondensedSolve, c->cflag.p, cs, df))
+      return fail(PL_ERR_STATE, "short iteration: the LDS-resident K*p does not fit this lattice");
+    int rc = launch_spmv(c, df.p_new, c->Ap.p, true, dot, c->maskC.p, pl::kEndsOthers);
+    if (rc) return rc;
+  } else {
+    if (!pl::launch_tile_spmv_lds_defer(c->tile, vw, tab, n_tab, r5, c->fixedbits.p, c->Ap.p, dot, c->stream, pl::kEndsAll,
+                                        nullptr, pl::CondSolve(), df))
+      return fail(PL_ERR_STATE, "short iteration: the LDS-resident K*p does not fit this lattice");
+  }
+  return small_tail(c, k, k);
+}
+
+// x += alpha_{K-1} p_{K-1} after K iterations (the K*p launch of iteration K would have made it)
+int small_finish(pl_context *c, int K) {
+  if (K <= 0) return PL_OK;
+  hipLaunchKernelGGL(pl::k_small_final_x, dim3(grid_stream(c->N * 6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                     c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr,
+                     (const double *)small_p_of(c, K - 1), (const double *)small_set(c, K - 1), c->x.p);
+  PL_HIP(hipGetLastError());
+  return PL_OK;
+}
+
 // One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
 int pcg_iteration(pl_context *c, int k) {
+  if (c->small_use) return small_iteration(c, k);
   const int64_t n6 = c->N * 6;
   const int set = pl::S_COUNT * pl::kSlots;
   double *cur = c->scal.p + (k & 1) * set, *nxt = c->scal.p + ((k + 1) & 1) * set;
@@ -226,7 +322,15 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        (const double *)c->p.p, c->r.p, c->x.p);
     PL_HIP(hipGetLastError());
   }
-  if (c->coarse.ready) {
+  if (c->small_use) {
+    // short form: z0 = M^-1 r0 and r0.z0 through the tail of an iteration "-1" (alpha = 0: set -1 of the ring is zero);
+    // iteration 0 then forms p0 = z0 + 0 p_old in its K*p launch
+    rc = small_prepare(c);
+    if (rc) return rc;
+    PL_HIP(hipMemsetAsync(c->Ap.p, 0, n6 * sizeof(double), c->stream));
+    rc = small_tail(c, -1, max_iter);
+    if (rc) return rc;
+  } else if (c->coarse.ready) {
     // z0 = M^-1 r0 needs the coarse solve: run the tail of an iteration "-1" with p = 0, alpha = 0 (p.Ap = 0) on
     // scalar set 1; its direction kernel leaves p = z0 and rz_old = r0.z0 in set 0, where iteration 0 starts.
     const int set = pl::S_COUNT * pl::kSlots;
@@ -321,6 +425,11 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   }
   if (!st->converged) st->iterations = k;
   c->last_iterations = st->converged ? st->iterations : 0;
+  if (c->small_use) {
+    rc = small_finish(c, k);
+    if (rc) return rc;
+    st->short_iteration_used = 1.0;
+  }
   if (c->cond_use) {   // eliminated nodes: x_c = K_cc^-1 (b_c - (K [x_v ; 0])_c)
     rc = launch_spmv(c, c->x.p, c->tmp2.p, false, nullptr, nullptr, pl::kEndsCondensed);
     if (rc) return rc;
@@ -349,6 +458,10 @@ inline void solver_plan(pl_context *c) {
   const bool mp = mp_applies(c);
   c->cond_use = c->cond_ready && c->coarse.ready && c->opkind == 0 && choose_kernel(c) == 3 && c->tile.ready &&
                 (!mp || c->opt.precision == 1) && c->opt.cg_form != 1;
+  // short form of the iteration (pl_small.h): the fp64 ordinary form on the LDS-resident K*p, explicit A_c^-1 at hand
+  const int form = kp_form_of(c);
+  c->small_use = !mp && small_wanted(c) && c->coarse.ready && !c->coarseL.ready && c->coarse.ainv_ready &&
+                 (form == 1 || form == 2) && c->tile.vis_ready;
 }
 inline bool cg1_applies(const pl_context *c) {
   return c->opt.cg_form == 1 && c->coarse.ready && !c->coarseL.ready && !c->cond_use && c->opt.precision == 0 &&

@@ -732,15 +732,47 @@ __device__ __forceinline__ Rec5 load_rec5(const Rec5 *__restrict__ rec5, int64_t
 //   streamed from rec5 - home visits are consecutive struts (TileDesc::h0), so a wave reads 2.5 KB contiguous; crossing
 //   visits run FIRST in this form (their record and out-of-tile row are requested before the barrier; nothing of them
 //   stays live across the interior visits, which hold the next visit's record in registers instead).
-template <bool MASK, bool DOT, int REC, typename VT, int ENDS = kEndsAll>
-__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(REC == kRecPalette ? PL_LDS_WAVES : PL_LDS_WAVES_STREAM, 8)))
+// DEFER (short form of the PCG iteration, pl_small.h): the operand is not stored yet - the previous launch wrote z = M^-1 r and
+// the slots of r.z, so beta is known only now.  The kernel forms p = z + beta p_old itself: for its own rows while staging them
+// (and stores them to p_new, together with the iterate's update x += alpha_prev p_old, which nobody else would make), for the
+// out-of-tile row of a crossing visit from the two gathered rows.  p_old and p_new are different buffers: another tile may still
+// be reading the old rows.  Scalars: sc_prev / sc_cur = the slotted scalar sets of the previous / this iteration
+// (S_RZ_OLD = r.z, S_PAP = p.Kp): alpha_prev = rz_prev / pap_prev, beta = rz_cur / rz_prev (0 where the denominator is 0:
+// the first iteration starts from p_old = 0).  fp64 only.
+struct Defer {
+  const double *z = nullptr, *p_old = nullptr;
+  double *p_new = nullptr, *xsol = nullptr;
+  const double *sc_prev = nullptr, *sc_cur = nullptr;
+};
+template <bool MASK, bool DOT, int REC, typename VT, int ENDS = kEndsAll, bool DEFER = false>
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(DEFER ? 1 : (REC == kRecPalette ? PL_LDS_WAVES : PL_LDS_WAVES_STREAM), 8)))
 void k_spmv_tile_lds_t(const TileDesc *__restrict__ tdesc, const uint32_t *__restrict__ vword,
                        const int32_t *__restrict__ vother, const double2 *__restrict__ tab, int n_tab,
                      const Rec5 *__restrict__ rec5, const int32_t *__restrict__ foreign_idx,
                      const uint8_t *__restrict__ fixedbits, const VT *__restrict__ x, VT *__restrict__ y,
                      double *__restrict__ dot_out, int stride, const uint8_t *__restrict__ cflag = nullptr,
-                     CondSolve cs = CondSolve(), const int32_t *__restrict__ tile_list = nullptr) {
+                     CondSolve cs = CondSolve(), const int32_t *__restrict__ tile_list = nullptr, Defer df = Defer()) {
+  static_assert(!DEFER || sizeof(VT) == 8, "the deferred direction is an fp64 path");
   constexpr bool kToCondensed = ENDS == kEndsCondensed || ENDS == kEndsCondensedSolve;
+  double d_alpha = 0.0, d_beta = 0.0;
+  if constexpr (DEFER) {
+    const double rz_prev = scalar_read(df.sc_prev, 0 /* S_RZ_OLD */), pap_prev = scalar_read(df.sc_prev, 1 /* S_PAP */);
+    const double rz_cur = scalar_read(df.sc_cur, 0);
+    d_alpha = (pap_prev != 0.0) ? rz_prev / pap_prev : 0.0;
+    d_beta = (rz_prev != 0.0) ? rz_cur / rz_prev : 0.0;
+  }
+  // an out-of-tile row of the operand (crossing visits)
+  auto load_other = [&](int32_t node, V3 &u, V3 &t) {
+    if constexpr (DEFER) {
+      V3 uz, tz, up, tp;
+      load6(reinterpret_cast<const double *>(df.z) + 6 * (int64_t)node, uz, tz);
+      load6(reinterpret_cast<const double *>(df.p_old) + 6 * (int64_t)node, up, tp);
+      u = uz + d_beta * up;
+      t = tz + d_beta * tp;
+    } else {
+      load6(x + 6 * (int64_t)node, u, t);
+    }
+  };
   constexpr bool kStream = REC == kRecCompact;
   constexpr int kSrcChunks = kStream ? 2 : 4, kTabChunks = kStream ? 2 : kPalLdsChunks;
   struct NoRec {};
@@ -795,7 +827,21 @@ void k_spmv_tile_lds_t(const TileDesc *__restrict__ tdesc, const uint32_t *__res
     // (fused first pass of the condensed operator: a condensed node's row is being rewritten by its tile - it counts as
     // zero and is not read)
     double2 val = {0.0, 0.0};
-    if (!(ENDS == kEndsCondensedSolve && f)) val = load_pair(x, 3 * (int64_t)n0 + i);
+    if constexpr (DEFER) {
+      if (!(ENDS == kEndsCondensedSolve && f)) {
+        const int64_t pr = 3 * (int64_t)n0 + i;
+        const double2 zz = load_pair(df.z, pr), po = load_pair(df.p_old, pr);
+        double2 xx = load_pair(df.xsol, pr);
+        val.x = zz.x + d_beta * po.x;
+        val.y = zz.y + d_beta * po.y;
+        xx.x += d_alpha * po.x;
+        xx.y += d_alpha * po.y;
+        store_pair(df.p_new, pr, val);
+        store_pair(df.xsol, pr, xx);
+      }
+    } else {
+      if (!(ENDS == kEndsCondensedSolve && f)) val = load_pair(x, 3 * (int64_t)n0 + i);
+    }
     xs2[i] = val;
   }
   for (int i = threadIdx.x; i < kSrcChunks * n_tab; i += kLdsBlock)
@@ -818,7 +864,7 @@ void k_spmv_tile_lds_t(const TileDesc *__restrict__ tdesc, const uint32_t *__res
   V3 uO = {0, 0, 0}, tO = {0, 0, 0};
   RQ cq = RQ();
   if (clive && cross_take(cw)) {
-    if (!other_zero(cw)) load6(x + 6 * (int64_t)co, uO, tO);
+    if (!other_zero(cw)) load_other(co, uO, tO);
     if constexpr (kStream) cq = load_rec5(rec5, cb);
   }
   PL_STAMP(1);
@@ -908,7 +954,7 @@ void k_spmv_tile_lds_t(const TileDesc *__restrict__ tdesc, const uint32_t *__res
       uO = {0, 0, 0};
       tO = {0, 0, 0};
       if (live_n && cross_take(cw_n)) {
-        if (!other_zero(cw_n)) load6(x + 6 * (int64_t)co_n, uO, tO);
+        if (!other_zero(cw_n)) load_other(co_n, uO, tO);
         if constexpr (kStream) cq = load_rec5(rec5, cb_n);
       }
       kc = kn;
@@ -1227,6 +1273,36 @@ inline bool launch_tile_spmv_lds(const TilePlan &plan, const uint32_t *vword, co
 #undef PL_TE
 #undef PL_TT
 #undef PL_T
+  return true;
+}
+
+// The same launch with the operand formed in the kernel (Defer, short form of the PCG iteration): fp64, all tiles, and only
+// the two passes that start an operator application - ends = kEndsAll (masked, with the dot) or kEndsCondensedSolve.
+inline bool launch_tile_spmv_lds_defer(const TilePlan &plan, const uint32_t *vword, const void *tab, int n_tab,
+                                       const Rec5 *rec5, const uint8_t *fixedbits, double *y, double *dot_dev, hipStream_t s,
+                                       int ends, const uint8_t *cflag, CondSolve cs, const Defer &df) {
+  if (!plan.vis_ready || !vword || n_tab <= 0 || n_tab > kPalDenseMax) return false;
+  if (ends != kEndsAll && ends != kEndsCondensedSolve) return false;
+  const int stride = plan.max_nodes | 1;
+  const size_t lds = (size_t)stride * 96 + (size_t)n_tab * 16 * (rec5 ? 2 : kPalLdsChunks) + (ends != kEndsAll ? (size_t)stride : 0);
+  if (lds > 60 * 1024) return false;
+  const dim3 g((unsigned)plan.n_tiles), blk(kLdsBlock);
+  const double2 *tab2 = static_cast<const double2 *>(tab);
+  const double *x = nullptr;
+#define PL_TD(R)                                                                                                          \
+  do {                                                                                                                    \
+    if (ends == kEndsCondensedSolve)                                                                                      \
+      hipLaunchKernelGGL((k_spmv_tile_lds_t<false, false, R, double, kEndsCondensedSolve, true>), g, blk, lds, s,         \
+                         plan.tdesc.p, vword, plan.vother.p, tab2, n_tab, rec5, plan.foreign_idx.p, fixedbits, x, y,      \
+                         dot_dev, stride, cflag, cs, (const int32_t *)nullptr, df);                                       \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_spmv_tile_lds_t<true, true, R, double, kEndsAll, true>), g, blk, lds, s, plan.tdesc.p, vword, \
+                         plan.vother.p, tab2, n_tab, rec5, plan.foreign_idx.p, fixedbits, x, y, dot_dev, stride, cflag,   \
+                         cs, (const int32_t *)nullptr, df);                                                               \
+  } while (0)
+  if (rec5) PL_TD(kRecCompact);
+  else PL_TD(kRecPalette);
+#undef PL_TD
   return true;
 }
 

@@ -904,6 +904,76 @@ def test_condensed_pcg_matches_oracle(golden_dir, name):
     assert its[1] <= its[-1] + 2          # (a few dozen iterations on these small lattices: +-1 is noise)
 
 
+@pytest.mark.parametrize("name,graded", [("bcc_4x4x4", False), ("bcc_6x3x3_flexion", True), ("bccoctet_2x2x2", False),
+                                         ("octet_3x2x2_size", True), ("bcchybrid1hybrid4_3x2x1_size", False)])
+@pytest.mark.parametrize("condense", [-1, 1])
+@pytest.mark.parametrize("modes", [(6, 6), (12, 6), (12, 12)])
+def test_short_iteration_matches_ordinary_form_and_oracle(golden_dir, name, graded, condense, modes):
+    """opts.short_iteration (pl_small.h): dense level through its explicit inverse inside the z-kernel, search direction formed
+    in the K*p launch - 3 (4) launches per iteration instead of 5 (6).  Same preconditioner and recurrences: the oracle's
+    solution, the ordinary form's iteration count (+-2: A_c^-1 is rounded to fp32 once more), with and without node
+    elimination, palette and streaming records (graded radii), 6- and 12-mode levels, prescribed displacements, a second
+    right-hand side and a warm start on the same handle."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    if graded:
+        rng = np.random.default_rng(5)
+        lat.beam_radius[:] = lat.beam_radius * (1.0 + 0.2 * rng.random(lat.n_beams))
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    f[lat.n_nodes // 2, :3] += [1e-3, -2e-3, 5e-4]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    uref2 = O.solve_dirichlet(K, L.fixed_DOF, 0 * ubar, np.where(L.fixed_DOF, 0.0, 2.0 * f)).reshape(-1, 6)
+    its = {}
+    for short in (-1, 1):
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=condense, palette=1, tile_modes=modes[0],
+                     coarse_modes=modes[1], short_iteration=short, warm_start=1) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st["converged"] == 1 and _rel(u, uref) < 1e-8
+            assert int(st["short_iteration_used"]) == (1 if short == 1 else 0)
+            assert (st["condensed_nodes"] > 0) == (condense > 0)
+            # (graded radii: more than 256 distinct records - on a small lattice the LDS-resident streaming form, which the
+            # short iteration needs, instead of the gather kernel with a large palette)
+            assert int(st["kp_form"]) == ((2 if short == 1 else 3) if graded else 1)
+            res = np.where(L.fixed_DOF, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(res) < 1e-9 * np.linalg.norm(f)
+            dev.set_bc(L.fixed_DOF, None, 2.0 * f)            # second right-hand side, warm start from the first solution
+            u2, st2 = dev.solve(rtol=1e-11, max_iter=20000)
+            assert st2["converged"] == 1 and _rel(u2, uref2) < 1e-8
+            its[short] = (st["iterations"], st2["iterations"])
+    assert abs(its[1][0] - its[-1][0]) <= 2 and abs(its[1][1] - its[-1][1]) <= 3, its
+
+
+def test_short_iteration_is_the_default_on_small_lattices_only():
+    """Automatic choice (opts.short_iteration = 0): on where every tile can read its rows of A_c^-1 once per iteration
+    (n_tiles x modes x dofs x 4 B <= 16 MB), off on the headline-sized lattice; never with the fp32 solver modes or the
+    single-reduction form."""
+    n = 10
+    lat = LA.generate((1, 1, 1), (n, n, n), ["BCC"], [0.05])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == float(n), 2] = -1e-3
+    used, sols = {}, {}
+    for key, kw in {"auto": {}, "off": {"short_iteration": -1}, "precision1": {"precision": 1}, "cg1": {"cg_form": 1}}.items():
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                              palette=1, **kw) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            sols[key], st = dev.solve(rtol=1e-10, max_iter=20000)
+            assert st["converged"] == 1
+            used[key] = (int(st["short_iteration_used"]), st["iterations"])
+    assert used["auto"][0] == 1 and used["off"][0] == 0 and used["precision1"][0] == 0 and used["cg1"][0] == 0
+    assert abs(used["auto"][1] - used["off"][1]) <= 2
+    for key in ("off", "precision1", "cg1"):
+        assert _rel(sols[key], sols["auto"]) < 1e-7
+
+
 def test_bfloat16_storage_of_the_dense_level():
     """opts.coarse_storage = 16: the inverse factor of the dense level in bfloat16 (half the bytes of the two triangular
     GEMVs per iteration; automatic from 1 024 dofs).  Same solution to the solver tolerance - the preconditioner only has
