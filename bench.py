@@ -443,7 +443,7 @@ def design_loop(args, local_rank):
             dev.assemble()
             u, st = dev.solve(rtol=args.rtol, max_iter=args.max_iter)
             C = float((f * u).sum())
-            g = -np.bincount(cell_of, weights=dev.sens(u), minlength=len(r))     # dC/dr_cell = -u^T dK/dr u
+            g = -np.bincount(cell_of, weights=dev.sens(None), minlength=len(r))  # dC/dr_cell = -u^T dK/dr u (u: on the device)
             its.append(st["iterations"])
             return C, g
         for k in range(args.warmup):      # (warm-up on slightly different radii: the first timed solve must not start from

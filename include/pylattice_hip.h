@@ -233,6 +233,14 @@ int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][
  * (full_scale_lattice_simulation.py:39-73,124-153).  Any of ubar/f may be NULL (= zeros). */
 int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const double *f);
 
+/* Periodic constraints for one-cell homogenisation (HomogenizedCell.periodic_boundary_condition,
+ * homogenization_cell.py:210-252: dolfinx_mpc ties all six dofs of opposite corner / edge / face nodes): master[i] = the node
+ * whose dofs node i shares (master[master[i]] == master[i]; i itself for an unconstrained node).  pl_solve then solves
+ * P^T K P v = P^T f, u = P v, as CG on Q K Q with Q the orthogonal projector "average over each group" - f must be periodic
+ * (the caller averages it over the groups) and the Dirichlet flags equal on all members of a group.  Jacobi PCG of a
+ * single-GPU handle (opts.precond = 1).  master = NULL: no constraints. */
+int pl_set_periodic(pl_handle h, const int32_t *master /*[n_nodes] or NULL*/);
+
 /* New radii, same topology/segment geometry (optimisation loop; Cell.change_beam_radius cell.py:896-917). */
 int pl_update_radii(pl_handle h, const double *beam_radius);
 /* Per-strut multiplicity: strut b stands for beam_mult[b] identical struts in parallel between its two nodes (its record,
@@ -275,7 +283,8 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
  * calculate_reaction_force_and_moment_at_position (simulation_base.py:582-645). */
 int pl_reactions(pl_handle h, const double *u, double *R);
 
-/* Per-strut sensitivity s_b = lam_e^T (dK_e/dr_b) u_e at fixed segment geometry (lam == NULL -> lam = u).
+/* Per-strut sensitivity s_b = lam_e^T (dK_e/dr_b) u_e at fixed segment geometry (lam == NULL -> lam = u; u == NULL -> the
+ * solution of the last pl_solve of this handle, which is still on the device: a design loop need not upload it again).
  * Replaces the dS/dr contraction of LatticeOpti.calculate_gradient (lattice_opti.py:746-902) and the dormant
  * Material.compute_gradient (material_definition.py:163-231). */
 int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr);

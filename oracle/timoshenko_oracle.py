@@ -21,8 +21,12 @@ What each function follows (paths relative to the reference repo):
 * ``solve_dirichlet``        src/pyLatticeSim/simulation_base.py:465-514 (assemble with bcs, lifting, point loads, LU)
 * ``reference_cg``           src/pyLatticeSim/conjugate_gradient_solver.py:15-122
 * ``submesh_vertices`` / ``homogenize_submeshed``  src/pyLatticeSim/homogenization_cell.py:112-147,200-252,
-                             309-331,367-376,405-436 (PARITY UNPINNED: no committed homogenisation output in the
-                             reference and dolfinx_mpc is absent; checked against closed forms in tests/ instead)
+                             309-331,367-376,405-436 (no committed homogenisation output in the reference and
+                             dolfinx_mpc is absent; pinned through ``homogenize_from_schur`` instead: the periodic
+                             homogenised matrix follows from the cell's Schur complement on its boundary nodes alone,
+                             and the reference commits those - tests/golden/homogenized_from_schur.npz)
+* ``homogenize_from_schur``  the same procedure on the condensed cell: what the reference's own dolfinx / PETSc Schur
+                             complements (data/outputs/schur_complement/*.npz) say the homogenised matrix is
 * ``condensed_beam`` / ``beam_matrix``  closed-form static condensation of the above (derivation in DESIGN.md §3)
 """
 from __future__ import annotations
@@ -435,3 +439,45 @@ def reference_cg(A, b, M=None, maxiter=100, tol=1e-5, mintol=1e-5, restart_every
         p = z + (rz_new / rz_old) * p
         rz_old = rz_new
     return x, info
+
+
+def homogenize_from_schur(S, xyz_b, lo=(0.0, 0.0, 0.0), size=(1.0, 1.0, 1.0), tol=1e-9):
+    """6x6 homogenised matrix of one periodic cell from its Schur complement S (6 n_b x 6 n_b, node-major
+    [ux, uy, uz, thx, thy, thz]) on the boundary nodes ``xyz_b`` - the procedure of ``homogenize_submeshed``
+    (homogenization_cell.py:200-252, 309-331, 405-436) after the exact elimination of every interior dof: the interior is
+    free and unloaded in the fluctuation problem (the load -K w is the reaction to a displacement field imposed on ALL
+    nodes, so total interior displacements minimise the energy for the given boundary values), hence
+        energy = 1/2 u_B^T S u_B,  u_B = w_B + P v,  P^T S (w_B + P v) = 0,  sigma = sum_b (S u_B)_b[:3] (x) x_b.
+    Periodic groups: boundary nodes with equal coordinates modulo the cell size; the translations of the first group are
+    fixed (the stresses do not depend on which).  Returns (C symmetrised, C_raw)."""
+    S = np.asarray(S, float)
+    xyz_b = np.asarray(xyz_b, float)
+    nb = len(xyz_b)
+    rel = (xyz_b - np.asarray(lo)) / np.asarray(size)
+    wrapped = np.where(np.abs(rel - 1.0) <= tol, 0.0, rel)
+    key = np.round(wrapped / (10 * tol)).astype(np.int64)
+    groups, master = {}, np.arange(nb)
+    for i in range(nb):
+        master[i] = groups.setdefault(tuple(key[i]), i)
+    reps = np.unique(master)
+    slot = np.full(nb, -1)
+    slot[reps] = np.arange(len(reps))
+    P = np.zeros((6 * nb, 6 * len(reps)))
+    for i in range(nb):
+        P[6 * i:6 * i + 6, 6 * slot[master[i]]:6 * slot[master[i]] + 6] = np.eye(6)
+    free = np.setdiff1d(np.arange(P.shape[1]), np.arange(3))
+    Sr = P.T @ S @ P
+    x, y, z = xyz_b.T
+    zero = np.zeros(nb)
+    cols = []
+    for wx, wy, wz in [(x, zero, zero), (zero, y, zero), (zero, zero, z), (y, x, zero), (z, zero, x), (zero, z, y)]:
+        w = np.zeros((nb, 6))
+        w[:, 0], w[:, 1], w[:, 2] = wx, wy, wz
+        b = -(P.T @ (S @ w.ravel()))
+        v = np.zeros(P.shape[1])
+        v[free] = np.linalg.solve(Sr[np.ix_(free, free)], b[free])
+        R = (S @ (w.ravel() + P @ v)).reshape(nb, 6)
+        macro = R[:, :3].T @ xyz_b
+        cols.append([macro[0, 0], macro[1, 1], macro[2, 2], macro[1, 0], macro[2, 0], macro[2, 1]])
+    C_raw = np.array(cols).T
+    return 0.5 * (C_raw + C_raw.T), C_raw

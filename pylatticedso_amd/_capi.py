@@ -19,7 +19,7 @@ PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_N
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
-           "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc",
+           "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc", "pl_set_periodic",
            "pl_update_radii", "pl_set_multiplicity", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_forget_history", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
@@ -85,7 +85,7 @@ def load_library(path: str | None = None):
     lib.pl_lattice_free.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {"pl_default_opts": [V, C.c_uint32], "pl_opts_size": [], "pl_stats_size": [], "pl_abi_version": [], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
-           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V],
+           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V], "pl_set_periodic": [V, V],
            "pl_update_radii": [V, V], "pl_set_multiplicity": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
@@ -417,7 +417,9 @@ class HipLattice:
         return u.reshape(self.n_nodes, 6), self.last_stats
 
     def sens(self, u, lam=None):
-        u = _f64(np.asarray(u).reshape(-1), 6 * self.n_nodes)
+        """Per-strut sensitivities lam^T (dK_e/dr) u (pl_sens).  u = None: the solution of the last solve() of this handle,
+        still on the device (no upload)."""
+        u = None if u is None else _f64(np.asarray(u).reshape(-1), 6 * self.n_nodes)
         lam_a = None if lam is None else _f64(np.asarray(lam).reshape(-1), 6 * self.n_nodes)
         out = np.empty(self.n_beams, np.float64)
         _check(self._lib, self._lib.pl_sens(self._h, _ptr(u), _ptr(lam_a), _ptr(out)))
@@ -452,6 +454,13 @@ class HipLattice:
         out = (C.c_double * 3)()
         _check(self._lib, self._lib.pl_algorithmic_bytes(self._h, out))
         return {"spmv": out[0], "pcg_iter": out[1], "bsr": out[2]}
+
+    def set_periodic(self, master):
+        """Periodic constraints: master[i] = node whose six dofs node i shares (pl_set_periodic); None removes them."""
+        m = None if master is None else np.ascontiguousarray(master, dtype=np.int32)
+        if m is not None and m.size != self.n_nodes:
+            raise ValueError(f"expected {self.n_nodes} entries, got {m.size}")
+        _check(self._lib, self._lib.pl_set_periodic(self._h, _ptr(m)))
 
     def forget_history(self):
         """Drop the previous solve's iteration count (first look at the residual history) and the warm-start solution."""

@@ -572,8 +572,8 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
       q = e;
     }
     c->ddm_n_tiles = (int64_t)tile_S.size();
-    if (m <= 48) {
-      const int KS = m <= 32 ? 8 : 12;
+    if (m <= 192) {
+      const int KS = pl::ddm_mfma_ks(m);
       std::vector<int32_t> gidx((size_t)c->ddm_n_tiles * KS * 64, -1);
       for (int64_t t = 0; t < c->ddm_n_tiles; ++t)
         for (int kk = 0; kk < KS; ++kk)
@@ -767,15 +767,59 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   return PL_OK;
 }
 
+int pl_set_periodic(pl_handle h, const int32_t *master) {
+  if (!valid(h)) return fail(PL_ERR_ARG, "pl_set_periodic: null handle");
+  if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_set_periodic: not available on a DDM handle");
+  h->n_per_groups = 0;
+  if (!master) return PL_OK;
+  if (h->opt.precond != 1 || h->dist.active)
+    return fail(PL_ERR_STATE, "pl_set_periodic: periodic constraints are served by the Jacobi PCG of a single-GPU handle (opts.precond = 1)");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t N = h->N;
+  std::vector<int32_t> inv((size_t)N);
+  for (int64_t i = 0; i < N; ++i) inv[(size_t)h->perm[i]] = (int32_t)i;          // caller node -> device node
+  std::vector<int32_t> cnt((size_t)N, 0);
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t m = master[i];
+    if (m < 0 || m >= N || master[m] != m) return fail(PL_ERR_ARG, "pl_set_periodic: master[i] must name a node that is its own master");
+    cnt[(size_t)m]++;
+  }
+  std::vector<int32_t> ptr(1, 0), nodes, start((size_t)N, -1);
+  for (int64_t m = 0; m < N; ++m)
+    if (cnt[(size_t)m] >= 2) {
+      start[(size_t)m] = (int32_t)ptr.size() - 1;
+      ptr.push_back(ptr.back() + cnt[(size_t)m]);
+    }
+  nodes.resize((size_t)ptr.back());
+  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t g = start[(size_t)master[i]];
+    if (g >= 0) nodes[(size_t)fill[(size_t)g]++] = inv[(size_t)i];
+  }
+  const int64_t ng = (int64_t)ptr.size() - 1;
+  if (ng == 0) return PL_OK;
+  PL_HIP(h->per_ptr.alloc(ptr.size()));
+  PL_HIP(h->per_nodes.alloc(nodes.size()));
+  PL_HIP(hipMemcpy(h->per_ptr.p, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->per_nodes.p, nodes.data(), nodes.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->n_per_groups = ng;
+  return PL_OK;
+}
+
 int pl_update_radii(pl_handle h, const double *beam_radius) {
   if (!valid(h) || !beam_radius) return fail(PL_ERR_ARG, "pl_update_radii: null argument");
   if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_update_radii: not available on a DDM handle");
   for (int64_t b = 0; b < h->B; ++b)
     if (!(beam_radius[b] > 0.0)) return fail(PL_ERR_ARG, "pl_update_radii: non-positive radius");
   PL_HIP(hipSetDevice(h->opt.device));
-  std::vector<double> radius(h->B);
-  for (int64_t b = 0; b < h->B; ++b) radius[b] = beam_radius[h->bperm[b]];
-  PL_HIP(hipMemcpy(h->radius.p, radius.data(), h->B * sizeof(double), hipMemcpyHostToDevice));
+  double *stg = nullptr;
+  int rc = stagingB(h, &stg);
+  if (rc) return rc;
+  pl::parallel_for(h->B, [&](int64_t b0, int64_t b1, unsigned) {
+    for (int64_t b = b0; b < b1; ++b) stg[b] = beam_radius[h->bperm[b]];
+  }, 1 << 16);
+  PL_HIP(hipMemcpyAsync(h->radius.p, stg, h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
   h->assembled = false;
   h->have_bsr = false;
   return PL_OK;
@@ -1089,6 +1133,8 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   // lifting: tmp = K ubar (ubar is zero on free dofs)
   int rc = launch_spmv(h, h->ubar.p, h->tmp.p, false, nullptr);
   if (rc) return rc;
+  if (h->n_per_groups > 0 && (h->coarse.ready || ref_cg(h) || h->dist.active))
+    return fail(PL_ERR_STATE, "pl_solve: periodic constraints (pl_set_periodic) need the plain Jacobi PCG");
   // fp32 solver modes need the multi-level preconditioner on the tile kernel; anything else runs the fp64 PCG
   const bool mp = mp_applies(h);
   solver_plan(h);
@@ -1106,8 +1152,10 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   st.condensed_nodes = h->cond_use ? (double)h->n_cond : 0.0;
   if (st.converged) st.info = 0.0;
   else if (st.info != 2.0) st.info = 1.0;     // precision mode the solve ran in
+  if (!h->usol.p) PL_HIP(h->usol.alloc((size_t)n6));
+  h->usol_valid = false;
   hipLaunchKernelGGL(pl::k_compose_solution, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, h->stream, n6, h->fixed.p,
-                     h->ubar.p, h->x.p, h->tmp2.p);
+                     h->ubar.p, h->x.p, h->usol.p);
   PL_HIP(hipEventRecord(h->ev1, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
   float ms = 0.f;
@@ -1116,8 +1164,9 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   st.ms_assembly = h->ms_assembly;
   st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->dd_blocks ? 3 : h->opt.precond >= 1 ? 1 : 0)
                                    : (h->coarse.ready ? h->opt.precond : 1);
+  h->usol_valid = true;
   if (u) {
-    rc = download6(h, h->tmp2.p, u);
+    rc = download6(h, h->usol.p, u);
     if (rc) return rc;
   }
   h->last = st;
@@ -1129,27 +1178,38 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
 int pl_reactions(pl_handle h, const double *u, double *R) { return spmv_common(h, u, R, false, "pl_reactions"); }
 
 int pl_sens(pl_handle h, const double *u, const double *lam, double *dCdr) {
-  if (!valid(h) || !u || !dCdr) return fail(PL_ERR_ARG, "pl_sens: null argument");
+  if (!valid(h) || !dCdr) return fail(PL_ERR_ARG, "pl_sens: null argument");
   if (h->opkind != 0) return fail(PL_ERR_STATE, "pl_sens: not available on a DDM handle");
+  // u == NULL: the solution of the last pl_solve, still on the device (a design loop evaluates the sensitivities of the
+  // displacement field it has just computed: no 6N-vector upload)
+  if (!u && !(h->usol.p && h->usol_valid)) return fail(PL_ERR_STATE, "pl_sens: u = NULL needs a pl_solve on this handle first");
   PL_HIP(hipSetDevice(h->opt.device));
   std::vector<double> stage;
-  int rc = upload6(h, u, h->tmp.p, stage);
-  if (rc) return rc;
-  const double *lam_dev = h->tmp.p;
+  int rc = PL_OK;
+  const double *u_dev = h->usol.p;
+  if (u) {
+    rc = upload6(h, u, h->tmp.p, stage);
+    if (rc) return rc;
+    u_dev = h->tmp.p;
+  }
+  const double *lam_dev = u_dev;
   if (lam) {
     rc = upload6(h, lam, h->tmp2.p, stage);
     if (rc) return rc;
     lam_dev = h->tmp2.p;
   }
-  DevBuf<double> out;
-  PL_HIP(out.alloc(h->B));
+  if (!h->sens_out.p) PL_HIP(h->sens_out.alloc(h->B));
   hipLaunchKernelGGL(pl::k_sens, dim3(grid_for(h->B)), dim3(pl::kBlock), 0, h->stream, h->B, h->xyz.p, h->conn.p,
-                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mult.p, h->mat, h->tmp.p, lam_dev, out.p);
+                     h->radius.p, h->seg_len.p, h->seg_nsub.p, h->mult.p, h->mat, u_dev, lam_dev, h->sens_out.p);
   PL_HIP(hipGetLastError());
-  std::vector<double> tmp(h->B);
-  PL_HIP(hipMemcpyAsync(tmp.data(), out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  double *stg = nullptr;
+  rc = stagingB(h, &stg);
+  if (rc) return rc;
+  PL_HIP(hipMemcpyAsync(stg, h->sens_out.p, h->B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
-  for (int64_t b = 0; b < h->B; ++b) dCdr[h->bperm[b]] = tmp[b];
+  pl::parallel_for(h->B, [&](int64_t b0, int64_t b1, unsigned) {
+    for (int64_t b = b0; b < b1; ++b) dCdr[h->bperm[b]] = stg[b];
+  }, 1 << 16);
   return PL_OK;
 }
 

@@ -216,6 +216,14 @@ struct pl_context {
   double ms_assembly = 0.0;
   double *pin6 = nullptr;      // pinned staging buffer of the vector transfers (pl_context.h: staging)
   size_t pin6_n = 0;
+  // periodic constraints (pl_set_periodic; one-cell homogenisation): groups of nodes that share their six dofs.  The Jacobi
+  // PCG then runs on Q K Q with Q = the orthogonal projector "average over every group" (pl_solver.h)
+  DevBuf<int32_t> per_ptr, per_nodes;
+  int64_t n_per_groups = 0;
+  double *pinB = nullptr;      // pinned staging buffer of the per-strut transfers (radii, sensitivities)
+  DevBuf<double> sens_out;     // [B] per-strut sensitivities of pl_sens (kept: a design loop calls it every iteration)
+  DevBuf<double> usol;         // composed solution of the last pl_solve (pl_sens with u = NULL reads it)
+  bool usol_valid = false;
 
   ~pl_context() {
     if (ev0) (void)hipEventDestroy(ev0);
@@ -229,6 +237,7 @@ struct pl_context {
     if (ev_t0) (void)hipEventDestroy(ev_t0);
     if (ev_t1) (void)hipEventDestroy(ev_t1);
     if (pin6) (void)hipHostFree(pin6);
+    if (pinB) (void)hipHostFree(pinB);
     if (ev_ov_a) (void)hipEventDestroy(ev_ov_a);
     if (ev_ov_x) (void)hipEventDestroy(ev_ov_x);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -258,6 +267,16 @@ int staging(pl_context *c, double **out) {
     c->pin6_n = n6;
   }
   *out = c->pin6;
+  return PL_OK;
+}
+
+int stagingB(pl_context *c, double **out) {
+  if (!c->pinB) {
+    void *p = nullptr;
+    PL_HIP(hipHostMalloc(&p, (size_t)std::max<int64_t>(c->B, 1) * sizeof(double), hipHostMallocDefault));
+    c->pinB = static_cast<double *>(p);
+  }
+  *out = c->pinB;
   return PL_OK;
 }
 

@@ -200,23 +200,34 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_reg(int64_t C, int 
 // Operand / result layout as in pl_dense.h.  The reference's skip rule (sum of a cell's displacements == 0 -> zero
 // reactions, lattice_sim.py:1239) is kept: the four lanes of a cell add their partial sums.
 typedef double v4f64_ddm __attribute__((ext_vector_type(4)));
+// K steps (of 4) of the matrix-pipe cell product for a cell with m dofs: one of the instantiated sizes (pl_ops.h dispatch)
+inline int ddm_mfma_ks(int m) { return m <= 32 ? 8 : m <= 48 ? 12 : m <= 72 ? 18 : m <= 96 ? 24 : m <= 120 ? 30 : m <= 156 ? 39 : 48; }
 #ifndef PL_DDM_TPW
 #define PL_DDM_TPW 1
 #endif
 constexpr int kDdmTilesPerWave = PL_DDM_TPW;
-template <int KS, int NB16>
+// Larger cells (round 5: Hybrid1, 12 boundary nodes, m = 72; the reference's BCC + Hybrid1 hybrids, 26 nodes, m = 156): S^T no
+// longer fits one wave's registers, so a tile's OUTPUT columns are cut into `slices` groups of NBW 16-column blocks and every
+// slice is one wave (it holds S^T[all k][its columns]: KS x NBW doubles, gathers the tile's displacements itself - the other
+// slices' gathers of the same entries hit the caches).  The K loop runs in chunks of KC instructions so that only KC gathered
+// operands are live at a time; the skip rule needs the sum over ALL of a cell's displacements, which is complete only at the
+// end - the product is formed regardless and dropped there.
+template <int KS, int NBW, int KC = (KS < 12 ? KS : (KS % 13 == 0 ? 13 : (KS % 12 == 0 ? 12 : (KS % 6 == 0 ? 6 : KS))))>
 __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tiles, int nb, const int32_t *__restrict__ tiles,
                                                                   const int32_t *__restrict__ tile_S,
                                                                   const int32_t *__restrict__ gidx /* [n_tiles][KS][64] */,
                                                                   const double *__restrict__ St,
                                                                   const double *__restrict__ x,
-                                                                  double *__restrict__ stage) {
+                                                                  double *__restrict__ stage, int slices = 1) {
+  static_assert(KS % KC == 0, "the K loop runs in whole chunks");
   const int m = 6 * nb;
   const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
   const int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-  const int64_t t0 = w * kDdmTilesPerWave;
+  const int64_t wt = w / slices;
+  const int cb0 = (int)(w - wt * slices) * NBW;               // first 16-column block of this wave's slice
+  const int64_t t0 = wt * kDdmTilesPerWave;
   if (t0 >= n_tiles) return;
-  double Bs[KS][NB16];
+  double Bs[KS][NBW];
   int loaded = -1;
   for (int q = 0; q < kDdmTilesPerWave; ++q) {
     const int64_t t = t0 + q;
@@ -227,8 +238,8 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tile
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-        for (int b = 0; b < NB16; ++b) {
-          const int k = 4 * kk + kq, j = 16 * b + i;
+        for (int b = 0; b < NBW; ++b) {
+          const int k = 4 * kk + kq, j = 16 * (cb0 + b) + i;
           Bs[kk][b] = (k < m && j < m) ? S[(size_t)k * m + j] : 0.0;        // St[k][j] = S[j][k]
         }
       // (tried: S through LDS once per workgroup, B operands from there: 15.0 against 12.8 us - the barrier and the
@@ -236,27 +247,31 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tile
       loaded = id;
     }
     const int32_t cell = tiles[16 * t + i];
-    // (the position in x of every operand entry was resolved on the host: one hop, the index loads coalesced)
-    int32_t gi[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) gi[kk] = gidx[((int64_t)t * KS + kk) * 64 + lane];
-    double Au[KS];
     double part = 0.0;
+    v4f64_ddm acc[NBW];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      Au[kk] = gi[kk] >= 0 ? x[gi[kk]] : 0.0;
-      part += Au[kk];
+    for (int b = 0; b < NBW; ++b) acc[b] = v4f64_ddm{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc < KS; kc += KC) {
+      // (the position in x of every operand entry was resolved on the host: one hop, the index loads coalesced)
+      int32_t gi[KC];
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) gi[kk] = gidx[((int64_t)t * KS + kc + kk) * 64 + lane];
+      double Au[KC];
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        Au[kk] = gi[kk] >= 0 ? x[gi[kk]] : 0.0;
+        part += Au[kk];
+      }
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[kk], Bs[kc + kk][b], acc[b], 0, 0, 0);
     }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
     const int skip = (part == 0.0) ? 1 : 0;                     // of cell i, in all four lanes that hold it
-    v4f64_ddm acc[NB16];
-#pragma unroll
-    for (int b = 0; b < NB16; ++b) acc[b] = v4f64_ddm{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-      for (int b = 0; b < NB16; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[kk], Bs[kk][b], acc[b], 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = kq + 4 * r;                               // D row = cell `row` of the tile
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tile
       const int srow = __shfl(skip, row);
       if (crow < 0) continue;
 #pragma unroll
-      for (int b = 0; b < NB16; ++b) {
-        const int j = 16 * b + i;
+      for (int b = 0; b < NBW; ++b) {
+        const int j = 16 * (cb0 + b) + i;
         if (j < m) stage[(int64_t)crow * m + j] = srow ? 0.0 : acc[b][r];
       }
     }

@@ -728,4 +728,19 @@ __global__ __launch_bounds__(kBlock) void k_energy(int64_t B, const int32_t *__r
   if (threadIdx.x == 0) unsafeAtomicAdd(out + (blockIdx.x & (kSlots - 1)), t);
 }
 
+// Periodic constraints (pl_set_periodic): v <- Q v, the average over every group of nodes that share their dofs, written
+// back to all members.  One thread per (group, component).
+__global__ __launch_bounds__(kBlock) void k_periodic_average(int64_t n_groups, const int32_t *__restrict__ gptr,
+                                                             const int32_t *__restrict__ gnodes, double *__restrict__ v) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 6 * n_groups) return;
+  const int64_t g = t / 6;
+  const int k = (int)(t - 6 * g);
+  const int32_t b = gptr[g], e = gptr[g + 1];
+  double s = 0.0;
+  for (int32_t q = b; q < e; ++q) s += v[6 * (int64_t)gnodes[q] + k];
+  s /= (double)(e - b);
+  for (int32_t q = b; q < e; ++q) v[6 * (int64_t)gnodes[q] + k] = s;
+}
+
 }  // namespace pl

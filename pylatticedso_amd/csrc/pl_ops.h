@@ -168,15 +168,33 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
     const int m = 6 * c->ddm_nb;
     const size_t lds = ((size_t)m * m + (size_t)(pl::kBlock / pl::kWave) * m) * sizeof(double);
     const unsigned gw = grid_for((c->ddm_cells + pl::kDdmWaveChunk - 1) / pl::kDdmWaveChunk, pl::kBlock / pl::kWave);
-    static const bool mfma_off = [] { const char *e = std::getenv("PL_DDM_MFMA"); return e && e[0] == '0'; }();
-    const unsigned gm = grid_for((c->ddm_n_tiles + pl::kDdmTilesPerWave - 1) / pl::kDdmTilesPerWave, pl::kBlock / pl::kWave);
-#define PL_DM(KS, NB16)                                                                                                 \
-  hipLaunchKernelGGL((pl::k_ddm_cell_product_mfma<KS, NB16>), dim3(gm), dim3(pl::kBlock), 0, c->stream, c->ddm_n_tiles, \
-                     c->ddm_nb, c->ddm_tiles.p, c->ddm_tile_S.p, c->ddm_tile_gidx.p, c->ddm_St.p, x, c->ddm_stage.p)
-    if (!mfma_off && c->ddm_n_tiles > 0 && c->ddm_tile_gidx.p && m <= 32)
+    // (read at every launch, so that one process can compare the matrix-pipe kernels with the generic ones: A/B runs, tests)
+    const char *mfma_env = std::getenv("PL_DDM_MFMA");
+    const bool mfma_off = mfma_env && mfma_env[0] == '0';
+    const int64_t tile_waves = (c->ddm_n_tiles + pl::kDdmTilesPerWave - 1) / pl::kDdmTilesPerWave;
+    // (KS, NBW): K steps and 16-column blocks per wave; a tile's ceil(m / 16) column blocks are dealt over `slices` waves
+#define PL_DM(KS, NBW)                                                                                                   \
+  do {                                                                                                                   \
+    const int slices = ((m + 15) / 16 + (NBW) - 1) / (NBW);                                                              \
+    hipLaunchKernelGGL((pl::k_ddm_cell_product_mfma<KS, NBW>), dim3(grid_for(tile_waves * slices, pl::kBlock / pl::kWave)), \
+                       dim3(pl::kBlock), 0, c->stream, c->ddm_n_tiles, c->ddm_nb, c->ddm_tiles.p, c->ddm_tile_S.p,        \
+                       c->ddm_tile_gidx.p, c->ddm_St.p, x, c->ddm_stage.p, slices);                                       \
+  } while (0)
+    const bool mfma_ok = !mfma_off && c->ddm_n_tiles > 0 && c->ddm_tile_gidx.p;
+    if (mfma_ok && m <= 32)
       PL_DM(8, 2);
-    else if (!mfma_off && c->ddm_n_tiles > 0 && c->ddm_tile_gidx.p && m <= 48)
+    else if (mfma_ok && m <= 48)
       PL_DM(12, 3);
+    else if (mfma_ok && m <= 72)       // Hybrid1 (12 boundary nodes): two slices of 3 column blocks
+      PL_DM(18, 3);
+    else if (mfma_ok && m <= 96)
+      PL_DM(24, 2);
+    else if (mfma_ok && m <= 120)
+      PL_DM(30, 2);
+    else if (mfma_ok && m <= 156)      // the reference's BCC + Hybrid1 (+ Hybrid4) hybrids: 26 boundary nodes, five slices
+      PL_DM(39, 2);
+    else if (mfma_ok && m <= 192)
+      PL_DM(48, 1);
     else if (m <= 48)
       hipLaunchKernelGGL(pl::k_ddm_cell_product_reg<48>, dim3(gw), dim3(pl::kBlock), 0, c->stream, c->ddm_cells,
                          c->ddm_nb, c->ddm_order.p, c->ddm_cell_nodes.p, c->ddm_cell_S.p, c->ddm_St.p, x, c->ddm_stage.p);

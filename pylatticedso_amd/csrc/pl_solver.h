@@ -198,6 +198,13 @@ int small_finish(pl_context *c, int K) {
   return PL_OK;
 }
 
+// v <- Q v (periodic constraints, pl_set_periodic)
+inline void periodic_average(pl_context *c, double *v) {
+  if (c->n_per_groups > 0)
+    hipLaunchKernelGGL(pl::k_periodic_average, dim3(grid_for(6 * c->n_per_groups)), dim3(pl::kBlock), 0, c->stream,
+                       c->n_per_groups, c->per_ptr.p, c->per_nodes.p, v);
+}
+
 // One PCG iteration (k = iteration index: selects the scalar set by parity and the residual-history slot).
 int pcg_iteration(pl_context *c, int k) {
   if (c->small_use) return small_iteration(c, k);
@@ -217,6 +224,7 @@ int pcg_iteration(pl_context *c, int k) {
   int rc = launch_spmv(c, c->p.p, c->Ap.p, true, cur + pl::S_PAP * pl::kSlots);
   if (rc) return rc;
   if (c->coarse.ready) return pcg_tail_coarse(c, cur, nxt, k);
+  periodic_average(c, c->Ap.p);        // (periodic constraints: the operator is Q K Q; p.Kp above is already p.QKQp)
   // reference-CG mode (conjugate_gradient_solver.py:79-109): every restart_every-th iteration the direction is rebuilt
   // on the PREVIOUS z (with a preconditioner; kept in tmp) or on the updated residual (without one: z aliases r there)
   const bool ref = ref_cg(c) && !c->dist.active;
@@ -259,6 +267,7 @@ int pcg_iteration(pl_context *c, int k) {
     hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
                        c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
   }
+  periodic_average(c, c->z.p);         // z = Q D^-1 r (r.z was summed with the un-averaged D^-1 r: the same number, r = Q r)
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
                      c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
   PL_HIP(hipGetLastError());
@@ -283,6 +292,10 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     if (pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_RZ_OLD * pl::kSlots, pl::kSlots, c->stream) ||
         pl::dist_sum_scalars(c->dist, c->scal.p + pl::S_BB * pl::kSlots, pl::kSlots, c->stream))
       return fail(PL_ERR_HIP, "RCCL all-reduce of the initial PCG scalars failed");
+  }
+  if (c->n_per_groups > 0) {   // periodic constraints: b is Q b (the caller's part), z0 = Q D^-1 r0, p0 = z0
+    periodic_average(c, c->z.p);
+    PL_HIP(hipMemcpyAsync(c->p.p, c->z.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   if (c->dd_ready || c->dd_blocks) {   // z0 = p0 = G^-1 r0, rz_old = r0.z0 (k_pcg_init ran with dinv = 0)
     ddm_precondition(c, c->scal.p + pl::S_RZ_OLD * pl::kSlots);

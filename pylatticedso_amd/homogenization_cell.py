@@ -16,9 +16,12 @@ What the reference computes, restated on the condensed strut operator:
   un-symmetrised matrix, then ``homogenizeMatrix`` is symmetrised (``solve_full_homogenization`` :405-436).
 
 The sub-meshed interior dofs of every strut are free and un-constrained in the reference, so condensing them out (the
-2-node strut records of libpylattice_hip) changes nothing in the equations above.  The device assembles the strut
-records and the BSR(6x6) global K and evaluates every K*w / K*u_tot; the constrained 6-RHS solve on the few dozen
-periodic master nodes of ONE cell is dense host algebra on that device-assembled K (the reference: PETSc LU).
+2-node strut records of libpylattice_hip) changes nothing in the equations above.  Everything with arithmetic in it runs
+on the device: the strut records, every K*w / K*u_tot, and the six constrained solves - the periodic constraints are a
+master / slave row map handed to the library (``pl_set_periodic``), whose Jacobi PCG then runs on Q K Q with Q the
+orthogonal projector "average over each periodic group" (= P^T K P v = -P^T K w, u = P v; the reference: dolfinx_mpc +
+PETSc LU).  The host only averages the six right-hand sides over the groups and sums reactions.  (Until round 5 the reduced
+matrix was factorised on the host with scipy; ``solver="host"`` keeps that path for cross-checks in the tests.)
 
 Two deliberate differences, both only visible where the reference misbehaves: periodic partners are matched by
 coordinates modulo the cell size (the reference pairs ``locate_dofs_topological`` results of equal boundary tags in
@@ -78,12 +81,17 @@ class HomogenizedCell:
     """Mirror of the reference's ``HomogenizedCell`` results interface: ``homogenizeMatrix``, ``orthotropicMatrix``,
     ``saveDataToExport`` (six total displacement fields, (N, 6) each), ``get_S_orthotropic`` and the print helpers."""
 
-    def __init__(self, lattice, device=None):
+    def __init__(self, lattice, device=None, solver="device", rtol=1e-13):
         if lattice.get_number_cells() > 1:
             raise ValueError("The lattice must contain only one cell for homogenization.")
+        if solver not in ("device", "host"):
+            raise ValueError("solver must be 'device' or 'host'")
         self.lattice = lattice
         self.BeamModel = self
-        self.device = device if device is not None else lattice.device_model()
+        self.solver = solver
+        self.rtol = rtol
+        self.pcg_iterations = []
+        self.device = device if device is not None else lattice.device_model(precond=1)
         self.homogenizeMatrix = None
         self.orthotropicMatrix = None
         self.saveDataToExport = None
@@ -100,7 +108,8 @@ class HomogenizedCell:
         dev = self.device
         dev.set_bc(np.zeros((dev.n_nodes, 6), bool))
         dev.assemble()
-        dev.assemble_bsr(with_bc=False)
+        if self.solver == "host":
+            dev.assemble_bsr(with_bc=False)
 
     def apply_dirichlet_for_homogenization(self):
         lat = self.lattice.lattice
@@ -146,8 +155,37 @@ class HomogenizedCell:
             raise RuntimeError("homogenisation: the periodic cell operator is singular (mechanism in the cell?)") from err
         self._solver = (P, free, factor)
 
+    def _group_average(self, v):
+        """Q v: the average over every periodic group, on all its members (rows of an (N, 6) array)."""
+        m = self._master
+        cnt = np.bincount(m, minlength=len(m)).astype(float)
+        acc = np.zeros_like(v)
+        np.add.at(acc, m, v)
+        return (acc / np.maximum(cnt, 1.0)[:, None])[m]
+
+    def _anchor_group(self):
+        """Nodes whose translations are fixed: the group of the centre vertex where the reference puts its Dirichlet
+        condition, else of the first master node (macro stresses do not depend on it)."""
+        a = self._master[self._anchor] if self._anchor is not None else int(np.unique(self._master)[0])
+        return np.flatnonzero(self._master == a)
+
     def solve_multiple_linear_problem(self, w):
         """u (N, 6) periodic with  P^T K (w + u) = 0  and the anchor translations zero."""
+        if self.solver == "device":
+            if self._master is None:
+                self.periodic_boundary_condition()
+            dev = self.device
+            if not getattr(self, "_periodic_set", False):
+                dev.set_periodic(self._master)
+                self._periodic_set = True
+            fixed = np.zeros((dev.n_nodes, 6), bool)
+            fixed[self._anchor_group(), :3] = True
+            f = self._group_average(-dev.spmv(w))
+            f[fixed] = 0.0
+            dev.set_bc(fixed, None, f)
+            u, st = dev.solve(rtol=self.rtol, max_iter=200000)
+            self.pcg_iterations.append(int(st["iterations"]))
+            return u
         import scipy.linalg
         self.initialize_solver()
         P, free, factor = self._solver

@@ -229,3 +229,36 @@ def test_device_cg_has_the_reference_semantics(golden_dir, tag, kw):
     assert np.allclose(x.ravel(), g[f"{tag}_x"], rtol=1e-8, atol=1e-12)
     if tag == "dirstop":
         assert int(st["stop_reason"]) == 1 and st["converged"] == 1
+
+
+@pytest.mark.parametrize("nb", [2, 8, 12, 14, 20, 26, 32])
+def test_cell_product_on_the_matrix_pipe_for_every_cell_size(nb, monkeypatch):
+    """The DDM operator sum_c B_c^T S_c B_c for cells with nb boundary nodes (m = 6 nb dofs): 8 = BCC, 12 = Hybrid1,
+    26 = the reference's BCC + Hybrid1 (+ Hybrid4) hybrids (optimization/Cantilever_L_beam.json) - all on
+    v_mfma_f64_16x16x4_f64 since round 5 (output columns of a tile dealt over several waves when S^T does not fit one
+    wave's registers) - against numpy, and against the generic kernels (PL_DDM_MFMA=0) of the same library."""
+    rng = np.random.default_rng(nb)
+    n_nodes, n_cells, n_S = 60, 45, 3
+    m = 6 * nb
+    cell_nodes = np.stack([rng.choice(n_nodes, nb, replace=False) for _ in range(n_cells)]).astype(np.int32)
+    A = rng.standard_normal((n_S, m, m))
+    S = A @ A.transpose(0, 2, 1) + m * np.eye(m)
+    cell_S = rng.integers(0, n_S, n_cells).astype(np.int32)
+    x = rng.standard_normal((n_nodes, 6))
+    x[cell_nodes[3]] = 0.0                       # one cell at rest: the reference's skip rule (lattice_sim.py:1239)
+    y_ref = np.zeros((n_nodes, 6))
+    for c in range(n_cells):
+        xc = x[cell_nodes[c]].ravel()
+        if xc.sum() == 0.0:
+            continue
+        np.add.at(y_ref, cell_nodes[c], (S[cell_S[c]] @ xc).reshape(nb, 6))
+    ys = {}
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("PL_DDM_MFMA", mfma)
+        with _capi.HipLattice.ddm(n_nodes, cell_nodes, S, cell_S) as dev:
+            dev.set_bc(np.zeros((n_nodes, 6), bool), None, np.zeros((n_nodes, 6)))
+            dev.assemble()
+            ys[mfma] = dev.spmv(x)
+            assert int(dev.time_kernel(0, 2) > 0)
+    assert _rel(ys["1"], y_ref) < 1e-13
+    assert _rel(ys["0"], y_ref) < 1e-13

@@ -1,6 +1,8 @@
 """Oracle's periodic homogenisation (oracle.homogenize_submeshed, restating homogenization_cell.py) against closed
-forms and invariants.  The reference commits no homogenisation output and cannot run here (dolfinx_mpc), so these
-closed forms are what anchors the oracle; tests/test_gpu_homogenization.py then holds the device path to the oracle."""
+forms, invariants and - since round 5 - REFERENCE-HELD data: the reference commits no homogenisation output and cannot run
+here (dolfinx_mpc), but the periodic homogenised matrix of a cell follows from its Schur complement on the boundary nodes
+alone, and the reference commits those (tests/golden/homogenized_from_schur.npz, made by
+tests/golden/make_homogenization_fixture.py).  tests/test_gpu_homogenization.py holds the device path to both."""
 import os
 
 import numpy as np
@@ -109,3 +111,34 @@ def test_engineering_constants_and_directional_modulus_of_an_isotropic_solid():
     assert np.allclose(S[:3, :3] @ C[:3, :3], np.eye(3)) and np.allclose(np.diag(S)[3:], 1 / G)
     for theta, phi in [(90, 0), (90, 45), (54.7356, 45), (30, 200), (0, 0)]:
         assert np.isclose(np.linalg.norm(directional_modulus(S, theta, phi)), Em, rtol=1e-12)
+
+
+def test_oracle_homogenisation_equals_what_the_reference_schur_complements_give(golden_dir):
+    """The pin: homogenize_submeshed on the sub-meshed model of the reference's own 1x1x1 periodic BCC cell (r = 0.05,
+    joint penalisation on - the settings of the reference's Schur dataset) against the matrix derived from the reference's
+    committed dolfinx / PETSc Schur complement of that cell.  Two independent routes (full sub-meshed K with periodic
+    constraints vs. the reference's condensed 48 x 48 operator) to 1e-10."""
+    fx = np.load(os.path.join(golden_dir, "homogenized_from_schur.npz"))
+    g = np.load(os.path.join(golden_dir, "lattice_bcc_1x1x1_periodic.npz"))
+    keep = ~g["beam_dup"]
+    K, _ = O.assemble_submeshed(g["node_xyz"], g["beam_conn"][keep], g["beam_radius"][keep], E, NU, 0.05)
+    V = O.submesh_vertices(g["node_xyz"], g["beam_conn"][keep], 0.05)
+    C, C_raw, _ = O.homogenize_submeshed(K, V, g["node_tag"])
+    i = int(np.argmin(np.abs(fx["BCC_radius"] - 0.05)))
+    assert fx["BCC_radius"][i] == 0.05
+    assert np.linalg.norm(C - fx["BCC_C"][i]) < 1e-10 * np.linalg.norm(C)
+
+
+def test_fixture_is_what_its_script_makes(golden_dir):
+    """The committed fixture is reproducible from the committed Schur goldens (no reference needed), cubic for the three
+    cells, positive definite, and monotone in the radius."""
+    fx = np.load(os.path.join(golden_dir, "homogenized_from_schur.npz"))
+    for geom in ("BCC", "Hybrid1", "Hybrid4"):
+        sg = np.load(os.path.join(golden_dir, f"schur_{geom}.npz"))
+        assert np.array_equal(sg["radius_values"].ravel(), fx[f"{geom}_radius"])
+        for S, C in zip(sg["schur_matrices"], fx[f"{geom}_C"]):
+            C2, _ = O.homogenize_from_schur(S, sg["boundary_node_xyz"])
+            assert np.linalg.norm(C2 - C) < 1e-12 * np.linalg.norm(C)
+            assert np.linalg.eigvalsh(C).min() > 0
+            assert np.allclose(np.diag(C)[:3], C[0, 0], rtol=1e-8) and np.allclose(np.diag(C)[3:], C[3, 3], rtol=1e-8)
+        assert np.all(np.diff(fx[f"{geom}_C"][:, 0, 0]) > 0)
