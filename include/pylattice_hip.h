@@ -396,6 +396,13 @@ int pl_boundary_index(int64_t n_cells, const int64_t *cell_node_ptr, const int64
                       const double *node_xyz, const double *cell_coord, const double *cell_size, int64_t *index_boundary,
                       int64_t *visit, int64_t *n_visit);
 
+/* The same for the reference's own rows (LatticeSim(reference_compat=True): the rows of a cell are its design nodes AND the
+ * penalisation points of its struts, visited in (round(x, 9), round(y, 9), round(z, 9), index) order - _sorted_nodes,
+ * lattice_sim.py:193-199): every cell's rows are sorted by that key here, all cells in parallel. */
+int pl_boundary_index_rows(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                           const double *node_xyz, const double *cell_coord, const double *cell_size,
+                           int64_t *index_boundary, int64_t *visit, int64_t *n_visit);
+
 /* Neighbour halo exchange ("sum of interface-node partial forces with the two neighbouring
  * slabs"): shared_peer[i] = the rank that holds the other copy of shared entry i of pl_dist_init (a node shared with
  * several ranks is listed once per peer there).  After this call the interface rows of every K*x travel by grouped

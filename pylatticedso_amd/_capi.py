@@ -24,7 +24,7 @@ EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_forget_history", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
            "pl_dist_unique_id", "pl_dist_loopback_id", "pl_dist_abort", "pl_dist_init", "pl_dist_set_peers", "pl_generate_lattice", "pl_lattice_fetch",
-           "pl_lattice_free", "pl_penalize", "pl_boundary_index"]
+           "pl_lattice_free", "pl_penalize", "pl_boundary_index", "pl_boundary_index_rows"]
 
 
 class PlMesh(C.Structure):
@@ -95,7 +95,8 @@ def load_library(path: str | None = None):
            "pl_dist_init": [V, I32, I32, V, V, V, I32, I32], "pl_dist_set_peers": [V, V],
            "pl_generate_lattice": [I64, V, V, V, I32, I32, V, V, V, V], "pl_lattice_fetch": [V] * 12,
            "pl_lattice_free": [V], "pl_penalize": [I64, V, V, V, D, V, V, V],
-           "pl_boundary_index": [I64, V, V, I64, V, V, V, V, V, V]}
+           "pl_boundary_index": [I64, V, V, I64, V, V, V, V, V, V],
+           "pl_boundary_index_rows": [I64, V, V, I64, V, V, V, V, V, V]}
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
     # ABI handshake (include/pylattice_hip.h): this binding's struct layouts must be the library's
@@ -207,8 +208,9 @@ def penalize_arrays(node_xyz, beam_conn, lzone, mesh_size):
     return seg_len, seg_nsub, pen
 
 
-def boundary_index(cell_node_ptr, cell_node_idx, node_xyz, cell_coord, cell_size):
-    """pl_boundary_index: (index_boundary (N,) int64 with -1 off the cell boxes, nodes in visit order)."""
+def boundary_index(cell_node_ptr, cell_node_idx, node_xyz, cell_coord, cell_size, by_coordinates=False):
+    """pl_boundary_index: (index_boundary (N,) int64 with -1 off the cell boxes, nodes in visit order).
+    by_coordinates: pl_boundary_index_rows - rows of a cell visited in rounded-coordinate order (reference_compat rows)."""
     lib = load_library()
     ptr = np.ascontiguousarray(cell_node_ptr, dtype=np.int64)
     idx = np.ascontiguousarray(cell_node_idx, dtype=np.int64)
@@ -217,8 +219,8 @@ def boundary_index(cell_node_ptr, cell_node_idx, node_xyz, cell_coord, cell_size
     ib = np.empty(len(xyz), np.int64)
     visit = np.empty(len(xyz), np.int64)
     nv = C.c_int64()
-    _check(lib, lib.pl_boundary_index(len(cc), _ptr(ptr), _ptr(idx), len(xyz), _ptr(xyz), _ptr(cc), _ptr(cs), _ptr(ib),
-                                      _ptr(visit), C.byref(nv)))
+    fn = lib.pl_boundary_index_rows if by_coordinates else lib.pl_boundary_index
+    _check(lib, fn(len(cc), _ptr(ptr), _ptr(idx), len(xyz), _ptr(xyz), _ptr(cc), _ptr(cs), _ptr(ib), _ptr(visit), C.byref(nv)))
     return ib, visit[:nv.value].copy()
 
 

@@ -310,13 +310,56 @@ void pl_lattice_free(pl_lattice *L) { delete L; }
 // the gmsh subdivision count of every segment (lattice_generation.py:50-64), per strut, multi-threaded.  The new points
 // sit at  end + (other - end) / round(length, 4) * L_zone  - the reference divides by Beam.length, which is rounded to
 // 4 decimals with Python's round(), i.e. the correctly rounded decimal: printf("%.4f") gives the same digits.
+static int boundary_index_impl(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                               const double *node_xyz, const double *cell_coord, const double *cell_size,
+                               int64_t *index_boundary, int64_t *visit, int64_t *n_visit, bool by_coordinates);
+
 int pl_boundary_index(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
                       const double *node_xyz, const double *cell_coord, const double *cell_size, int64_t *index_boundary,
                       int64_t *visit, int64_t *n_visit) {
+  return boundary_index_impl(n_cells, cell_node_ptr, cell_node_idx, n_nodes, node_xyz, cell_coord, cell_size, index_boundary,
+                             visit, n_visit, false);
+}
+int pl_boundary_index_rows(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                           const double *node_xyz, const double *cell_coord, const double *cell_size,
+                           int64_t *index_boundary, int64_t *visit, int64_t *n_visit) {
+  return boundary_index_impl(n_cells, cell_node_ptr, cell_node_idx, n_nodes, node_xyz, cell_coord, cell_size, index_boundary,
+                             visit, n_visit, true);
+}
+
+static int boundary_index_impl(int64_t n_cells, const int64_t *cell_node_ptr, const int64_t *cell_node_idx, int64_t n_nodes,
+                               const double *node_xyz, const double *cell_coord, const double *cell_size,
+                               int64_t *index_boundary, int64_t *visit, int64_t *n_visit, bool by_coordinates) {
   if (n_cells <= 0 || n_nodes <= 0 || !cell_node_ptr || !cell_node_idx || !node_xyz || !cell_coord || !cell_size ||
       !index_boundary || !visit || !n_visit)
     return PL_ERR_ARG;
   try {
+    // by_coordinates (the reference's own rows, LatticeSim(reference_compat=True): design nodes and penalisation points of a
+    // cell interleave): inside a cell the rows are visited in (round(x, 9), round(y, 9), round(z, 9), index) order
+    // (_sorted_nodes, lattice_sim.py:193-199; numpy's round(x, 9) is rint(x 1e9) / 1e9, so rint(x 1e9) orders alike) -
+    // every cell sorted on its own, all cells in parallel
+    std::vector<int64_t> sorted_rows;
+    if (by_coordinates) {
+      sorted_rows.assign(cell_node_idx, cell_node_idx + cell_node_ptr[n_cells]);
+      std::atomic<int> bad_idx{0};
+      parallel_for(n_cells, [&](int64_t cb, int64_t ce, unsigned) {
+        for (int64_t c = cb; c < ce; ++c) {
+          int64_t *r0 = sorted_rows.data() + cell_node_ptr[c], *r1 = sorted_rows.data() + cell_node_ptr[c + 1];
+          for (int64_t *q = r0; q < r1; ++q)
+            if (*q < 0 || *q >= n_nodes) bad_idx = 1;
+          if (bad_idx) return;
+          std::sort(r0, r1, [&](int64_t a, int64_t b) {
+            for (int k = 0; k < 3; ++k) {
+              const double ka = std::nearbyint(node_xyz[3 * a + k] * 1e9), kb = std::nearbyint(node_xyz[3 * b + k] * 1e9);
+              if (ka != kb) return ka < kb;
+            }
+            return a < b;
+          });
+        }
+      }, 256);
+      if (bad_idx) return PL_ERR_ARG;
+      cell_node_idx = sorted_rows.data();
+    }
     std::vector<std::atomic<uint8_t>> on_box((size_t)n_nodes);
     parallel_for(n_nodes, [&](int64_t b, int64_t e, unsigned) {
       for (int64_t i = b; i < e; ++i) {
@@ -345,7 +388,7 @@ int pl_boundary_index(int64_t n_cells, const int64_t *cell_node_ptr, const int64
     for (int64_t c = 0; c < n_cells; ++c) {
       const int64_t q0 = cell_node_ptr[c], q1 = cell_node_ptr[c + 1];
       const int64_t *r = cell_node_idx + q0;
-      if (!std::is_sorted(r, r + (q1 - q0))) {
+      if (!by_coordinates && !std::is_sorted(r, r + (q1 - q0))) {
         row.assign(r, r + (q1 - q0));
         std::sort(row.begin(), row.end());
         r = row.data();

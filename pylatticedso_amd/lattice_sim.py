@@ -402,9 +402,10 @@ class LatticeSim(LatticeViews):
         ptr, idx = self.cell_points()
         node_xyz = self.node_coordinates()
         N = len(node_xyz)
-        if N >= 20000 and not self._compat_rows:   # large lattices: the same rule in multi-threaded C++ (pl_boundary_index)
+        if N >= 20000:   # large lattices: the same rule in multi-threaded C++ (pl_boundary_index / pl_boundary_index_rows)
             from ._capi import boundary_index
-            self.index_boundary, visit = boundary_index(ptr, idx, node_xyz, lat.cell_coord, lat.cell_size)
+            self.index_boundary, visit = boundary_index(ptr, idx, node_xyz, lat.cell_coord, lat.cell_size,
+                                                        by_coordinates=bool(self._compat_rows))
             self.max_index_boundary = len(visit) - 1
             self._boundary_visit_order = visit
             return
