@@ -76,7 +76,12 @@ typedef struct {
                             6 x 6 block solves); 4 = 3 plus a rank-LOCAL dense level (aggregates of this handle only,
                             nodes shared with other ranks left out, no communication) under the global one: for
                             multi-GPU runs, where the all-reduced global level has to coarsen with the rank count.
-                            2, 3 and 4 need reorder = 1 */
+                            2, 3 and 4 need reorder = 1;
+                            5 = the dense Cholesky factor of P K P + (I - P) itself (6 n_nodes <= PL_DDM_DENSE_MAX; built by
+                            pl_assemble from the BSR blocks, fp64 inverse factor): the PCG converges in one or two steps - what
+                            PETSc's preonly / LU is to the reference, for lattices of a few hundred nodes (its own presets) where
+                            hundreds of PCG iterations cost more than a factorisation; pl_stats_t.precond_used = 5, or 1 (Jacobi)
+                            when the matrix is not positive definite (a mechanism).  Single-GPU handles */
   int32_t reorder;       /* 0 = keep caller's node numbering on the device, 1 = spatial tile reordering */
   int32_t check_every;   /* PCG: iterations between host-side convergence checks; 0 = adaptive (32 while far from
                             the threshold, then what the observed decay rate predicts is still needed) */

@@ -145,6 +145,8 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(PL_ERR_NODEVICE, "pl_create: no HIP device visible (libpylattice_hip has no CPU fallback)");
   if (o->device < 0 || o->device >= ndev) return fail(PL_ERR_ARG, "pl_create: bad device ordinal");
+  if (o->precond == 5 && 6 * m->n_nodes > PL_DDM_DENSE_MAX)
+    return fail(PL_ERR_ARG, "pl_create: precond = 5 (dense factorisation) serves at most PL_DDM_DENSE_MAX dofs");
   const int64_t N = m->n_nodes, B = m->n_beams;
   {
     std::atomic<int64_t> bad_ends{-1}, bad_radius{-1}, bad_len{-1}, bad_seg{-1};
@@ -285,7 +287,7 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   pl::parallel_for(N, [&](int64_t i0, int64_t i1, unsigned) {
     for (int64_t i = i0; i < i1; ++i) c->iperm[c->perm[i]] = (int32_t)i;
   }, 1 << 16);
-  if (o->condense >= 0 && o->precond >= 2 && o->precision != 2 && o->reorder == 1) {
+  if (o->condense >= 0 && o->precond >= 2 && o->precond <= 4 && o->precision != 2 && o->reorder == 1) {
     // Candidates for exact elimination inside the PCG (opts.condense): a greedy maximal independent set of the node
     // graph (no two share a strut; at least three struts each).  Inside every tile they are numbered LAST, so that the
     // vector kernels, which skip them, skip one contiguous run of rows per tile.
@@ -450,8 +452,12 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   PL_HIPC(c->fixedbits.alloc(N));
   PL_HIPC(c->ubar.alloc(n6));
   PL_HIPC(c->f.alloc(n6));
-  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2})
-    PL_HIPC(v->alloc(n6));
+  // (precond = 5: padded to the block size of the dense solver and zeroed - its GEMVs read / write whole blocks)
+  const size_t vpad = o->precond == 5 ? (size_t)pl::kNB : 0;
+  for (DevBuf<double> *v : {&c->diag, &c->dinv, &c->x, &c->r, &c->z, &c->p, &c->Ap, &c->tmp, &c->tmp2}) {
+    PL_HIPC(v->alloc(n6 + vpad));
+    if (vpad) PL_HIPC(hipMemset(v->p, 0, (n6 + vpad) * sizeof(double)));
+  }
   PL_HIPC(c->scal.alloc(2 * pl::S_COUNT * pl::kSlots));   // two sets, selected by iteration parity
   PL_HIPC(hipMemset(c->fixed.p, 0, n6));
   PL_HIPC(hipMemset(c->fixedbits.p, 0, N));
@@ -641,6 +647,16 @@ int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S, const i
 }
 
 // G = sum_c B^T Shat B on the free dofs (unit diagonal elsewhere), Cholesky + explicit inverse factor on the device.
+static int ensure_bsr_buffers(pl_context *h) {
+  if (h->bsr_vals.p) return PL_OK;
+  PL_HIP(h->bsr_rowptr.alloc(h->N + 1));
+  PL_HIP(h->bsr_col.alloc(h->nblk));
+  PL_HIP(h->bsr_vals.alloc((size_t)h->nblk * 36));
+  PL_HIP(hipMemcpy(h->bsr_rowptr.p, h->h_rowptr.data(), (h->N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->bsr_col.p, h->h_col.data(), h->nblk * sizeof(int32_t), hipMemcpyHostToDevice));
+  return PL_OK;
+}
+
 static int ddm_factor_preconditioner(pl_context *h) {
   const int64_t n6 = h->N * 6;
   const int np = (int)((n6 + pl::kNB - 1) / pl::kNB * pl::kNB);
@@ -674,6 +690,54 @@ static int ddm_factor_preconditioner(pl_context *h) {
   PL_HIP(hipMemcpyAsync(info, h->dd_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
   h->dd_ready = (info[0] == 0);   // not positive definite (e.g. an indefinite surrogate matrix): caller falls back
+  return PL_OK;
+}
+
+// precond = 5 on a strut-operator handle: P K P + (I - P) as a dense matrix from the BSR(6 x 6) blocks, factorised by the same
+// device Cholesky as the DDM path's assembled Schur matrix (fp64 inverse factor); the PCG then converges in one or two
+// iterations.  What PETSc's preonly / LU is to the reference (simulation_base.py:501-511), for lattices of a few hundred
+// nodes - the sizes of the reference's own presets - where hundreds of PCG iterations cost more than the factorisation.
+static int fem_factor_dense(pl_context *h) {
+  const int64_t n6 = h->N * 6;
+  const int np = (int)((n6 + pl::kNB - 1) / pl::kNB * pl::kNB);
+  if (h->dd_n != np) {
+    const size_t nn = (size_t)np * np;
+    PL_HIP(h->dd_A.alloc(nn));
+    PL_HIP(h->dd_Lf.alloc(nn));
+    PL_HIP(h->dd_W.alloc(nn));
+    PL_HIP(h->dd_Wt.alloc(nn));
+    PL_HIP(h->dd_Dinv.alloc((size_t)np * pl::kNB));
+    PL_HIP(h->dd_tv.alloc(np));
+    PL_HIP(h->dd_info.alloc(2));
+    PL_HIP(hipMemsetAsync(h->dd_W.p, 0, nn * sizeof(double), h->stream));
+    PL_HIP(hipMemsetAsync(h->dd_Wt.p, 0, nn * sizeof(double), h->stream));
+    h->dd_n = np;
+    // block bandwidth of K in the device numbering (spatial tiles: a banded matrix)
+    int64_t band = 0;
+    for (int64_t i = 0; i < h->N; ++i)
+      for (int64_t q = h->h_rowptr[i]; q < h->h_rowptr[i + 1]; ++q) band = std::max<int64_t>(band, std::llabs((long long)(h->h_col[q] - i)));
+    h->dd_bw = (int)((6 * (band + 1) + pl::kNB - 1) / pl::kNB + 1);
+  }
+  h->dd_ready = false;
+  int rc = ensure_bsr_buffers(h);
+  if (rc) return rc;
+  PL_HIP(hipMemsetAsync(h->dd_A.p, 0, (size_t)np * np * sizeof(double), h->stream));
+  PL_HIP(hipMemsetAsync(h->dd_info.p, 0, 2 * sizeof(int), h->stream));
+  rc = launch_bsr_fill(h, 1, h->stream);            // dolfinx's Dirichlet treatment: constrained rows / columns zero, unit diagonal
+  if (rc) return rc;
+  h->have_bsr = false;                              // (the caller's explicit matrix, if any, is refreshed by pl_assemble)
+  hipLaunchKernelGGL(pl::k_bsr_to_dense, dim3(grid_for(h->nblk * 36)), dim3(pl::kBlock), 0, h->stream, h->N, h->nblk,
+                     h->bsr_rowptr.p, h->bsr_col.p, (const double *)h->bsr_vals.p, np, h->dd_A.p);
+  hipLaunchKernelGGL(pl::k_ddm_dense_unit, dim3((np + 255) / 256), dim3(256), 0, h->stream, n6, np, (const uint8_t *)nullptr,
+                     h->dd_A.p);
+  pl::dense_factor_inverse(h->dd_A.p, h->dd_Lf.p, h->dd_W.p, h->dd_Wt.p, h->dd_Dinv.p, np, np, h->dd_info.p, h->dd_bw,
+                           h->stream);
+  PL_HIP(hipGetLastError());
+  int info[2] = {0, 0};
+  PL_HIP(hipMemcpyAsync(info, h->dd_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  h->dd_ready = (info[0] == 0);   // not positive definite (a mechanism): the solve falls back to Jacobi
+  if (h->dd_ready) PL_HIP(hipMemsetAsync(h->dinv.p, 0, n6 * sizeof(double), h->stream));     // z comes from the dense solve
   return PL_OK;
 }
 
@@ -721,6 +785,11 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
   }, 1 << 15);
   PL_HIP(hipMemcpyAsync(h->f.p, st, n6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   PL_HIP(hipStreamSynchronize(h->stream));
+  // The same Dirichlet set as before (only prescribed values / loads changed - the columns of pl_schur, the adjoint solves of
+  // a design loop): everything that depends on the mask (Jacobi inverse, coarse levels, eliminated nodes, dense factor) stands
+  const bool same_mask = h->have_bc && !h->dist.active && h->h_fixedbits == bits;
+  h->h_fixedbits = bits;
+  if (same_mask) return PL_OK;
   h->have_bc = true;
   h->coarse.n_fix = -1;
   h->coarseL.n_fix = -1;
@@ -763,6 +832,10 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
       (void)keep;
     }
     if (h->bsr_with_bc) h->have_bsr = false;   // an explicit matrix built with the old mask is stale
+    if (h->opt.precond == 5 && !h->dist.active) {   // the dense factor depends on the mask
+      rc = fem_factor_dense(h);
+      if (rc) return rc;
+    }
   }
   return PL_OK;
 }
@@ -988,6 +1061,12 @@ int pl_assemble(pl_handle h) {
   // (round 3, tried: the fill queued HERE, beside the tile-block front of the assembly instead of behind the chain's last
   // link: assembly 2.27 -> 2.46 ms in two alternating pairs of runs - it slows the front and the first links)
   PL_HIP(hipEventRecord(h->ev_join, h->side));
+  h->dd_ready = false;
+  if (h->opt.precond == 5 && h->have_bc && !h->dist.active) {
+    PL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));       // (the Jacobi diagonal first: the fallback, and dinv is cleared after)
+    rc = fem_factor_dense(h);
+    if (rc) return rc;
+  }
   rc = build_coarse(h, h->coarse.enabled && h->have_bc ? std::function<void(int)>(queue_fill) : std::function<void(int)>());
   if (rc) return rc;
   queue_fill(1);                                 // (no dense level: queue it now)
@@ -1020,13 +1099,7 @@ int pl_assemble_bsr(pl_handle h, int with_bc, int64_t *n_block_rows, int64_t *n_
   if (!h->assembled) return fail(PL_ERR_STATE, "pl_assemble_bsr: call pl_assemble first");
   if (with_bc && !h->have_bc) return fail(PL_ERR_STATE, "pl_assemble_bsr: with_bc needs pl_set_bc");
   PL_HIP(hipSetDevice(h->opt.device));
-  if (!h->bsr_vals.p) {
-    PL_HIP(h->bsr_rowptr.alloc(h->N + 1));
-    PL_HIP(h->bsr_col.alloc(h->nblk));
-    PL_HIP(h->bsr_vals.alloc((size_t)h->nblk * 36));
-    PL_HIP(hipMemcpy(h->bsr_rowptr.p, h->h_rowptr.data(), (h->N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    PL_HIP(hipMemcpy(h->bsr_col.p, h->h_col.data(), h->nblk * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
+  if (int rcb = ensure_bsr_buffers(h)) return rcb;
   const bool fresh = h->have_bsr && h->want_bsr && h->bsr_with_bc == (with_bc ? 1 : 0);
   h->want_bsr = true;
   h->bsr_with_bc = with_bc ? 1 : 0;
@@ -1163,7 +1236,7 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   st.ms_solve = ms;
   st.ms_assembly = h->ms_assembly;
   st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->dd_blocks ? 3 : h->opt.precond >= 1 ? 1 : 0)
-                                   : (h->coarse.ready ? h->opt.precond : 1);
+                                   : (h->coarse.ready ? h->opt.precond : (h->dd_ready ? 5 : 1));
   h->usol_valid = true;
   if (u) {
     rc = download6(h, h->usol.p, u);

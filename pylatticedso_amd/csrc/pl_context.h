@@ -117,6 +117,7 @@ struct pl_context {
   // boundary data
   DevBuf<uint8_t> fixed;       // [6N] 0/1
   DevBuf<uint8_t> fixedbits;   // [N] 6 bits
+  std::vector<uint8_t> h_fixedbits;   // host copy (device numbering): a pl_set_bc with the SAME Dirichlet set only uploads ubar / f
   DevBuf<double> ubar, f;
   // solver state
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;

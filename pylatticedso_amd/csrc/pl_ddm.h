@@ -389,6 +389,22 @@ __global__ __launch_bounds__(kBlock) void k_ddm_dense_assemble(int64_t C, int nb
   if (fixed && (fixed[gi] || fixed[gj])) return;
   unsafeAtomicAdd(G + gi * ld + gj, St[(size_t)cell_S[c] * m * m + (size_t)j * m + i]);
 }
+// BSR(6 x 6) -> dense (precond = 5 of a strut-operator handle): G[6 i + a][6 j + b] = vals[block (i, j)][a][b]
+__global__ __launch_bounds__(kBlock) void k_bsr_to_dense(int64_t N, int64_t nblk, const int64_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, const double *__restrict__ vals,
+                                                         int ld, double *__restrict__ G) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nblk * 36) return;
+  const int64_t blk = e / 36;
+  const int ab = (int)(e - 36 * blk), a = ab / 6, b = ab - 6 * a;
+  int64_t lo = 0, hi = N;                        // row of the block: the last i with rowptr[i] <= blk
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= blk) lo = mid;
+    else hi = mid;
+  }
+  G[(6 * lo + a) * (int64_t)ld + 6 * (int64_t)col[blk] + b] = vals[e];
+}
 __global__ void k_ddm_dense_unit(int64_t n6, int ld, const uint8_t *__restrict__ fixed, double *__restrict__ G) {
   const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ld) return;

@@ -37,7 +37,9 @@ from .views import LatticeViews
 DDM_DENSE_MAX = 16384      # PL_DDM_DENSE_MAX of include/pylattice_hip.h
 # device_model(): lattice sizes from which the handle is asked for the multi-level preconditioner + record palette, and for
 # fp32-stored PCG vectors with fp64 refinement (measured crossovers, DESIGN.md sections 7 / 7a)
-MULTILEVEL_MIN_NODES = 20000
+MULTILEVEL_MIN_NODES = 600
+DIRECT_MAX_NODES = 200        # up to here: dense factorisation of K as the preconditioner (opts.precond = 5), see device_model
+SMALL_TILES_MAX_NODES = 5000  # multi-level PCG below this size: 32-node tiles and 12-mode dense level
 FP32_VECTORS_MIN_NODES = 2_000_000
 
 _ROOT = Path(__file__).resolve().parents[1]
@@ -558,11 +560,23 @@ class LatticeSim(LatticeViews):
         from ._capi import HipLattice
         if self._device is None:
             pen = self.penalized
+            if self.lattice.n_nodes <= DIRECT_MAX_NODES:
+                # the sizes of the reference's own presets (6x3x3 cells = 166 nodes): a slender cantilever of a few hundred nodes
+                # needs 200 - 300 PCG iterations whatever the preconditioner (3.3 ms), the dense Cholesky factor of its ~1 000
+                # dofs takes 16 launches; the PCG then converges in one or two steps (tools/experiments/small_lattice_precond.py)
+                # (measured, profiles/r05_g_small_precond.txt: BCC 6x3x3 3.05 -> 1.66 ms per assembly + solve, 8x4x4 4.5 -> 3.2;
+                # beyond ~350 nodes the factorisation chain of n / 64 links overtakes the PCG, and Octet lattices, which
+                # converge in 60 - 100 iterations, are served better by the PCG from 300 nodes on)
+                kw.setdefault("precond", 5)
             if self.lattice.n_nodes >= MULTILEVEL_MIN_NODES:
-                # large lattices: multi-level preconditioner + record palette (what bench.py measures); small ones
-                # converge in a few hundred Jacobi iterations and have too few nodes per tile for the coarse levels
+                # multi-level preconditioner + record palette (what bench.py measures).  Round 5: from 600 nodes instead of
+                # 20 000 - with the short iteration (pl_small.h) and small tiles it beats Jacobi from there on (BCC 16x8x8:
+                # 10.3 -> 5.2 ms, Octet 10x5x5 2.9 -> 1.8, 12^3 Octet 4.8 -> 2.1, 16^3 BCC 11.9 -> 5.8 ms per assembly + solve)
                 kw.setdefault("precond", 3)
                 kw.setdefault("palette", 1)
+                if self.lattice.n_nodes < SMALL_TILES_MAX_NODES:
+                    kw.setdefault("tile_nodes", 32)
+                    kw.setdefault("coarse_modes", 12)
             if self.lattice.n_nodes >= FP32_VECTORS_MIN_NODES:
                 # from ~2 M nodes the PCG vectors no longer fit the caches and stream from HBM: fp32 inner solves with fp64
                 # refinement (rtol still refers to the TRUE fp64 residual).  Measured: 100^3 Octet 284 against 234 M

@@ -974,6 +974,58 @@ def test_short_iteration_is_the_default_on_small_lattices_only():
         assert _rel(sols[key], sols["auto"]) < 1e-7
 
 
+@pytest.mark.parametrize("name", ["bcc_2x2x2", "bcc_4x4x4", "bcc_6x3x3_flexion", "bccoctet_2x2x2", "octet_2x2x2_pull",
+                                  "bcchybrid1hybrid4_3x2x1_size"])
+def test_dense_factor_preconditioner_on_small_lattices(golden_dir, name):
+    """opts.precond = 5 (what LatticeSim.device_model asks for below 400 nodes): the dense Cholesky factor of P K P as the
+    preconditioner - the oracle's solution in one or two PCG steps, prescribed displacements and a second Dirichlet set on the
+    same handle included; the explicit BSR matrix the caller asked for is left as asked."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    f[lat.n_nodes // 2, :3] += [1e-3, -2e-3, 5e-4]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    with _device(L, precond=5) as dev:
+        dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+        dev.assemble()
+        dev.assemble_bsr(False)
+        u, st = dev.solve(rtol=1e-10, max_iter=100)
+        assert st["converged"] == 1 and int(st["precond_used"]) == 5 and st["iterations"] <= 3, st
+        assert _rel(u, uref) < 1e-8
+        rng = np.random.default_rng(3)
+        xr = rng.standard_normal((lat.n_nodes, 6))
+        assert _rel(dev.spmv_bsr(xr), dev.spmv(xr)) < 1e-12           # the caller's BSR (without bcs) is intact
+        fixed2 = L.fixed_DOF.copy()
+        fixed2[lat.n_nodes - 1] = True                                # a new Dirichlet set on the assembled handle
+        dev.set_bc(fixed2, None, f)
+        u2, st2 = dev.solve(rtol=1e-10, max_iter=100)
+        uref2 = O.solve_dirichlet(K, fixed2, 0 * ubar, np.where(fixed2, 0.0, f)).reshape(-1, 6)
+        assert int(st2["precond_used"]) == 5 and st2["iterations"] <= 3 and _rel(u2, uref2) < 1e-8
+    # the drop-in layer picks it for small lattices
+    xsol, model = solve_FEM_FenicsX(L)
+    assert int(model.stats["precond_used"]) == 5 and model.stats["iterations"] <= 3
+    L._device.close()
+
+
+def test_dense_factor_preconditioner_falls_back_on_a_mechanism():
+    """A lattice that is not held (no Dirichlet dof): P K P is singular, the factorisation reports it and the solve runs as
+    Jacobi PCG (precond_used = 1) instead of failing."""
+    lat = LA.generate((1, 1, 1), (2, 2, 2), ["BCC"], [0.05])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=5) as dev:
+        f = np.zeros((lat.n_nodes, 6))
+        f[0, 0], f[-1, 0] = 1e-3, -1e-3                               # self-equilibrated load: solvable by CG
+        dev.set_bc(np.zeros((lat.n_nodes, 6), bool), None, f)
+        dev.assemble()
+        u, st = dev.solve(rtol=1e-8, max_iter=5000, raise_on_noconv=False)
+        assert int(st["precond_used"]) in (1, 5)
+        if int(st["precond_used"]) == 5:                              # (rounding made the factorisation go through)
+            assert st["converged"] == 1
+
+
 def test_bfloat16_storage_of_the_dense_level():
     """opts.coarse_storage = 16: the inverse factor of the dense level in bfloat16 (half the bytes of the two triangular
     GEMVs per iteration; automatic from 1 024 dofs).  Same solution to the solver tolerance - the preconditioner only has
