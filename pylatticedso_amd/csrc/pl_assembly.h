@@ -332,7 +332,9 @@ int build_coarse_level(pl_context *c, pl::Coarse &cs, const uint8_t *mask, bool 
   }
   pl::coarse_factor(cs, n, c->stream, after_chol, c->opt.chol_persistent ? cs.bar : (unsigned *)nullptr, ph);
   cs.ainv_ready = false;
-  if (&cs == &c->coarse && small_wanted(c)) {    // explicit A_c^-1 for the short form of the iteration (pl_small.h)
+  // explicit A_c^-1: for the short form of the iteration (pl_small.h), and for every global level small enough to be applied
+  // in one GEMV launch (pl_coarse.h coarse_apply; 2 n^3 / 3 flops on the matrix pipe: ~60 us at 1 536 dofs)
+  if (&cs == &c->coarse && (small_wanted(c) || (n <= pl::kOneGemvMaxDofs && c->opkind == 0))) {
     if (!cs.Ainv && hipMalloc((void **)&cs.Ainv, (size_t)n * n * sizeof(float)) != hipSuccess)
       return fail(PL_ERR_HIP, "pl_assemble: out of device memory for the explicit inverse of the dense level");
     const long tiles = (long)(n / 32) * (n / 32 + 1) / 2;

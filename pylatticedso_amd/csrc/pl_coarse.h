@@ -921,8 +921,16 @@ inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<
   else
     dense_factor_inverse(cs.Ac, cs.Lf, cs.W, cs.Wt, cs.Dinv, n, n, cs.info, cs.bw_blocks, s, after_chol, bar, ph);
 }
+// levels up to this size apply their explicit inverse in ONE GEMV launch (k_full_gemv) instead of two triangular ones
+constexpr int kOneGemvMaxDofs = 2048;
 inline void coarse_apply(const Coarse &cs, const double *r, double *t, double *y, double *dot_out, const double *add0,
                          hipStream_t s) {
+  static const bool one_off = [] { const char *e = std::getenv("PL_ONE_GEMV"); return e && e[0] == '0'; }();
+  if (cs.ainv_ready && cs.Ainv && cs.ncp <= kOneGemvMaxDofs && !one_off) {
+    hipLaunchKernelGGL(k_full_gemv, dim3((cs.ncp + 3) / 4), dim3(kBlock), 0, s, cs.ncp, (const float *)cs.Ainv, cs.ncp, r, y,
+                       dot_out, add0);
+    return;
+  }
   if (cs.w16)
     dense_apply(reinterpret_cast<const bf16_t *>(cs.W), reinterpret_cast<const bf16_t *>(cs.Wt), cs.ncp, cs.ncp, r, t, y,
                 dot_out, add0, s);

@@ -737,6 +737,39 @@ inline void dense_factor_inverse(double *A, double *Lf, WT *W, WT *Wt, double *D
   trtri(s, done, nb);
 }
 
+// y = G r with the explicitly stored symmetric G = A^-1 (fp32, pl_small.h k_dense_explicit_inverse), one wave per row;
+// dot_out[slot] += r.y (+ add0 once).  ONE launch instead of the two triangular GEMVs: at <= 2 048 dofs those are two latency
+// chains of ~4.9 us each, whatever they read.
+__global__ __launch_bounds__(kBlock) void k_full_gemv(int n, const float *__restrict__ G, int ld, const double *__restrict__ r,
+                                                      double *__restrict__ y, double *__restrict__ dot_out,
+                                                      const double *__restrict__ add0) {
+  __shared__ double red[kBlock / kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * (kBlock / kWave) + wv;
+  double part = 0.0;
+  if (row < n) {
+    const double s = wave_sum(row_dot(G + (size_t)row * ld, r, 0, n, lane));
+    if (lane == 0) {
+      y[row] = s;
+      part = s * r[row];
+    }
+  }
+  if (dot_out) {
+    double extra = 0.0;
+    if (blockIdx.x == 0 && add0 && wv == 0) {
+      for (int q = lane; q < kSlots; q += kWave) extra += add0[q];
+      extra = wave_sum(extra);
+    }
+    if (lane == 0) red[wv] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = extra;
+      for (int q = 0; q < kBlock / kWave; ++q) s += red[q];
+      unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+    }
+  }
+}
+
 // y = A^-1 r through W; dot_out[kSlots] += r.A^-1 r (+ *add0 once)
 template <typename WT>
 inline void dense_apply(const WT *W, const WT *Wt, int n, int ld, const double *r, double *t, double *y,
