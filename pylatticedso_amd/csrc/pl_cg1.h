@@ -109,7 +109,6 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
                                                        double *__restrict__ rc, double *__restrict__ sc, int ncp,
                                                        double *__restrict__ hist, int k) {
   __shared__ double red[14][kBlock / kWave];
-  __shared__ volatile double tot[16], ys[16];
   const int t = blockIdx.x;
   double alpha = 0.0, beta = 0.0;
   if (!INIT) {
@@ -217,40 +216,28 @@ __global__ __launch_bounds__(kBlock) void k_cg1_update(const int32_t *__restrict
     }
   }
   __syncthreads();
-  // first wave: tot[0..5] rigid restriction, 6 r.r, 7 r.D^-1 r, 8..13 strain restriction; then the tile level
-  // y_t = B_t^-1 (Z_t^T r), whose share r_t . y_t of r.u joins r.D^-1 r.  The 16 lanes belong to one wave; its cross-lane
-  // exchanges through tot[] / ys[] are volatile accesses ordered by a wavefront-scope release / acquire pair.
+  // first wave: lanes 0..5 rigid restriction, 6 r.r, 7 r.D^-1 r, 8..13 strain restriction; then the tile level
+  // y_t = B_t^-1 (Z_t^T r), whose share r_t . y_t of r.u joins r.D^-1 r.  The 16 lanes belong to one wave: the sums reach every
+  // lane by v_readlane (compile-time lane numbers), the final sum by a DPP row reduction - no LDS exchange without a barrier
+  // (round-4 advisor finding), and no fence that would wait for the atomics issued on the way.
   if (threadIdx.x < 16) {
     double *gam_slot = blk_nxt + ncp + kSlots + (blockIdx.x & (kSlots - 1)), *rr_slot = gam_slot + kSlots;
     double v = 0.0;
     if (threadIdx.x < (TM == 12 ? 14 : 8))
       for (int q = 0; q < nw; ++q) v += red[threadIdx.x][q];
-    tot[threadIdx.x] = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (threadIdx.x == 6) unsafeAtomicAdd(rr_slot, v);
     if (!Bt_inv) {
       if (threadIdx.x == 7) unsafeAtomicAdd(gam_slot, v);
     } else {
-      // mode m of the tile level sits in tot[m] (m < 6) or tot[m + 2] (strains)
+      // mode m of the tile level sits in lane m (m < 6) or lane m + 2 (strains)
       double y = 0.0, stv = 0.0;
-      if (threadIdx.x < TM) {
-        stv = tot[threadIdx.x < 6 ? threadIdx.x : threadIdx.x + 2];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) y += bi[j] * tot[j < 6 ? j : j + 2];
-        yt[TM * (size_t)t + threadIdx.x] = y;
-      }
-      ys[threadIdx.x] = threadIdx.x < TM ? y * stv : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (threadIdx.x == 0) {
-        double g = tot[7];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) g += ys[j];
-        unsafeAtomicAdd(gam_slot, g);
-      }
+      for (int j = 0; j < TM; ++j) y += bi[j] * lane_value(v, j < 6 ? j : j + 2);
+      // (fetched by all 16 lanes: a permute must not read a lane that sits out of a branch)
+      stv = lane_value_dyn(v, threadIdx.x < 6 ? (int)threadIdx.x : min((int)threadIdx.x + 2, 15));
+      if (threadIdx.x < TM) yt[TM * (size_t)t + threadIdx.x] = y;
+      const double g = row_sums((threadIdx.x < TM ? y * stv : 0.0) + (threadIdx.x == 7 ? v : 0.0));      // lane 15: the total
+      if (threadIdx.x == 15) unsafeAtomicAdd(gam_slot, g);
     }
   }
 }

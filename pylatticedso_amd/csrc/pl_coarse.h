@@ -971,7 +971,6 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const uint8_t *__restrict__ skip_rows /* may be null */,
                                                             int cm = 6 /* modes per aggregate of the dense level */) {
   __shared__ double red[32][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
-  __shared__ volatile double sst[16], sv[16];      // cross-lane exchange of ONE wave: volatile + wavefront-scope fences
   if constexpr (!MULTI) {
     w = nullptr;
     shared = nullptr;
@@ -1155,31 +1154,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
       if (!Bt_inv) {
         if (threadIdx.x == 7) unsafeAtomicAdd(rdr_slot, s);
       } else {
-        // the 12 x 12 product through LDS (one wave; volatile accesses ordered by wavefront-scope fences): 12 independent broadcast reads
-        // per lane instead of 24 dependent ds_bpermute
+        // the 12 x 12 product: the twelve restriction sums sit in lanes 0-5 and 8-13 of this wave and reach every lane by
+        // v_readlane (lane numbers are compile-time constants).  (Rounds 2 - 4 passed them through LDS without a barrier, which
+        // is a data race under the HIP memory model; with wavefront-scope fences the release waited for the atomics issued just
+        // above: +2.3 us per iteration at 50^3 Octet - measured in round 5.)
         double st = my_mode >= 0 ? s : 0.0;                // this lane's component of the tile restriction
         if (own_t && threadIdx.x < 6) {                    // several GPUs: the rigid part without the shared nodes
           st = 0.0;
           for (int q = 0; q < nw; ++q) st += red[14 + threadIdx.x][q];
         }
-        sst[threadIdx.x] = st;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double y = 0.0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) y += sbi[threadIdx.x][j] * sst[j < 6 ? j : j + 2];
+        for (int j = 0; j < 12; ++j) y += sbi[threadIdx.x][j] * lane_value(st, j < 6 ? j : j + 2);
         if (my_mode >= 0) yt[12 * (size_t)t + my_mode] = y;
-        sv[threadIdx.x] = my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (threadIdx.x == 0) {
-          double v = 0.0;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) v += sv[j];
-          unsafeAtomicAdd(rdr_slot, v);
-        }
+        const double v = row_sums(my_mode >= 0 ? y * st : (threadIdx.x == 7 ? s : 0.0));     // lane 15: the sum over lanes 0-15
+        if (threadIdx.x == 15) unsafeAtomicAdd(rdr_slot, v);
       }
     }
     return;

@@ -42,6 +42,14 @@ __device__ __forceinline__ double row_sums(double v) {
   v = dpp_row_shr_add(v, 4);
   return dpp_row_shr_add(v, 8);
 }
+// value of lane l (a compile-time constant after unrolling) of the calling wave, for every lane: two v_readlane_b32
+__device__ __forceinline__ double lane_value(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// ... of a lane that differs from lane to lane (ds_bpermute)
+__device__ __forceinline__ double lane_value_dyn(double v, int l) {
+  return __hiloint2double(__shfl(__double2hiint(v), l), __shfl(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_row_shr_add(v, 1);
   v = dpp_row_shr_add(v, 2);
