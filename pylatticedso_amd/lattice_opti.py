@@ -125,7 +125,8 @@ class LatticeOpti(LatticeSim):
     def denormalize_optimization_parameters(self, r_norm):
         if not self.enable_normalization:
             return list(r_norm)
-        return [self._clamp_radius(v * (self.max_radius - self.min_radius) + self.min_radius) for v in r_norm]
+        r = np.asarray(r_norm, dtype=float) * (self.max_radius - self.min_radius) + self.min_radius
+        return np.minimum(self.max_radius, np.maximum(self.min_radius, r)).tolist()       # (_clamp_radius, vectorised)
 
     def normalize_optimization_parameters(self, r):
         if not self.enable_normalization:
@@ -202,16 +203,24 @@ class LatticeOpti(LatticeSim):
             # are on, as lattice_sim.py:1020-1054 does with dolfinx solves); surrogates: one batched evaluation
             self.calculate_schur_complement_cells()
             return
-        dev = self.device_model()
-        dev.update_radii(lat.beam_radius)
+        # the device gets the new radii when it is next asked for (device_model): SLSQP differentiates the density constraint by
+        # finite differences - 54 parameter vectors per iteration on the reference's 6x3x3 preset, none of which is simulated
+        # (round 5: 1 174 of 1 253 calls of this method in a 20-iteration run uploaded radii nobody used)
+        self._device_radii_stale = True
 
     def device_model(self, **kw):
         """As LatticeSim.device_model; a compliance loop solves ONE slowly changing system over and over, so its handle
         starts every solve from the previous solution (pl_opts_t.warm_start; objectives with adjoint solves alternate two
-        right-hand sides on the handle and keep the cold start)."""
+        right-hand sides on the handle and keep the cold start).  Radii set since the last call are uploaded here."""
         if self._device is None and getattr(self, "objective_type", None) == "compliance":
             kw.setdefault("warm_start", 1)
-        return super().device_model(**kw)
+        fresh = self._device is None
+        dev = super().device_model(**kw)
+        if getattr(self, "_device_radii_stale", False) and not self._ddm_mode:
+            if not fresh:                      # (a handle created just now was built from the current radii)
+                dev.update_radii(self.lattice.beam_radius)
+            self._device_radii_stale = False
+        return dev
 
     # -- equilibrium / objective ------------------------------------------------------------------------------
     def _initialize_simulation_parameters(self):
