@@ -761,8 +761,13 @@ def main():
     # SQ counter passes of the same workload / kernel body (tools/prof_kp_config.sh; matched by the K*p source hash).
     kp_form = int(st.get("kp_form", 0))
     issue, issue_why = None, "not the single-GPU default workload"
-    if headline and kp_form == 1:
+    # (weak scaling on several GPUs: every rank runs the headline's kernel on a slab of the same size - the counters of the
+    # single-GPU pass apply when this rank's strut count is within 2 % of the profiled one; rank 0's K*p time prices them)
+    weak_rank = args.config == 1 and (world > 1 or loop) and not args.cells and not args.geom and not args.radius
+    if (headline or weak_rank) and kp_form == 1:
         sq, issue_why = committed_counters("sq_spmv_latest.json", KP_FORMS[kp_form], args.palette)
+        if sq is not None and not headline and abs(per_rank[0] - sq.get("struts", 0)) > 0.02 * per_rank[0]:
+            sq, issue_why = None, f"this rank holds {per_rank[0]} struts, the counters were taken on {sq.get('struts')}"
         if sq is not None:
             issue = issue_model(sq, ms_spmv, "sq_spmv_latest.json")
 
@@ -870,6 +875,10 @@ def main():
                                f"({cfg['name']}{' per GPU' if cfg['scaling'] == 'weak' else ''})",
                    "struts": n_beams_total, "struts_per_gpu": per_rank[0], "nodes_per_gpu": per_rank[1],
                    "partition": part, "ranks": nranks,
+                   # what the COMMUNICATOR says (ncclCommCount / ncclCommUserRank read inside pl_dist_init, or the loopback
+                   # group's size), not the launcher's environment
+                   "communicator": ({"ranks": int(st.get("comm_world", 0)), "this_rank": int(st.get("comm_rank", 0)),
+                                     "source": "pl_stats_t.comm_world / comm_rank"} if (multi or loop) else None),
                    "rtol": args.rtol, "pcg_iterations": st["iterations"], "converged": st["converged"],
                    "rel_residual": st["rel_residual"], "precision": args.precision,
                    "inner_solves": st.get("restarts", 0.0), "condensed_nodes": int(st.get("condensed_nodes", 0)),
