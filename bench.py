@@ -433,7 +433,9 @@ def design_loop(args, local_rank):
     fixed, f, _ = cantilever_bc(lat.node_xyz, float(n))
     cell_of = lat.beam_cell0
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
-                          device=local_rank, precond=3, palette=1, warm_start=1) as dev:
+                          device=local_rank, precond=3, palette=1, warm_start=1, tile_nodes=args.tile_nodes,
+                          coarse_modes=args.coarse_modes, coarse_max_dofs=args.coarse_max_dofs,
+                          tile_modes=max(args.tile_modes, 0), condense=args.condense) as dev:
         dev.set_bc(fixed, None, f)
         r = rc.copy()
         its = []

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pl::", "")
-is_pcg = lambda r: any(k in r["Kernel_Name"] for k in ("k_pcg_", "k_spmv_tile", "k_tri_gemv"))
+is_pcg = lambda r: any(k in r["Kernel_Name"] for k in ("k_pcg_", "k_spmv_tile", "k_tri_gemv", "k_full_gemv", "k_small_z"))
 # assembly phases = maximal runs of non-PCG kernels that contain k_build_records
 phases, cur = [], []
 for r in rows:
