@@ -135,7 +135,8 @@ def roofline_of(kname, palette_form, ab_spmv, ms_spmv, issue, issue_why, traffic
         out.update(achieved=None, frac=None, counters_missing=issue_why)
         return out
     frac = max(issue["valu_issue_frac"], issue["lds_active_frac"])
-    out.update(achieved=issue["valu_wave_instructions"] / issue["cu_clocks"], frac=frac, inconsistent=bool(frac > 1.0),
+    out["unit"] = "share of the CU clocks in which the busier of the two pipes (vector-ALU issue port, LDS) is active"
+    out.update(achieved=frac, frac=frac, inconsistent=bool(frac > 1.0),
                model="a CU issues at most one vector instruction per clock (4 SIMDs x 1 wave instruction / 4 clocks) and its "
                      "LDS serves one access stream; frac = max(VALU issue share, LDS-active share) over n_cu x clock x the "
                      "K*p time of this run", **{k: issue[k] for k in (
