@@ -436,7 +436,8 @@ def design_loop(args, local_rank):
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
                           device=local_rank, precond=3, palette=1, warm_start=1, tile_nodes=args.tile_nodes,
                           coarse_modes=args.coarse_modes, coarse_max_dofs=args.coarse_max_dofs,
-                          tile_modes=max(args.tile_modes, 0), condense=args.condense) as dev:
+                          tile_modes=max(args.tile_modes, 0), condense=args.condense, cg_form=args.cg_form,
+                          short_iteration=args.short_iteration) as dev:
         dev.set_bc(fixed, None, f)
         r = rc.copy()
         its = []
@@ -525,6 +526,8 @@ def main():
     ap.add_argument("--cg-form", type=int, default=0,
                     help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
                          "vectors); 0 = ordinary form")
+    ap.add_argument("--short-iteration", type=int, default=0,
+                    help="small lattices: 0 = automatic, 1 = short form of the iteration (pl_small.h), -1 = ordinary form")
     ap.add_argument("--precision", type=int, default=-1,
                     help="0 = fp64, 1 = fp32 inner PCG + fp64 refinement, 2 = fp32 p and K*p only (-1 = the "
                          "configuration's: fp64, configs[4] precision 1)")
@@ -621,7 +624,7 @@ def main():
     opts = dict(spmv_kernel=args.kernel, reorder=args.reorder, lanes_per_node=args.lpn, precond=args.precond,
                 palette=args.palette, tile_nodes=args.tile_nodes, coarse_max_dofs=args.coarse_max_dofs,
                 precision=args.precision, condense=args.condense, cg_form=args.cg_form, tile_modes=args.tile_modes,
-                coarse_modes=args.coarse_modes, coarse_storage=args.coarse_storage)
+                coarse_modes=args.coarse_modes, coarse_storage=args.coarse_storage, short_iteration=args.short_iteration)
     if args.overlap >= 0:
         opts["overlap"] = args.overlap
 

@@ -24,6 +24,7 @@
 #include "pl_coarse.h"
 #include "pl_cg1.h"
 #include "pl_small.h"
+#include "pl_persist.h"
 #include "pl_palette.h"
 #include "pl_ddm.h"
 #include "pl_lzone.h"
@@ -196,6 +197,12 @@ struct pl_context {
   // short form of the iteration on small lattices (pl_small.h): second p buffer, ring of four scalar sets, two r_c buffers
   DevBuf<double> p2, small_scal, small_rc;
   bool small_use = false;    // the running solve takes the short form (solver_plan)
+  // the whole PCG loop as one persistent launch (pl_persist.h, opts.short_iteration = 2)
+  bool persist_use = false;
+  DevBuf<double> ps_Ug, ps_red;
+  DevBuf<unsigned> ps_flags;          // [2 n_tiles + 4]: flagU | flagR | err | iterations, converged
+  DevBuf<int32_t> ps_agg_ptr, ps_agg_idx;
+  int ps_n_agg = 0;
   int last_iterations = 0;   // of the previous converged pcg_solve on this handle (hint for the first convergence check)
   int64_t n_cond = 0;
   bool cond_ready = false;   // K_cc^-1 valid for the current records and mask

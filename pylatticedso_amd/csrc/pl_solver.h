@@ -274,6 +274,110 @@ int pcg_iteration(pl_context *c, int k) {
   return PL_OK;
 }
 
+// The PCG loop as one persistent launch (pl_persist.h): x, r hold the initial iterate and residual on entry, the result on exit.
+int persist_solve(pl_context *c, double thresh, double bb, int max_iter, pl_stats_t *st) {
+  pl::Coarse &cs = c->coarse;
+  const int64_t n6 = c->N * 6;
+  const int G = (int)c->tile.n_tiles;
+  if (!c->ps_Ug.p) {
+    PL_HIP(c->ps_Ug.alloc((size_t)n6));
+    PL_HIP(c->ps_red.alloc((size_t)G * pl::kPersistRed));
+    PL_HIP(c->ps_flags.alloc((size_t)2 * G + 4));
+    // aggregate -> its tiles
+    std::vector<int32_t> aot((size_t)G);
+    PL_HIP(hipMemcpy(aot.data(), cs.agg_of_tile.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int n_agg = 0;
+    for (int32_t v : aot) n_agg = std::max(n_agg, v + 1);
+    std::vector<int32_t> ptr((size_t)n_agg + 1, 0), idx((size_t)G);
+    for (int32_t v : aot) ptr[(size_t)v + 1]++;
+    for (int g = 0; g < n_agg; ++g) ptr[(size_t)g + 1] += ptr[(size_t)g];
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int t = 0; t < G; ++t) idx[(size_t)fill[(size_t)aot[(size_t)t]]++] = t;
+    PL_HIP(c->ps_agg_ptr.alloc(ptr.size()));
+    PL_HIP(c->ps_agg_idx.alloc(idx.size()));
+    PL_HIP(hipMemcpy(c->ps_agg_ptr.p, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    PL_HIP(hipMemcpy(c->ps_agg_idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->ps_n_agg = n_agg;
+  }
+  if ((int64_t)c->ps_n_agg * cs.cm > cs.ncp) return fail(PL_ERR_STATE, "persistent PCG: aggregate table does not match the dense level");
+  PL_HIP(hipMemsetAsync(c->ps_flags.p, 0, ((size_t)2 * G + 4) * sizeof(unsigned), c->stream));
+  const bool stream_form = !c->pal_lds;
+  pl::PersistArgs a;
+  a.tdesc = c->tile.tdesc.p;
+  a.vword = stream_form ? c->vword_dir.p : c->vword.p;
+  a.vother = c->tile.vother.p;
+  a.tab = static_cast<const double2 *>(stream_form ? (const void *)c->tile.dir_table.p : (const void *)c->pal_dense.p);
+  a.n_tab = stream_form ? c->tile.n_dir : c->pal_entries;
+  a.rec5 = stream_form ? reinterpret_cast<const pl::Rec5 *>(c->rec5.p) : (const pl::Rec5 *)nullptr;
+  a.foreign_idx = c->tile.foreign_idx.p;
+  a.fixedbits = c->fixedbits.p;
+  a.stride = c->tile.max_nodes | 1;
+  a.agg_of_tile = cs.agg_of_tile.p;
+  a.cen = cs.cen.p;
+  a.xyz = c->xyz.p;
+  a.dinv32 = cs.dinv32;
+  a.Bt_inv = cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr;
+  a.Ainv = cs.Ainv;
+  a.agg_tile_ptr = c->ps_agg_ptr.p;
+  a.agg_tile_idx = c->ps_agg_idx.p;
+  a.ncp = cs.ncp;
+  a.cm = cs.cm;
+  a.n_agg = c->ps_n_agg;
+  a.x = c->x.p;
+  a.r = c->r.p;
+  a.Ug = c->ps_Ug.p;
+  a.red = c->ps_red.p;
+  a.flagU = c->ps_flags.p;
+  a.flagR = c->ps_flags.p + G;
+  a.err = c->ps_flags.p + 2 * G;
+  a.hist = c->hist.p;
+  a.max_iter = max_iter;
+  a.thresh = thresh;
+  a.iters_out = reinterpret_cast<int *>(c->ps_flags.p + 2 * G + 1);
+  const size_t lds = ((size_t)12 * a.stride + (size_t)2 * a.n_tab * (stream_form ? 2 : pl::kPalLdsChunks) + (size_t)2 * cs.ncp +
+                      (size_t)G * pl::kPersistRed) * sizeof(double);
+  if (lds > 150 * 1024) return fail(PL_ERR_STATE, "persistent PCG: the tile state does not fit the LDS");
+  const bool tm12 = tile_modes_now(c) == 12;
+#define PL_PS3(R, TM, NC)                                                                                               \
+  do {                                                                                                                  \
+    PL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pl::k_persist_cg1<R, TM, NC>),                           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                   \
+    hipLaunchKernelGGL((pl::k_persist_cg1<R, TM, NC>), dim3((unsigned)G), dim3(pl::kPersistBlock), lds, c->stream, a); \
+  } while (0)
+#define PL_PS(R, TM)                                                                   \
+  do {                                                                                 \
+    if (cs.ncp <= 2 * pl::kPersistBlock) PL_PS3(R, TM, 2);                             \
+    else if (cs.ncp <= 3 * pl::kPersistBlock) PL_PS3(R, TM, 3);                        \
+    else PL_PS3(R, TM, 4);                                                             \
+  } while (0)
+  if (stream_form) {
+    if (tm12) PL_PS(pl::kRecCompact, 12);
+    else PL_PS(pl::kRecCompact, 6);
+  } else {
+    if (tm12) PL_PS(pl::kRecPalette, 12);
+    else PL_PS(pl::kRecPalette, 6);
+  }
+#undef PL_PS
+#undef PL_PS3
+  PL_HIP(hipGetLastError());
+  unsigned tail[3] = {0, 0, 0};
+  PL_HIP(hipMemcpyAsync(tail, c->ps_flags.p + 2 * G, sizeof(tail), hipMemcpyDeviceToHost, c->stream));
+  PL_HIP(hipStreamSynchronize(c->stream));
+  if (tail[0] != 0) return fail(PL_ERR_HIP, "persistent PCG: a hand-off between workgroups timed out");
+  const int its = (int)tail[1];
+  st->iterations = its;
+  st->converged = (int)tail[2];
+  st->info = st->converged ? 0.0 : 1.0;
+  st->short_iteration_used = 2.0;
+  if (its >= 0 && its < c->hist_cap) {
+    double rr = 0.0;
+    PL_HIP(hipMemcpy(&rr, c->hist.p + std::min(its, max_iter - 1), sizeof(double), hipMemcpyDeviceToHost));
+    if (std::isnan(rr) || std::isinf(rr)) return fail(PL_ERR_NAN, "NaN/Inf in the PCG residual");
+    st->rel_residual = std::sqrt(rr / bb);
+  }
+  return PL_OK;
+}
+
 // Solve P K P x = rhs (device rhs already masked), x0 = 0.  Result in c->x.  Returns iterations through stats.
 int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, double rtol, int max_iter,
               pl_stats_t *st) {
@@ -335,7 +439,9 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        (const double *)c->p.p, c->r.p, c->x.p);
     PL_HIP(hipGetLastError());
   }
-  if (c->small_use) {
+  if (c->persist_use) {
+    // (the persistent launch builds u0 = M^-1 r0 itself)
+  } else if (c->small_use) {
     // short form: z0 = M^-1 r0 and r0.z0 through the tail of an iteration "-1" (alpha = 0: set -1 of the ring is zero);
     // iteration 0 then forms p0 = z0 + 0 p_old in its K*p launch
     rc = small_prepare(c);
@@ -369,6 +475,17 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     return std::isnan(bb) ? fail(PL_ERR_NAN, "NaN in the right-hand side") : PL_OK;
   }
   const double thresh = rtol * rtol * bb;
+  if (c->persist_use) {
+    rc = persist_solve(c, thresh, bb, max_iter, st);
+    if (rc) return rc;
+    c->last_iterations = st->converged ? st->iterations : 0;
+    if (c->opt.warm_start == 1 && st->converged) {      // keep the solution for the next solve (as below)
+      if (!c->xprev.p) PL_HIP(c->xprev.alloc(n6));
+      PL_HIP(hipMemcpyAsync(c->xprev.p, c->x.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      c->xprev_valid = true;
+    }
+    return PL_OK;
+  }
   // The host looks at the residual history every `chunk` iterations.  With the default (check_every = 0) the chunk
   // adapts: 32 while far from the threshold, then what the observed decay rate predicts is still needed - a fixed
   // chunk overshoots by 16 iterations on average, 8 % of a 200-iteration solve.  (Every rank of a multi-GPU run sees
@@ -475,6 +592,14 @@ inline void solver_plan(pl_context *c) {
   const int form = kp_form_of(c);
   c->small_use = !mp && small_wanted(c) && c->coarse.ready && !c->coarseL.ready && c->coarse.ainv_ready &&
                  (form == 1 || form == 2) && c->tile.vis_ready;
+  // ... or, opt-in, the whole loop as one persistent launch (pl_persist.h): single-reduction CG without node elimination,
+  // one workgroup per tile, all co-resident
+  c->persist_use = c->small_use && c->opt.short_iteration == 2 && c->tile.n_tiles <= 256 &&
+                   c->coarse.ncp <= pl::kPersistBlock * pl::kPersistMaxCols && c->tile.max_nodes <= pl::kPersistBlock;
+  if (c->persist_use) {
+    c->cond_use = false;
+    c->small_use = false;
+  }
 }
 inline bool cg1_applies(const pl_context *c) {
   return c->opt.cg_form == 1 && c->coarse.ready && !c->coarseL.ready && !c->cond_use && c->opt.precision == 0 &&

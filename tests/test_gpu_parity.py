@@ -948,6 +948,40 @@ def test_short_iteration_matches_ordinary_form_and_oracle(golden_dir, name, grad
     assert abs(its[1][0] - its[-1][0]) <= 2 and abs(its[1][1] - its[-1][1]) <= 3, its
 
 
+@pytest.mark.parametrize("name,graded", [("bcc_4x4x4", False), ("bcc_6x3x3_flexion", True), ("bccoctet_2x2x2", False),
+                                         ("octet_3x2x2_size", True)])
+@pytest.mark.parametrize("modes", [(6, 6), (12, 12)])
+def test_persistent_pcg_matches_oracle(golden_dir, name, graded, modes):
+    """opts.short_iteration = 2 (pl_persist.h, experimental): the whole PCG loop - single-reduction CG, multi-level
+    preconditioner, no node elimination - as ONE persistent launch with hand-offs between the tiles' workgroups.  The oracle's
+    solution, iteration counts near the multi-launch solver's, a second solve on the same handle."""
+    _, L = _sim(golden_dir, name)
+    lat = L.lattice
+    if graded:
+        rng = np.random.default_rng(5)
+        lat.beam_radius[:] = lat.beam_radius * (1.0 + 0.2 * rng.random(lat.n_beams))
+    f = np.zeros((lat.n_nodes, 6))
+    f[:, :3] = L.applied_force[:, :3]
+    f[lat.n_nodes // 2, :3] += [1e-3, -2e-3, 5e-4]
+    K = O.assemble_condensed(lat.node_xyz, lat.beam_conn, _oracle_scalars(L))
+    ubar = np.where(L.fixed_DOF, L.displacement_vector, 0.0)
+    uref = O.solve_dirichlet(K, L.fixed_DOF, ubar, np.where(L.fixed_DOF, 0.0, f)).reshape(-1, 6)
+    its = {}
+    for short in (-1, 2):
+        with _device(L, precond=3, tile_nodes=32, coarse_max_dofs=600, condense=-1, palette=1, tile_modes=modes[0],
+                     coarse_modes=modes[1], short_iteration=short) as dev:
+            dev.set_bc(L.fixed_DOF, L.displacement_vector, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=5000)
+            assert st["converged"] == 1, st
+            assert int(st["short_iteration_used"]) == (2 if short == 2 else 0)
+            assert _rel(u, uref) < 1e-7
+            u2, st2 = dev.solve(rtol=1e-10, max_iter=5000)
+            assert st2["converged"] == 1 and _rel(u2, u) < 1e-8
+            its[short] = st["iterations"]
+    assert abs(its[2] - its[-1]) <= max(3, its[-1] // 10), its
+
+
 def test_short_iteration_is_the_default_on_small_lattices_only():
     """Automatic choice (opts.short_iteration = 0): on where every tile can read its rows of A_c^-1 once per iteration
     (n_tiles x modes x dofs x 4 B <= 16 MB), off on the headline-sized lattice; never with the fp32 solver modes or the
