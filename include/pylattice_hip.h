@@ -151,7 +151,11 @@ typedef struct {
                           * solve and the prolongation fused into one launch that writes z = M^-1 r and r.z, the search
                           * direction p = z + beta p formed inside the next K*p launch: 3 dependent launches per iteration
                           * instead of 5 (4 instead of 6 under node elimination); 0 = automatic (on where it applies: fp64,
-                          * ordinary CG form, single-GPU handle, n_tiles x modes x dense dofs small), -1 = never.
+                          * ordinary CG form, single-GPU handle, n_tiles x modes x dense dofs small), -1 = never;
+                          * 2 = EXPERIMENTAL: the whole loop as ONE persistent launch (pl_persist.h: single-reduction CG without
+                          * node elimination, one workgroup per tile, hand-offs through write-through stores and flags; at most
+                          * 256 tiles of <= 512 nodes, dense level <= 2 048 dofs) - measured slower than 1, kept for
+                          * the record; pl_stats_t.short_iteration_used = 2.
                           * pl_stats_t.short_iteration_used says what ran */
 } pl_opts_t;
 

@@ -201,6 +201,7 @@ struct pl_context {
   bool persist_use = false;
   DevBuf<double> ps_Ug, ps_red;
   DevBuf<unsigned> ps_flags;          // [2 n_tiles + 4]: flagU | flagR | err | iterations, converged
+  DevBuf<unsigned long long> ps_dbg;  // [8] per-phase clock ticks of workgroup 0 (PL_PERSIST_DEBUG=1 prints them)
   DevBuf<int32_t> ps_agg_ptr, ps_agg_idx;
   int ps_n_agg = 0;
   int last_iterations = 0;   // of the previous converged pcg_solve on this handle (hint for the first convergence check)

@@ -56,6 +56,7 @@ struct PersistArgs {
   int max_iter;
   double thresh;
   int *iters_out;                  // [0] iterations run, [1] converged
+  unsigned long long *dbg;         // [8] ticks of the 100 MHz clock workgroup 0 spent per phase (summed over the iterations)
 };
 
 #define PL_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
   double *rcs = reinterpret_cast<double *>(ps2 + kTabChunks * a.n_tab);  // [ncp] r_c
   double *scs = rcs + ncp;                                               // [ncp] Z^T s
   double *stage = scs + ncp;                                             // [gridDim.x][kPersistRed] gathered partial sums
+  int32_t *agp = reinterpret_cast<int32_t *>(stage + (size_t)gridDim.x * kPersistRed);   // [n_agg + 1] aggregate -> tiles (CSR)
+  int32_t *agi = agp + a.n_agg + 1;                                                       // [gridDim.x]
   __shared__ double redw[24][kPersistBlock / kWave];
   __shared__ double tot[24];
   __shared__ double yct[16];
@@ -145,6 +148,8 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
   for (int i = tid; i < kSrcChunks * a.n_tab; i += kPersistBlock)
     ps2[(i / kSrcChunks) * kTabChunks + (i % kSrcChunks)] = a.tab[i];
   for (int e = tid; e < ncp; e += kPersistBlock) scs[e] = 0.0;
+  for (int e = tid; e <= a.n_agg; e += kPersistBlock) agp[e] = a.agg_tile_ptr[e];
+  for (int e = tid; e < (int)gridDim.x; e += kPersistBlock) agi[e] = a.agg_tile_idx[e];
   // ---- r_c of the initial residual: restriction summed over ALL tiles through one all-gather (epoch 1 of flagR)
   auto restrict12 = [&](const double v[6], double acc[12]) {
     acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2];
@@ -202,13 +207,20 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
       const int g = e / cm, m = e - cm * g;
       double s = 0.0;
       if (g < a.n_agg)
-        for (int q = a.agg_tile_ptr[g]; q < a.agg_tile_ptr[g + 1]; ++q) s += stage[a.agg_tile_idx[q] * kPersistRed + m];
+        for (int q = agp[g]; q < agp[g + 1]; ++q) s += stage[agi[q] * kPersistRed + m];
       rcs[e] = s;
     }
     __syncthreads();
   }
   double gamma_old = 0.0, alpha_old = 0.0;
   int k = 0, converged = 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#define PL_PH(i)                                \
+  do {                                          \
+    const unsigned long long now_ = wall_clock64(); \
+    ph[i] += now_ - tlast;                      \
+    tlast = now_;                               \
+  } while (0)
   for (; k < a.max_iter; ++k) {
     const unsigned eU = (unsigned)k + 1u, eR = (unsigned)k + 2u;
     // ---- u = D^-1 r + P Z (y_c + y_t)
@@ -259,11 +271,13 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(a.flagU + t, eU, PL_RLX);
+    PL_PH(0);
     if (wv == 0) {
       const bool good = persist_wait_all(a.flagU, G, eU, a.err);
       if (lane == 0) ok_s = good ? 1 : 0;
     }
     __syncthreads();
+    PL_PH(1);
     if (!ok_s) break;
     // ---- w = K u on the tile's rows
     auto record_of = [&](unsigned id, const Rec5 &q) -> Record {
@@ -325,6 +339,7 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
       }
     }
     __syncthreads();
+    PL_PH(2);
     // ---- partial sums of this tile: Z^T w, delta, gamma, rr
     double pr15[16];
 #pragma unroll
@@ -342,12 +357,15 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
     block_sums(pr15, std::integral_constant<int, 15>());
     if (tid == 15) tot[15] = 0.0;
     __syncthreads();
+    PL_PH(3);
     if (!all_gather(eR)) break;
+    PL_PH(4);
     // ---- scalars in a fixed order (every workgroup alike), coarse recurrences
-    if (tid < 3) {
-      double s = 0.0;
-      for (int g = 0; g < G; ++g) s += stage[g * kPersistRed + 12 + tid];
-      tot[16 + tid] = s;
+    if (wv < 3) {                          // wave w sums column 12 + w over the tiles: lanes take g = lane, lane + 64, ... in
+      double s = 0.0;                      // order, then a DPP tree - the same order in every workgroup
+      for (int g = lane; g < G; g += 64) s += stage[g * kPersistRed + 12 + wv];
+      s = wave_sum(s);
+      if (lane == 0) tot[16 + wv] = s;
     }
     __syncthreads();
     const double delta = tot[16], gamma = tot[17], rr_now = tot[18];
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
       const int g = e / cm, m = e - cm * g;
       double zw = 0.0;
       if (g < a.n_agg)
-        for (int q = a.agg_tile_ptr[g]; q < a.agg_tile_ptr[g + 1]; ++q) zw += stage[a.agg_tile_idx[q] * kPersistRed + m];
+        for (int q = agp[g]; q < agp[g + 1]; ++q) zw += stage[agi[q] * kPersistRed + m];
       const double sv = zw + beta * scs[e];
       scs[e] = sv;
       rcs[e] -= alpha * sv;
@@ -383,7 +401,11 @@ __global__ __launch_bounds__(kPersistBlock) void k_persist_cg1(PersistArgs a) {
       }
     }
     __syncthreads();
+    PL_PH(5);
   }
+#undef PL_PH
+  if (t == 0 && tid == 0 && a.dbg)
+    for (int i = 0; i < 8; ++i) a.dbg[i] = ph[i];
   if (own) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {

@@ -283,6 +283,7 @@ int persist_solve(pl_context *c, double thresh, double bb, int max_iter, pl_stat
     PL_HIP(c->ps_Ug.alloc((size_t)n6));
     PL_HIP(c->ps_red.alloc((size_t)G * pl::kPersistRed));
     PL_HIP(c->ps_flags.alloc((size_t)2 * G + 4));
+    PL_HIP(c->ps_dbg.alloc(8));
     // aggregate -> its tiles
     std::vector<int32_t> aot((size_t)G);
     PL_HIP(hipMemcpy(aot.data(), cs.agg_of_tile.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -334,8 +335,9 @@ int persist_solve(pl_context *c, double thresh, double bb, int max_iter, pl_stat
   a.max_iter = max_iter;
   a.thresh = thresh;
   a.iters_out = reinterpret_cast<int *>(c->ps_flags.p + 2 * G + 1);
+  a.dbg = c->ps_dbg.p;
   const size_t lds = ((size_t)12 * a.stride + (size_t)2 * a.n_tab * (stream_form ? 2 : pl::kPalLdsChunks) + (size_t)2 * cs.ncp +
-                      (size_t)G * pl::kPersistRed) * sizeof(double);
+                      (size_t)G * pl::kPersistRed) * sizeof(double) + ((size_t)c->ps_n_agg + 1 + G + 2) * sizeof(int32_t);
   if (lds > 150 * 1024) return fail(PL_ERR_STATE, "persistent PCG: the tile state does not fit the LDS");
   const bool tm12 = tile_modes_now(c) == 12;
 #define PL_PS3(R, TM, NC)                                                                                               \
@@ -364,6 +366,14 @@ int persist_solve(pl_context *c, double thresh, double bb, int max_iter, pl_stat
   PL_HIP(hipMemcpyAsync(tail, c->ps_flags.p + 2 * G, sizeof(tail), hipMemcpyDeviceToHost, c->stream));
   PL_HIP(hipStreamSynchronize(c->stream));
   if (tail[0] != 0) return fail(PL_ERR_HIP, "persistent PCG: a hand-off between workgroups timed out");
+  if (const char *e = std::getenv("PL_PERSIST_DEBUG"); e && e[0] == '1') {
+    unsigned long long ph[8];
+    PL_HIP(hipMemcpy(ph, c->ps_dbg.p, sizeof(ph), hipMemcpyDeviceToHost));
+    const double it = std::max(1u, tail[1]);
+    std::fprintf(stderr, "[persist] %u iterations; us per iteration in workgroup 0: u + publish %.2f | wait u %.2f | K u %.2f | sums + publish "
+                 "%.2f | wait + gather %.2f | scalars + recurrences %.2f\n", tail[1], ph[0] * 0.01 / it, ph[1] * 0.01 / it,
+                 ph[2] * 0.01 / it, ph[3] * 0.01 / it, ph[4] * 0.01 / it, ph[5] * 0.01 / it);
+  }
   const int its = (int)tail[1];
   st->iterations = its;
   st->converged = (int)tail[2];
