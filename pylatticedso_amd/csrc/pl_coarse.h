@@ -70,6 +70,11 @@ struct Coarse {
   // the coarse modes must be EXACTLY rigid per aggregate - their energy is tiny next to ||K||, and a 1e-7 error in
   // the lever arms costs iterations (measured)
   float *dinv32 = nullptr;
+  // ... but where every lever arm (node position minus its aggregate's reference point) happens to be a float EXACTLY - unit
+  // cells of size 1, 1/2, 1/4 ...: every BASELINE configuration - the two vector kernels read it as 12 bytes per node instead
+  // of 24 (+ the reference point): the same numbers, bit for bit (rel_exact; checked node by node in coarse_setup)
+  TBuf<float> rel32;
+  bool rel_exact = false;
   // struts inside one aggregate that touch a Dirichlet dof (the only non-crossing struts with coarse energy);
   // rebuilt on the device after every pl_set_bc
   TBuf<int32_t> fix_list;
@@ -146,8 +151,27 @@ inline int coarse_setup(Coarse &c, const std::vector<int32_t> &tile_start, const
     for (int32_t i = tile_start[t]; i < tile_start[t + 1]; ++i) agg_of_node[i] = a;
   }
   {
-    (void)xyz_dev_order;
     if (hipMalloc((void **)&c.dinv32, (size_t)N * 6 * sizeof(float)) != hipSuccess) return 2;
+    // lever arms as floats, kept only if not one bit is lost (see rel32)
+    c.rel_exact = false;
+    if (!local && xyz_dev_order && !std::getenv("PL_NO_REL32")) {
+      std::vector<float> rel((size_t)N * 3);
+      bool exact = true;
+      for (int64_t i = 0; i < N && exact; ++i)
+        for (int k = 0; k < 3; ++k) {
+          const double d = xyz_dev_order[3 * i + k] - cen[3 * (size_t)agg_of_node[i] + k];
+          const float f = (float)d;
+          if ((double)f != d) {
+            exact = false;
+            break;
+          }
+          rel[3 * (size_t)i + k] = f;
+        }
+      if (exact) {
+        if (c.rel32.upload(rel) != hipSuccess) return 1;
+        c.rel_exact = true;
+      }
+    }
   }
   c.n_agg = n_agg;
   c.nc = modes * n_agg;
@@ -969,7 +993,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
                                                             const uint8_t *__restrict__ shared /* may be null */,
                                                             double *__restrict__ rcL, int ncp,
                                                             const uint8_t *__restrict__ skip_rows /* may be null */,
-                                                            int cm = 6 /* modes per aggregate of the dense level */) {
+                                                            int cm = 6 /* modes per aggregate of the dense level */,
+                                                            const float *__restrict__ rel32 = nullptr /* Coarse::rel32 */) {
   __shared__ double red[32][4 * kBlock / kWave];   // one partial per row of 16 lanes (row_sums)
   if constexpr (!MULTI) {
     w = nullptr;
@@ -1043,7 +1068,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_tile(const int32_t *__res
 #pragma unroll
       for (int k = 0; k < 6; ++k) wt[k] = w[6 * (int64_t)i + k];
     }
-    const double rx = xyz[3 * (int64_t)i] - c0, ry = xyz[3 * (int64_t)i + 1] - c1, rz = xyz[3 * (int64_t)i + 2] - c2;
+    double rx, ry, rz;
+    if (rel32) {          // the same three numbers as 12 bytes (exact by construction: Coarse::rel_exact)
+      rx = (double)rel32[3 * (int64_t)i];
+      ry = (double)rel32[3 * (int64_t)i + 1];
+      rz = (double)rel32[3 * (int64_t)i + 2];
+    } else {
+      rx = xyz[3 * (int64_t)i] - c0;
+      ry = xyz[3 * (int64_t)i + 1] - c1;
+      rz = xyz[3 * (int64_t)i + 2] - c2;
+    }
     const double ru[3] = {wt[0] * rv[0], wt[1] * rv[1], wt[2] * rv[2]};
     acc[0] += ru[0];
     acc[1] += ru[1];
@@ -1406,7 +1440,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
                                                                  const uint8_t *__restrict__ shared /* may be null */,
                                                                  double *__restrict__ rcL, int ncpL,
                                                                  const uint8_t *__restrict__ zero_rows /* may be null */,
-                                                                 int cm = 6) {
+                                                                 int cm = 6,
+                                                                 const float *__restrict__ rel32 = nullptr /* Coarse::rel32 */) {
   if constexpr (!MULTI) shared = nullptr;
   if constexpr (!MULTI || !LOCAL) aggL_of_tile = nullptr;
   double old, rz_new, pap;
@@ -1476,7 +1511,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_coarse(const int32_t *
     // eliminated node: not an unknown of this CG (its row of p is rewritten by the first pass of every product, which
     // takes the old content as zero: k_spmv_tile<.., kEndsCondensedSolve>)
     if (zero_rows && zero_rows[i]) continue;
-    const double rx = xyz[3 * i] - c0, ry = xyz[3 * i + 1] - c1, rz = xyz[3 * i + 2] - c2;
+    double rx, ry, rz;
+    if (rel32) {
+      rx = (double)rel32[3 * i];
+      ry = (double)rel32[3 * i + 1];
+      rz = (double)rel32[3 * i + 2];
+    } else {
+      rx = xyz[3 * i] - c0;
+      ry = xyz[3 * i + 1] - c1;
+      rz = xyz[3 * i + 2] - c2;
+    }
     double zc[6] = {U0 + (W1 * rz - W2 * ry), U1 + (W2 * rx - W0 * rz), U2 + (W0 * ry - W1 * rx), W0, W1, W2};
     if constexpr (TM == 12) {   // uniform strains: u += eps r (several GPUs: the aggregate's everywhere, the tile's on own nodes)
      if (shared && cm == 12) {
@@ -1549,7 +1593,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
                                                                double *__restrict__ hist, int k,
                                                                double *__restrict__ rc, int ncp,
                                                                const int32_t *__restrict__ keep /* may be null */,
-                                                               int cm, const uint8_t *__restrict__ shared /* may be null */) {
+                                                               int cm, const uint8_t *__restrict__ shared /* may be null */,
+                                                               const float *__restrict__ rel32 = nullptr /* Coarse::rel32 */) {
   // keep: with node elimination (opts.condense) N counts the nodes that stay unknowns and keep[] lists them - the lanes
   // map onto those only (a flag test per node left half of the lanes of a BCC lattice idle: 80 us for 1.03 M kept nodes at
   // 100^3 against 26 us for 0.5 M nodes of the Octet lattice)
@@ -1598,7 +1643,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction_flat(int64_t N, const 
 #pragma unroll
     for (int m = 0; m < TM; ++m) C[m] += w[m];
   }
-  const double rx = xyz[3 * i] - cen[3 * a], ry = xyz[3 * i + 1] - cen[3 * a + 1], rz = xyz[3 * i + 2] - cen[3 * a + 2];
+  double rx, ry, rz;
+  if (rel32) {
+    rx = (double)rel32[3 * i];
+    ry = (double)rel32[3 * i + 1];
+    rz = (double)rel32[3 * i + 2];
+  } else {
+    rx = xyz[3 * i] - cen[3 * a];
+    ry = xyz[3 * i + 1] - cen[3 * a + 1];
+    rz = xyz[3 * i + 2] - cen[3 * a + 2];
+  }
   double zc[6] = {C[0] + (C[4] * rz - C[5] * ry), C[1] + (C[5] * rx - C[3] * rz), C[2] + (C[3] * ry - C[4] * rx),
                   C[3], C[4], C[5]};
   if constexpr (TM == 12) {

@@ -35,7 +35,9 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.rc, cs.tile_level ? (const double *)cs.Bt_inv : (const double *)nullptr, cs.yt,               \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p,                   \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,   \
-                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+                     cs.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm, rel32)
+  // lever arms as exact floats where the lattice allows it (Coarse::rel32); the rank-local level has its own reference points
+  const float *rel32 = cs.rel_exact ? (const float *)cs.rel32.p : (const float *)nullptr;
   if (useL) {
     if (tile_modes_now(c) == 12) PL_UPD(12, true, true);
     else PL_UPD(6, true, true);
@@ -61,7 +63,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      c->hist.p, hist_slot, cs.rc, cs.ncp,                                                                \
                      useL ? (const int32_t *)cl.agg_of_tile.p : (const int32_t *)nullptr, cl.cen.p, cl.yc,                \
                      (c->dist.active || useL) ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, cl.rc,       \
-                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm)
+                     cl.ncp, c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, cs.cm, rel32)
   const int64_t n_flat = c->cond_use ? c->N - c->n_cond : c->N;       // nodes that are unknowns of this CG
 #define PL_DIRF(TM)                                                                                                      \
   hipLaunchKernelGGL((pl::k_pcg_direction_flat<PT, RT, TM>), dim3((unsigned)((3 * n_flat + pl::kBlock - 1) / pl::kBlock)), \
@@ -69,7 +71,7 @@ int pcg_tail_coarse_t(pl_context *c, double *cur, double *nxt, int hist_slot, PT
                      cs.agg_of_tile.p, cs.cen.p, cs.yc, cs.tile_level ? (const double *)cs.yt : (const double *)nullptr,  \
                      c->fixedbits.p, p, x, cur, nxt, c->hist.p, hist_slot, cs.rc, cs.ncp,                                \
                      c->cond_use ? (const int32_t *)c->ckeep.p : (const int32_t *)nullptr, cs.cm,                        \
-                     c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr)
+                     c->dist.active ? (const uint8_t *)c->sharedbits.p : (const uint8_t *)nullptr, rel32)
   // flat mapping, contiguous per wave: fp64 p without a rank-local level (measured on one box, 50^3 Octet: 26.2 -> 24.5 us;
   // fp32 p / fp64 r the same either way, fp32 p / fp32 r 19.0 -> 22.0 us - 8-byte loads per lane are too few in flight)
   if (!useL && sizeof(PT) == 8) {

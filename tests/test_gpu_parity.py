@@ -1394,3 +1394,35 @@ def test_assembly_schedules_give_the_same_operator_and_solution(env, monkeypatch
         # the dense level is the same operator whatever the launch schedule: same iteration count (+- the one a last-bit
         # difference in the atomically assembled coarse operator can cost)
         assert abs(st["iterations"] - 133) <= 3, st["iterations"]
+
+
+@pytest.mark.parametrize("cell,geom,condense", [(1.0, "Octet", 0), (0.5, "BCC", 1), (0.7, "Octet", 0)])
+def test_float_lever_arms_of_the_vector_kernels_change_nothing(cell, geom, condense, monkeypatch):
+    """Round 5: where every node's position relative to its aggregate's reference point is a float exactly (cell sizes 1, 1/2 ...:
+    checked node by node at pl_create), k_pcg_update_tile / k_pcg_direction_* read it as 12 bytes per node instead of 24.  The
+    numbers are the same, so the preconditioner is: same iteration count (+- what a last-bit difference of the atomically
+    assembled coarse operator can cost) and the same displacements as with the table switched off (PL_NO_REL32); a cell size of
+    0.7 has no exact table and takes the fp64 positions as before."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 14
+    lat = LA.generate((cell, cell, cell), (n, n, n), [geom], [0.04 * cell])
+    pen = LA.penalize(lat, _capi.lzone(lat.node_xyz, lat.beam_conn, lat.beam_radius))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[np.isclose(lat.node_xyz[:, 0], n * cell), 2] = -1e-3
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("PL_NO_REL32", "1")
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                              palette=1, condense=condense) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=5000)
+            assert st["converged"] == 1
+            r = np.where(fixed, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(f)
+            out.append((u, st["iterations"]))
+    assert abs(out[0][1] - out[1][1]) <= 3, (out[0][1], out[1][1])
+    assert _rel(out[0][0].ravel(), out[1][0].ravel()) < 1e-8
