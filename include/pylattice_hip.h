@@ -217,9 +217,10 @@ void pl_destroy(pl_handle h);
  * Cell.define_node_order_to_simulate, cell.py:611-680) through the dense Schur complement S[cell_S[c]] ((6nb)^2,
  * row-major).  The handle then serves pl_set_bc / pl_assemble / pl_spmv / pl_spmv_free / pl_solve / pl_reactions with
  * K := sum_c B_c^T S_c B_c; pl_solve runs plain CG (opts->precond = 0, as the reference's default), Jacobi-CG
- * (opts->precond = 1), CG preconditioned by the factorised assembled matrix (opts->precond = 2, below) or by the inverted
+ * (opts->precond = 1), CG preconditioned by the factorised assembled matrix (opts->precond = 2, below), by the inverted
  * 6 x 6 node blocks of the assembled matrix (opts->precond = 3: any size; built by pl_assemble for the current Dirichlet
- * mask from the same matrices as precond = 2), with opts->alpha_max. */
+ * mask from the same matrices as precond = 2) or by the node blocks plus a dense level on aggregates of nodes
+ * (opts->precond = 4, pl_ddm_set_geometry below), with opts->alpha_max. */
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S, const double *S,
                   const int32_t *cell_S, const pl_opts_t *opts, pl_handle *out);
 
@@ -236,6 +237,18 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
 #define PL_DDM_DENSE_MAX 16384
 int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/,
                               const int32_t *cell_S /*[n_cells]*/);
+
+/* Beyond PL_DDM_DENSE_MAX dofs (round 5): opts->precond = 4 on a DDM handle = the node blocks of precond = 3 plus a dense
+ * level, M^-1 = B^-1 + Z A_c^-1 Z^T with A_c = Z^T P G P Z - twelve modes (six rigid-body motions, six uniform strains) per
+ * aggregate of boundary nodes, aggregates = boxes of a regular grid over the nodes' bounding box, as many as
+ * opts->coarse_max_dofs / 12 allows (0: 1 536 dofs).  It stands where the reference factorises the assembled matrix
+ * (build_preconditioner, lattice_sim.py:1351-1415): not a direct solve, but an iteration count that no longer grows with the
+ * lattice (32^3 BCC cells: 2.2 x fewer iterations than the node blocks).  The modes need the node positions, which
+ * pl_create_ddm does not take: this call hands them over (before pl_assemble; calling it again re-cuts the aggregates).
+ * pl_assemble builds the node blocks, A_c from the cell matrices (the palette of pl_ddm_set_preconditioner if one is set)
+ * and its Cholesky / inverse factor; when A_c is not positive definite the node blocks alone are used and
+ * pl_stats_t.precond_used says 3. */
+int pl_ddm_set_geometry(pl_handle h, const double *node_xyz /*[3 n_nodes]*/);
 
 /* Dirichlet / load data per dof.  fixed[6N] (0/1), ubar[6N] prescribed values (read where fixed), f[6N] nodal
  * loads.  Replaces apply_displacement_all_nodes_with_lattice_data / apply_force_on_all_nodes_with_lattice_data

@@ -19,7 +19,7 @@ PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_N
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
-           "pl_ddm_set_preconditioner", "pl_destroy", "pl_set_bc", "pl_set_periodic",
+           "pl_ddm_set_preconditioner", "pl_ddm_set_geometry", "pl_destroy", "pl_set_bc", "pl_set_periodic",
            "pl_update_radii", "pl_set_multiplicity", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_forget_history", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
@@ -85,7 +85,7 @@ def load_library(path: str | None = None):
     lib.pl_lattice_free.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {"pl_default_opts": [V, C.c_uint32], "pl_opts_size": [], "pl_stats_size": [], "pl_abi_version": [], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
-           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V], "pl_set_periodic": [V, V],
+           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_ddm_set_geometry": [V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V], "pl_set_periodic": [V, V],
            "pl_update_radii": [V, V], "pl_set_multiplicity": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
@@ -272,11 +272,16 @@ class HipLattice:
             self.set_multiplicity(beam_mult)
 
     @classmethod
-    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=1, precond=0, mintol=0.0,
-            restart_every=0):
+    def ddm(cls, n_nodes, cell_nodes, S, cell_S, device=0, alpha_max=100.0, check_every=0, precond=0, mintol=0.0,
+            restart_every=0, node_xyz=None, coarse_max_dofs=0):
         """Handle for the domain-decomposition operator sum_c B^T S B (pl_create_ddm).  precond = 0: plain CG as the
         reference's default; 1: Jacobi on the assembled diagonal; 2: the reference's factorised assembled matrix
-        (of the operator's own cell matrices unless ``set_ddm_preconditioner`` installs others)."""
+        (of the operator's own cell matrices unless ``set_ddm_preconditioner`` installs others); 3: its 6 x 6 node blocks;
+        4: node blocks + a dense level of 12 modes per aggregate of nodes (needs ``node_xyz``, pl_ddm_set_geometry).
+        check_every = 0: the host looks at the residual history every few dozen iterations; the device applies the
+        reference's stopping rules itself and freezes the iterate at the iteration that meets them (k_pcg_direction), so the
+        result is the reference's iterate whatever the host had queued (until round 5 the default was a look - and a drained
+        stream - after every iteration)."""
         self = cls.__new__(cls)
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -289,12 +294,24 @@ class HipLattice:
         opts = default_opts(self._lib)
         opts.device, opts.alpha_max, opts.check_every = device, alpha_max, check_every
         opts.precond = precond
+        opts.coarse_max_dofs = int(coarse_max_dofs)
         opts.mintol, opts.restart_every = float(mintol), int(restart_every)   # conjugate_gradient_solver.py:96-109
+        if precond == 4 and node_xyz is None:
+            raise ValueError("precond = 4 on a DDM handle needs node_xyz (the modes of its dense level)")
         _check(self._lib, self._lib.pl_create_ddm(self.n_nodes, cn.shape[0], cn.shape[1], _ptr(cn), Sm.shape[0],
                                                   _ptr(Sm), _ptr(cs), C.byref(opts), C.byref(self._h)))
         self.last_stats = None
         self._n_cells, self._m = cn.shape[0], 6 * cn.shape[1]
+        if node_xyz is not None:
+            self.set_ddm_geometry(node_xyz)
         return self
+
+    def set_ddm_geometry(self, node_xyz):
+        """Node positions of a DDM handle (pl_ddm_set_geometry): aggregates and modes of the dense level of precond = 4."""
+        xyz = np.ascontiguousarray(node_xyz, dtype=np.float64)
+        if xyz.shape != (self.n_nodes, 3):
+            raise ValueError(f"node_xyz must be ({self.n_nodes}, 3), got {xyz.shape}")
+        _check(self._lib, self._lib.pl_ddm_set_geometry(self._h, _ptr(xyz)))
 
     def set_ddm_preconditioner(self, S=None, cell_S=None):
         """Cell matrices of the assembled-Schur preconditioner (pl_ddm_set_preconditioner); None = the operator's."""

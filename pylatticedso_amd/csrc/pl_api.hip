@@ -490,7 +490,8 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   c->opt = *o;
   // 0: the reference's plain CG; 1: Jacobi on the assembled Schur diagonal; 2: the reference's own preconditioner, the
   // factorised assembled Schur matrix (dense Cholesky on the device, hence the size limit)
-  c->opt.precond = (o->precond >= 1 && o->precond <= 3) ? o->precond : 0;     // 3: node-block Jacobi (6 x 6 blocks of G)
+  c->opt.precond = (o->precond >= 1 && o->precond <= 4) ? o->precond : 0;     // 3: node-block Jacobi (6 x 6 blocks of G);
+                                                                              // 4: + a dense level on node aggregates (pl_ddm_set_geometry)
   if (c->opt.precond == 2 && 6 * n_nodes > PL_DDM_DENSE_MAX) {
     delete c;
     return fail(PL_ERR_ARG, "pl_create_ddm: precond = 2 factorises a dense (6 n_nodes)^2 matrix; limit is " +
@@ -618,6 +619,130 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
   PL_HIPC(hipDeviceSynchronize());
 #undef PL_HIPC
   *out = c;
+  return PL_OK;
+}
+
+// Node positions of a DDM handle -> aggregates of the two-level preconditioner (opts.precond = 4): boxes of a regular grid over
+// the bounding box, as many as opts.coarse_max_dofs / 12 allows (default 1 536 dofs = 128 aggregates) but at least ~27 nodes
+// each, numbered with the longest axis slowest (narrow band of A_c); the band is taken from the cells themselves.
+int pl_ddm_set_geometry(pl_handle h, const double *node_xyz) {
+  if (!valid(h) || !node_xyz) return fail(PL_ERR_ARG, "pl_ddm_set_geometry: null argument");
+  if (h->opkind != 1) return fail(PL_ERR_STATE, "pl_ddm_set_geometry: not a DDM handle");
+  PL_HIP(hipSetDevice(h->opt.device));
+  const int64_t N = h->N;
+  h->dd2_plan = false;
+  h->dd2_ready = false;
+  h->assembled = false;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) lo[k] = hi[k] = node_xyz[k];
+  for (int64_t i = 0; i < N; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const double v = node_xyz[3 * i + k];
+      if (!std::isfinite(v)) return fail(PL_ERR_ARG, "pl_ddm_set_geometry: non-finite coordinate");
+      lo[k] = std::min(lo[k], v);
+      hi[k] = std::max(hi[k], v);
+    }
+  const int budget = h->opt.coarse_max_dofs > 0 ? h->opt.coarse_max_dofs : 1536;
+  const int64_t n_target = std::max<int64_t>(1, std::min<int64_t>(budget / pl::kDdmModes, N / 27));
+  double ext[3];
+  for (int k = 0; k < 3; ++k) ext[k] = hi[k] - lo[k];
+  const double emax = std::max(ext[0], std::max(ext[1], ext[2]));
+  int64_t na[3] = {1, 1, 1};
+  if (emax > 0.0) {     // boxes as close to cubes as the count allows: na_k ~ ext_k / side, side shrunk while the product fits
+    double side = emax;
+    for (int it = 0; it < 200; ++it) {
+      int64_t t[3];
+      for (int k = 0; k < 3; ++k) t[k] = std::max<int64_t>(1, (int64_t)std::floor(ext[k] / (side * 0.96) + 0.5));
+      if (t[0] * t[1] * t[2] > n_target) break;
+      for (int k = 0; k < 3; ++k) na[k] = t[k];
+      side *= 0.96;
+    }
+  }
+  const int n_agg = (int)(na[0] * na[1] * na[2]);
+  int ax[3] = {0, 1, 2};
+  std::stable_sort(ax, ax + 3, [&](int l, int r) { return na[l] > na[r]; });
+  std::vector<int32_t> agg((size_t)N), ptr((size_t)n_agg + 1, 0), nodes((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    int64_t b[3];
+    for (int k = 0; k < 3; ++k) {
+      b[k] = ext[k] > 0.0 ? (int64_t)std::floor((node_xyz[3 * i + k] - lo[k]) / ext[k] * (double)na[k]) : 0;
+      b[k] = std::min<int64_t>(std::max<int64_t>(b[k], 0), na[k] - 1);
+    }
+    agg[(size_t)i] = (int32_t)((b[ax[0]] * na[ax[1]] + b[ax[1]]) * na[ax[2]] + b[ax[2]]);
+    ptr[(size_t)agg[(size_t)i] + 1]++;
+  }
+  for (int a = 0; a < n_agg; ++a) ptr[(size_t)a + 1] += ptr[(size_t)a];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < N; ++i) nodes[(size_t)fill[(size_t)agg[(size_t)i]]++] = (int32_t)i;
+  }
+  std::vector<double> cen((size_t)n_agg * 3);
+  for (int a = 0; a < n_agg; ++a) {
+    int64_t b[3];
+    b[ax[0]] = a / (na[ax[1]] * na[ax[2]]);
+    b[ax[1]] = (a / na[ax[2]]) % na[ax[1]];
+    b[ax[2]] = a % na[ax[2]];
+    for (int k = 0; k < 3; ++k) cen[3 * (size_t)a + k] = lo[k] + ((double)b[k] + 0.5) * ext[k] / (double)na[k];
+  }
+  // band of A_c: the largest difference of aggregate numbers inside one cell
+  std::vector<int32_t> cn((size_t)h->ddm_cells * h->ddm_nb);
+  PL_HIP(hipMemcpy(cn.data(), h->ddm_cell_nodes.p, cn.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int64_t max_diff = 0;
+  for (int64_t c = 0; c < h->ddm_cells; ++c) {
+    int32_t amin = n_agg, amax = -1;
+    for (int i = 0; i < h->ddm_nb; ++i) {
+      const int32_t a = agg[(size_t)cn[(size_t)c * h->ddm_nb + i]];
+      amin = std::min(amin, a);
+      amax = std::max(amax, a);
+    }
+    max_diff = std::max<int64_t>(max_diff, amax - amin);
+  }
+  pl::Coarse &cs = h->dd2;
+  const int nc = pl::kDdmModes * n_agg, ncp = (nc + pl::kNB - 1) / pl::kNB * pl::kNB;
+  if (cs.ncp != ncp) {
+    for (void **q : {(void **)&cs.Ac, (void **)&cs.Lf, (void **)&cs.W, (void **)&cs.Wt, (void **)&cs.Dinv, (void **)&cs.rc,
+                     (void **)&cs.yc, (void **)&cs.tv, (void **)&cs.info, (void **)&cs.bar, (void **)&cs.Ainv})
+      if (*q) {
+        (void)hipFree(*q);
+        *q = nullptr;
+      }
+    const size_t n2 = (size_t)ncp * ncp;
+    PL_HIP(hipMalloc((void **)&cs.Ac, n2 * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.Lf, n2 * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.W, n2 * sizeof(float)));
+    PL_HIP(hipMalloc((void **)&cs.Wt, n2 * sizeof(float)));
+    PL_HIP(hipMalloc((void **)&cs.Dinv, (size_t)ncp * pl::kNB * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.rc, (size_t)(ncp + 2 * pl::kSlots) * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.yc, (size_t)ncp * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.tv, (size_t)ncp * sizeof(double)));
+    PL_HIP(hipMalloc((void **)&cs.info, 2 * sizeof(int)));
+    PL_HIP(hipMalloc((void **)&cs.bar, sizeof(unsigned)));
+    if (ncp <= pl::kOneGemvMaxDofs) PL_HIP(hipMalloc((void **)&cs.Ainv, n2 * sizeof(float)));
+    PL_HIP(hipMemset(cs.Lf, 0, n2 * sizeof(double)));
+    PL_HIP(hipMemset(cs.W, 0, n2 * sizeof(float)));
+    PL_HIP(hipMemset(cs.Wt, 0, n2 * sizeof(float)));
+    PL_HIP(hipMemset(cs.rc, 0, (size_t)(ncp + 2 * pl::kSlots) * sizeof(double)));
+    PL_HIP(hipMemset(cs.yc, 0, (size_t)ncp * sizeof(double)));
+  }
+  cs.n_agg = n_agg;
+  cs.nc = nc;
+  cs.ncp = ncp;
+  cs.cm = pl::kDdmModes;
+  cs.bw_blocks = (int)((pl::kDdmModes * (max_diff + 1) + pl::kNB - 1) / pl::kNB + 1);
+  cs.w16 = h->opt.coarse_storage == 16 || (h->opt.coarse_storage == 0 && ncp >= 1024);
+  cs.ainv_ready = false;
+  h->dd2_n_agg = n_agg;
+  PL_HIP(h->dd2_xyz.alloc((size_t)N * 3));
+  PL_HIP(h->dd2_cen.alloc(cen.size()));
+  PL_HIP(h->dd2_agg.alloc(agg.size()));
+  PL_HIP(h->dd2_ptr.alloc(ptr.size()));
+  PL_HIP(h->dd2_nodes.alloc(nodes.size()));
+  PL_HIP(hipMemcpy(h->dd2_xyz.p, node_xyz, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->dd2_cen.p, cen.data(), cen.size() * sizeof(double), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->dd2_agg.p, agg.data(), agg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->dd2_ptr.p, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PL_HIP(hipMemcpy(h->dd2_nodes.p, nodes.data(), nodes.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->dd2_plan = true;
   return PL_OK;
 }
 
@@ -798,12 +923,13 @@ int pl_set_bc(pl_handle h, const uint8_t *fixed, const double *ubar, const doubl
     if (rcs) return rcs;
   }
   if (h->assembled && h->opkind == 1) {
-    if (h->opt.precond == 2 || h->opt.precond == 3) {
-      // the factorised G / the node blocks were built for the old Dirichlet mask (and dinv must stay 0 next to them):
-      // build them again
+    if (h->opt.precond >= 2 && h->opt.precond <= 4) {
+      // the factorised G / the node blocks (and the dense level on top of them) were built for the old Dirichlet mask (and
+      // dinv must stay 0 next to them): build them again
       h->assembled = false;
       h->dd_ready = false;
       h->dd_blocks = false;
+      h->dd2_ready = false;
     } else {
       pl::launch_invert_diag(h->N * 6, h->diag.p, h->fixed.p, h->dinv.p, h->stream);
       PL_HIP(hipStreamSynchronize(h->stream));
@@ -940,7 +1066,10 @@ int pl_assemble(pl_handle h) {
   if (h->opkind == 1) {   // DDM operator: nothing to build; plain CG as the reference, Jacobi, or the factorised matrix
     h->dd_ready = false;
     h->dd_blocks = false;
-    if (h->opt.precond == 3) {      // node-block Jacobi: the 6 x 6 diagonal blocks of the assembled matrix, inverted
+    h->dd2_ready = false;
+    if (h->opt.precond == 4 && !h->dd2_plan)
+      return fail(PL_ERR_STATE, "pl_assemble: precond = 4 on a DDM handle needs the node positions (pl_ddm_set_geometry)");
+    if (h->opt.precond == 3 || h->opt.precond == 4) {      // node-block Jacobi: the 6 x 6 diagonal blocks of the assembled matrix, inverted
       PL_HIP(hipEventRecord(h->ev0, h->stream));
       if (!h->dd_B.p) PL_HIP(h->dd_B.alloc((size_t)h->N * 36));
       PL_HIP(hipMemsetAsync(h->dd_B.p, 0, (size_t)h->N * 36 * sizeof(double), h->stream));
@@ -951,12 +1080,39 @@ int pl_assemble(pl_handle h) {
       hipLaunchKernelGGL(pl::k_ddm_node_blocks_invert, dim3(grid_for(h->N)), dim3(pl::kBlock), 0, h->stream, h->N,
                          h->have_bc ? (const uint8_t *)h->fixed.p : (const uint8_t *)nullptr, h->dd_B.p);
       PL_HIP(hipMemsetAsync(h->dinv.p, 0, h->N * 6 * sizeof(double), h->stream));      // z comes from the node blocks
+      int info2[2] = {0, 0};
+      if (h->opt.precond == 4) {    // + the dense level: A_c = Z^T P G P Z cell by cell, Cholesky + inverse factor (pl_dense.h)
+        pl::Coarse &cs = h->dd2;
+        const int n = cs.ncp, m = 6 * h->ddm_nb;
+        PL_HIP(hipMemsetAsync(cs.Ac, 0, (size_t)n * n * sizeof(double), h->stream));
+        PL_HIP(hipMemsetAsync(cs.info, 0, 2 * sizeof(int), h->stream));
+        hipLaunchKernelGGL(pl::k_ddm_coarse_cells, dim3((unsigned)h->ddm_cells), dim3(pl::kWave),
+                           (size_t)2 * m * pl::kDdmModes * sizeof(double), h->stream, h->ddm_cells, h->ddm_nb,
+                           h->ddm_cell_nodes.p, h->ddm_have_P ? h->ddm_cell_P.p : h->ddm_cell_S.p,
+                           h->ddm_have_P ? h->ddm_Pt.p : h->ddm_St.p, h->dd2_agg.p, h->dd2_cen.p, h->dd2_xyz.p,
+                           h->have_bc ? (const uint8_t *)h->fixed.p : (const uint8_t *)nullptr, n, cs.Ac);
+        hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cs.Ac);
+        pl::coarse_factor(cs, n, h->stream, nullptr, (unsigned *)nullptr);
+        cs.ainv_ready = false;
+        if (cs.Ainv) {
+          const long tiles = (long)(n / 32) * (n / 32 + 1) / 2;
+          if (cs.w16)
+            hipLaunchKernelGGL(pl::k_dense_explicit_inverse<pl::bf16_t>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0,
+                               h->stream, n, reinterpret_cast<const pl::bf16_t *>(cs.W), n, cs.Ainv);
+          else
+            hipLaunchKernelGGL(pl::k_dense_explicit_inverse<float>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, h->stream,
+                               n, (const float *)cs.W, n, cs.Ainv);
+          cs.ainv_ready = true;
+        }
+        PL_HIP(hipMemcpyAsync(info2, cs.info, sizeof(info2), hipMemcpyDeviceToHost, h->stream));
+      }
       PL_HIP(hipEventRecord(h->ev1, h->stream));
       PL_HIP(hipEventSynchronize(h->ev1));
       PL_HIP(hipGetLastError());
       float ms = 0.f;
       PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
       h->ms_assembly = ms;
+      h->dd2_ready = h->opt.precond == 4 && info2[0] == 0;     // (A_c not positive definite: the node blocks alone; precond_used = 3)
       h->dd_blocks = true;
       h->assembled = true;
       return PL_OK;
@@ -1235,7 +1391,7 @@ int pl_solve(pl_handle h, double rtol, int32_t max_iter, double *u, pl_stats_t *
   PL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   st.ms_solve = ms;
   st.ms_assembly = h->ms_assembly;
-  st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->dd_blocks ? 3 : h->opt.precond >= 1 ? 1 : 0)
+  st.precond_used = h->opkind == 1 ? (h->dd_ready ? 2 : h->dd2_ready ? 4 : h->dd_blocks ? 3 : h->opt.precond >= 1 ? 1 : 0)
                                    : (h->coarse.ready ? h->opt.precond : (h->dd_ready ? 5 : 1));
   h->usol_valid = true;
   if (u) {
@@ -1401,6 +1557,7 @@ int pl_time_kernel(pl_handle h, int which, int reps, double *avg_ms) {
   int rc = ensure_hist(h, reps + 1);
   if (rc) return rc;
   solver_plan(h);   // which == 3 times the iteration the next pl_solve would run, whatever was called before
+  h->stop_use = false;   // (a finished solve has stopped itself on the device: time the iteration, not its early return)
   if (h->small_use && (which == 3 || which == 11)) {     // short form: its buffers (zeroed operands: the timing does not care)
     rc = small_prepare(h);
     if (rc) return rc;

@@ -152,6 +152,17 @@ struct pl_context {
   bool dd_ready = false;
   DevBuf<double> dd_B;   // node-block Jacobi of the DDM operator (opt.precond = 3): inverted 6 x 6 blocks
   bool dd_blocks = false;
+  // two-level preconditioner of a DDM handle (opt.precond = 4, pl_ddm.h): the node blocks + a dense level of 12 modes per
+  // aggregate of nodes; geometry and aggregates from pl_ddm_set_geometry
+  DevBuf<double> dd2_xyz, dd2_cen;
+  DevBuf<int32_t> dd2_agg, dd2_ptr, dd2_nodes;   // aggregate of every node; the nodes aggregate by aggregate (CSR)
+  pl::Coarse dd2;                                // its matrices (A_c, factors, r_c, y_c), ncp, bw_blocks, w16
+  int dd2_n_agg = 0;
+  bool dd2_plan = false, dd2_ready = false;
+  // device-side stop of the CG of a DDM handle (k_pcg_direction): the flag, and the numbers of the solve in flight
+  DevBuf<int> stop_flag;
+  bool stop_use = false;
+  double stop_thresh = 0.0;
   // record palette (pl_palette.h)
   DevBuf<unsigned long long> pal_keys;
   DevBuf<int> pal_owner, pal_flags;

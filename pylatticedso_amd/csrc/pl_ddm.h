@@ -411,4 +411,203 @@ __global__ void k_ddm_dense_unit(int64_t n6, int ld, const uint8_t *__restrict__
   if (d >= n6 || (fixed && fixed[d]) || G[d * ld + d] == 0.0) G[d * ld + d] = 1.0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two-level preconditioner of the DDM operator (opts.precond = 4 on a DDM handle; round 5):
+//     M^-1 = B^-1 + Z A_c^-1 Z^T ,   A_c = Z^T P G P Z ,   G = sum_c B_c^T S_c B_c
+// B = the 6 x 6 node blocks of G (precond = 3), Z = 12 modes per aggregate of nodes (six rigid-body motions about the
+// aggregate's reference point + the six uniform strains u = eps (x - c), no rotation), aggregates = boxes of a regular grid
+// over the nodes' bounding box (pl_ddm_set_geometry).  What it replaces: the reference factorises the assembled G with
+// SuperLU (LatticeSim.build_preconditioner, lattice_sim.py:1351-1415), which a dense device factorisation follows up to
+// PL_DDM_DENSE_MAX dofs only.  Host prototype: tools/experiments/ddm_two_level_host.py (24^3 BCC cells: 356 iterations with
+// the node blocks, 141 / 169 / 207 with aggregates of 4 / 5 / 6 cells per axis; 32^3: 474 -> 213 with 125 aggregates).
+// ---------------------------------------------------------------------------------------------------------------
+// dof d (0-2 translations, 3-5 rotations) of a node at `rel` from the reference point under mode q
+__device__ __forceinline__ double ddm_mode(int q, int d, double rx, double ry, double rz) {
+  if (q < 3) return d == q ? 1.0 : 0.0;
+  if (q < 6) {
+    if (d >= 3) return d == q ? 1.0 : 0.0;
+    const int a = q - 3;                               // u = e_a x r
+    if (a == 0) return d == 1 ? -rz : (d == 2 ? ry : 0.0);
+    if (a == 1) return d == 0 ? rz : (d == 2 ? -rx : 0.0);
+    return d == 0 ? -ry : (d == 1 ? rx : 0.0);
+  }
+  if (d >= 3) return 0.0;
+  switch (q) {
+    case 6: return d == 0 ? rx : 0.0;
+    case 7: return d == 1 ? ry : 0.0;
+    case 8: return d == 2 ? rz : 0.0;
+    case 9: return d == 0 ? 0.5 * ry : (d == 1 ? 0.5 * rx : 0.0);
+    case 10: return d == 1 ? 0.5 * rz : (d == 2 ? 0.5 * ry : 0.0);
+    default: return d == 2 ? 0.5 * rx : (d == 0 ? 0.5 * rz : 0.0);
+  }
+}
+constexpr int kDdmModes = 12;
+// A_c += Z_c^T S_c Z_c cell by cell: ONE wave per cell.  The cell's nodes fall into k <= 8 aggregates ("slots"); for every
+// slot s the wave forms T_s = S_c Z_s (m x 12, Z_s = the masked mode rows of the nodes in s, zero elsewhere) in LDS and then,
+// for every slot t whose aggregate number is not below s's, the 12 x 12 block Z_t^T T_s, added to A_c[agg_t][agg_s] - the
+// block LOWER triangle, which is what the factorisation reads; diagonal blocks are symmetrised (a surrogate S need not be
+// symmetric to the last bit).  Rows of fixed dofs are zero in Z: A_c is the Galerkin operator of P G P.
+__global__ __launch_bounds__(kWave) void k_ddm_coarse_cells(int64_t C, int nb, const int32_t *__restrict__ cell_nodes,
+                                                            const int32_t *__restrict__ cell_S,
+                                                            const double *__restrict__ St,
+                                                            const int32_t *__restrict__ agg_of_node,
+                                                            const double *__restrict__ cen,
+                                                            const double *__restrict__ xyz,
+                                                            const uint8_t *__restrict__ fixed /* [6N], may be null */,
+                                                            int ld, double *__restrict__ Ac) {
+  extern __shared__ double lds[];
+  const int m = 6 * nb;
+  double *Z = lds;                      // [m][12]
+  double *T = lds + m * kDdmModes;      // [m][12]
+  __shared__ int s_slot[32], s_agg[8], s_k;
+  const int64_t c = blockIdx.x;
+  if (c >= C) return;
+  const int lane = threadIdx.x;
+  const int32_t *nd = cell_nodes + c * nb;
+  if (lane == 0) {
+    int k = 0;
+    for (int i = 0; i < nb; ++i) {
+      const int a = agg_of_node[nd[i]];
+      int sl = -1;
+      for (int q = 0; q < k; ++q)
+        if (s_agg[q] == a) sl = q;
+      if (sl < 0 && k < 8) {
+        s_agg[k] = a;
+        sl = k++;
+      }
+      s_slot[i] = sl;                   // (-1: a ninth aggregate - cannot happen while aggregates are boxes at least a cell wide;
+    }                                   //  such a node is left out of the coarse operator, which stays SPD)
+    s_k = k;
+  }
+  for (int e = lane; e < m * kDdmModes; e += kWave) {
+    const int row = e / kDdmModes, q = e - row * kDdmModes, i = row / 6, d = row - 6 * i;
+    const int64_t n = nd[i];
+    const int a = agg_of_node[n];
+    double v = ddm_mode(q, d, xyz[3 * n] - cen[3 * a], xyz[3 * n + 1] - cen[3 * a + 1], xyz[3 * n + 2] - cen[3 * a + 2]);
+    if (fixed && fixed[6 * n + d]) v = 0.0;
+    Z[e] = v;
+  }
+  __syncthreads();
+  const int k = s_k;
+  const double *S = St + (size_t)cell_S[c] * m * m;              // St[col][row]
+  for (int s = 0; s < k; ++s) {
+    for (int e = lane; e < m * kDdmModes; e += kWave) {          // T_s[row][q], consecutive lanes = consecutive rows
+      const int q = e / m, row = e - q * m;
+      double acc = 0.0;
+      for (int j = 0; j < nb; ++j) {
+        if (s_slot[j] != s) continue;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) acc += S[(size_t)(6 * j + d) * m + row] * Z[(6 * j + d) * kDdmModes + q];
+      }
+      T[row * kDdmModes + q] = acc;
+    }
+    __syncthreads();
+    for (int t = 0; t < k; ++t) {
+      if (s_agg[t] < s_agg[s]) continue;
+      for (int e = lane; e < kDdmModes * kDdmModes; e += kWave) {
+        const int p = e / kDdmModes, q = e - p * kDdmModes;
+        double v = 0.0, w = 0.0;
+        for (int i = 0; i < nb; ++i) {
+          if (s_slot[i] != t) continue;
+#pragma unroll
+          for (int d = 0; d < 6; ++d) {
+            v += Z[(6 * i + d) * kDdmModes + p] * T[(6 * i + d) * kDdmModes + q];
+            if (t == s) w += Z[(6 * i + d) * kDdmModes + q] * T[(6 * i + d) * kDdmModes + p];
+          }
+        }
+        if (t == s) v = 0.5 * (v + w);
+        if (v != 0.0)
+          unsafeAtomicAdd(Ac + (size_t)(kDdmModes * s_agg[t] + p) * ld + kDdmModes * s_agg[s] + q, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+// r_c = Z^T r: one workgroup per aggregate over its node list (no atomics; r is zero on fixed dofs - the mask is applied
+// all the same, the modes of A_c are the masked ones)
+__global__ __launch_bounds__(kBlock) void k_ddm_restrict(const int32_t *__restrict__ agg_ptr,
+                                                         const int32_t *__restrict__ agg_nodes,
+                                                         const double *__restrict__ cen, const double *__restrict__ xyz,
+                                                         const uint8_t *__restrict__ fixed /* may be null */,
+                                                         const double *__restrict__ r, double *__restrict__ rc) {
+  __shared__ double red[kDdmModes][kBlock / kWave];
+  const int a = blockIdx.x;
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double acc[kDdmModes];
+#pragma unroll
+  for (int q = 0; q < kDdmModes; ++q) acc[q] = 0.0;
+  for (int e = agg_ptr[a] + (int)threadIdx.x; e < agg_ptr[a + 1]; e += kBlock) {
+    const int64_t n = agg_nodes[e];
+    double v[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) v[d] = (fixed && fixed[6 * n + d]) ? 0.0 : r[6 * n + d];
+    const double rx = xyz[3 * n] - c0, ry = xyz[3 * n + 1] - c1, rz = xyz[3 * n + 2] - c2;
+    acc[0] += v[0];
+    acc[1] += v[1];
+    acc[2] += v[2];
+    acc[3] += v[3] + (ry * v[2] - rz * v[1]);
+    acc[4] += v[4] + (rz * v[0] - rx * v[2]);
+    acc[5] += v[5] + (rx * v[1] - ry * v[0]);
+    acc[6] += rx * v[0];
+    acc[7] += ry * v[1];
+    acc[8] += rz * v[2];
+    acc[9] += 0.5 * (ry * v[0] + rx * v[1]);
+    acc[10] += 0.5 * (rz * v[1] + ry * v[2]);
+    acc[11] += 0.5 * (rz * v[0] + rx * v[2]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < kDdmModes; ++q) {
+    const double s = wave_sum(acc[q]);
+    if (lane == 0) red[q][wv] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kDdmModes) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) s += red[threadIdx.x][w];
+    rc[kDdmModes * a + threadIdx.x] = s;
+  }
+}
+// z = B^-1 r + P Z y_c node by node; dot_out[slot] += r . B^-1 r (the dense level's share r_c . y_c comes from its GEMV)
+__global__ __launch_bounds__(kBlock) void k_ddm_two_level_apply(int64_t N, const double *__restrict__ B,
+                                                                const int32_t *__restrict__ agg_of_node,
+                                                                const double *__restrict__ cen,
+                                                                const double *__restrict__ xyz,
+                                                                const uint8_t *__restrict__ fixed /* may be null */,
+                                                                const double *__restrict__ yc,
+                                                                const double *__restrict__ r, double *__restrict__ z,
+                                                                double *__restrict__ dot_out) {
+  __shared__ double red[kBlock / kWave];
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;     // one lane per row of a node block
+  double acc = 0.0;
+  if (t < 6 * N) {
+    const int64_t n = t / 6;
+    const int d = (int)(t - 6 * n);
+    const double *row = B + 6 * t;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v += row[j] * r[6 * n + j];
+    acc = v * r[t];
+    if (!(fixed && fixed[t])) {
+      const int a = agg_of_node[n];
+      const double *y = yc + kDdmModes * a;
+      const double rx = xyz[3 * n] - cen[3 * a], ry = xyz[3 * n + 1] - cen[3 * a + 1], rz = xyz[3 * n + 2] - cen[3 * a + 2];
+      double zc;
+      if (d >= 3) {
+        zc = y[d];
+      } else {
+        const double U[3] = {y[0] + (y[4] * rz - y[5] * ry), y[1] + (y[5] * rx - y[3] * rz), y[2] + (y[3] * ry - y[4] * rx)};
+        const double E[3] = {y[6] * rx + 0.5 * (y[9] * ry + y[11] * rz), y[7] * ry + 0.5 * (y[9] * rx + y[10] * rz),
+                             y[8] * rz + 0.5 * (y[10] * ry + y[11] * rx)};
+        zc = U[d] + E[d];
+      }
+      v += zc;
+    }
+    z[t] = v;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0 && dot_out) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+}
+
 }  // namespace pl

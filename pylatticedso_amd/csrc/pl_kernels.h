@@ -471,8 +471,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
                                                        const double *__restrict__ dinv, double *__restrict__ x,
                                                        double *__restrict__ r, double *__restrict__ z,
                                                        double *__restrict__ scal, double alpha_max,
-                                                       const double *__restrict__ pn) {
+                                                       const double *__restrict__ pn,
+                                                       const int *__restrict__ stop = nullptr /* see k_pcg_direction */) {
   __shared__ double red[4][kBlock / kWave];
+  if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // the iterate is final
   const double pap = scalar_read(scal, S_PAP);
   double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
   if (alpha_max > 0.0 && alpha > alpha_max) alpha = alpha_max;
@@ -529,10 +531,18 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(int64_t n6, const double 
 // reference CG that is the previous z (with a preconditioner) or the updated residual (without: z aliases r there).
 // hist_cap > 0: also record ||psrc||^2, ||x||^2 and the step length (slots filled by k_pcg_update<true>) behind the
 // residual history, at hist[hist_cap + k], hist[2 hist_cap + k], hist[3 hist_cap + k].
+// stop != null (DDM handles, round 5): the stopping rules of conjugate_gradient_solver.py:96-109 are evaluated HERE, on the
+// numbers the host would look at - ||r||^2 <= thresh, or (mintol > 0) ||p|| < mintol (||x|| + 1e-12) - and the first iteration
+// that meets one sets *stop = k + 1; from then on this kernel and k_pcg_update return at once, so the iterate stays exactly
+// where the reference's loop would have left it however many iterations the host had queued (it used to drain the stream
+// after EVERY iteration for that: ~190 us per iteration against 25 - 50 us of work).
 __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const double *__restrict__ z,
                                                           double *p, const double *__restrict__ scal,
                                                           double *__restrict__ scal_next, double *__restrict__ hist,
-                                                          int k, const double *psrc, int hist_cap) {
+                                                          int k, const double *psrc, int hist_cap,
+                                                          int *__restrict__ stop = nullptr, double thresh = 0.0,
+                                                          double mintol = 0.0) {
+  if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const double old = scalar_read(scal, S_RZ_OLD);
   const double beta = (old != 0.0) ? scalar_read(scal, S_RZ_NEW) / old : 0.0;
   if (blockIdx.x == 0 && threadIdx.x < kWave) {
@@ -550,6 +560,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_direction(int64_t n6, const doub
         hist[2 * hist_cap + k] = xx;
         hist[3 * hist_cap + k] = scal[S_ALPHA * kSlots];
       }
+      if (stop && (rr <= thresh || (hist_cap > 0 && mintol > 0.0 && sqrt(pp) < mintol * (sqrt(xx) + 1e-12))))
+        __hip_atomic_store(stop, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int q = s; q < kSlots; q += kWave) {
       scal_next[S_RZ_OLD * kSlots + q] = scal[S_RZ_NEW * kSlots + q];

@@ -97,6 +97,18 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
 
 // z = G^-1 r of a DDM handle (dense factor of the assembled matrix, or its inverted node blocks); dot[kSlots] += r.z
 inline void ddm_precondition(pl_context *c, double *dot) {
+  if (c->dd2_ready) {   // two-level: r_c = Z^T r, y_c = A_c^-1 r_c (dot += r_c . y_c), z = B^-1 r + P Z y_c (dot += r . B^-1 r)
+    pl::Coarse &cs = c->dd2;
+    const uint8_t *fx = c->have_bc ? (const uint8_t *)c->fixed.p : (const uint8_t *)nullptr;
+    hipLaunchKernelGGL(pl::k_ddm_restrict, dim3((unsigned)c->dd2_n_agg), dim3(pl::kBlock), 0, c->stream, c->dd2_ptr.p,
+                       c->dd2_nodes.p, (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx, (const double *)c->r.p,
+                       cs.rc);
+    pl::coarse_apply(cs, cs.rc, cs.tv, cs.yc, dot, (const double *)nullptr, c->stream);
+    hipLaunchKernelGGL(pl::k_ddm_two_level_apply, dim3(grid_for(c->N * 6)), dim3(pl::kBlock), 0, c->stream, c->N,
+                       (const double *)c->dd_B.p, c->dd2_agg.p, (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx,
+                       (const double *)cs.yc, (const double *)c->r.p, c->z.p, dot);
+    return;
+  }
   if (c->dd_ready)
     pl::dense_apply(c->dd_W.p, c->dd_Wt.p, c->dd_n, c->dd_n, c->r.p, c->dd_tv.p, c->z.p, dot, (const double *)nullptr,
                     c->stream);
@@ -243,17 +255,20 @@ int pcg_iteration(pl_context *c, int k) {
     }
   }
   const int hcap = ref ? c->hist_cap : 0;
+  int *stop = c->stop_use ? c->stop_flag.p : (int *)nullptr;     // (DDM handles: the device stops itself, k_pcg_direction)
+  const double stop_mintol = ref ? c->opt.mintol : 0.0;
   if (c->dd_ready || c->dd_blocks) {   // DDM with the factorised assembled matrix / its node blocks: update leaves z = 0,
                                        // r.z = 0; then z = G^-1 r
     if (ref)
       hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn, (const int *)stop);
     else
       hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
+                         c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr,
+                         (const int *)stop);
     ddm_precondition(c, cur + pl::S_RZ_NEW * pl::kSlots);
     hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
-                       c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
+                       c->p.p, cur, nxt, c->hist.p, k, psrc, hcap, stop, c->stop_thresh, stop_mintol);
     PL_HIP(hipGetLastError());
     return PL_OK;
   }
@@ -264,14 +279,15 @@ int pcg_iteration(pl_context *c, int k) {
       return fail(PL_ERR_HIP, "RCCL all-reduce of the PCG scalars failed");
   } else if (ref) {
     hipLaunchKernelGGL(pl::k_pcg_update<true>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn);
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, pn, (const int *)stop);
   } else {
     hipLaunchKernelGGL(pl::k_pcg_update<false>, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->p.p,
-                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr);
+                       c->Ap.p, c->dinv.p, c->x.p, c->r.p, c->z.p, cur, c->opt.alpha_max, (const double *)nullptr,
+                       (const int *)stop);
   }
   periodic_average(c, c->z.p);         // z = Q D^-1 r (r.z was summed with the un-averaged D^-1 r: the same number, r = Q r)
   hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
-                     c->p.p, cur, nxt, c->hist.p, k, psrc, hcap);
+                     c->p.p, cur, nxt, c->hist.p, k, psrc, hcap, stop, c->stop_thresh, stop_mintol);
   PL_HIP(hipGetLastError());
   return PL_OK;
 }
@@ -506,6 +522,14 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   const int chunk = adaptive ? 32 : c->opt.check_every;
   const bool ref = ref_cg(c) && !c->dist.active && !c->coarse.ready;
   const int hcap = c->hist_cap;
+  // DDM handles: the device applies the stopping rules itself and freezes the iterate (k_pcg_direction), so the host may
+  // queue as many iterations as it likes between two looks at the history and still hands back the reference's iterate
+  c->stop_use = c->opkind == 1 && !c->dist.active && !c->coarse.ready && !c->small_use;
+  if (c->stop_use) {
+    if (!c->stop_flag.p) PL_HIP(c->stop_flag.alloc(1));
+    PL_HIP(hipMemsetAsync(c->stop_flag.p, 0, sizeof(int), c->stream));
+    c->stop_thresh = thresh;
+  }
   // A design loop solves a slowly changing system over and over: the iteration count of the previous converged solve on
   // this handle (identical on every rank) is where the first look at the history is worth taking - three iterations
   // before it - instead of every 32 iterations on the way there (each look drains the stream: 30-50 us).
@@ -550,6 +574,7 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
           st->info = 2.0;
         }
       }
+      if (st->converged && c->stop_use) break;     // (the device stopped there too: later slots of the history are not written)
     }
     k += todo;
     if (st->converged) break;

@@ -347,9 +347,9 @@ class LatticeOpti(LatticeSim):
         bn = self._boundary_nodes_by_index()
         fixed = self.fixed_DOF[bn]
         dev.set_bc(fixed, None, np.where(fixed, 0.0, q_nodes[bn]))
-        if getattr(self, "_ddm_precond", 0) in (2, 3):
+        if getattr(self, "_ddm_precond", 0) in (2, 3, 4):
             # pl_set_bc drops what depends on the Dirichlet mask: the factorised assembled-Schur preconditioner (2) and the
-            # inverted node blocks (3; the handle is then "not assembled" and pl_solve refuses)
+            # inverted node blocks (3; with their dense level: 4) - the handle is then "not assembled" and pl_solve refuses
             dev.assemble()
         lam_b, _ = dev.solve(rtol=1e-10, max_iter=max(2000, self.number_iteration_max or 0))
         lam = np.zeros_like(self.displacement_vector)

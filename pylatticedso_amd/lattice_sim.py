@@ -35,6 +35,8 @@ from .timing import timing
 from .views import LatticeViews
 
 DDM_DENSE_MAX = 16384      # PL_DDM_DENSE_MAX of include/pylattice_hip.h
+DDM_LARGE_PRECOND = 4       # above it: 4 = node blocks + dense level on node aggregates (3 = the node blocks alone)
+DDM_COARSE_MAX_DOFS = 0     # size of that dense level (pl_opts_t.coarse_max_dofs; 0 = the library's default, 1 536)
 # device_model(): lattice sizes from which the handle is asked for the multi-level preconditioner + record palette, and for
 # fp32-stored PCG vectors with fp64 refinement (measured crossovers, DESIGN.md sections 7 / 7a)
 MULTILEVEL_MIN_NODES = 600
@@ -706,14 +708,21 @@ class LatticeSim(LatticeViews):
             # The device does the same (dense Cholesky, precond = 2) up to DDM_DENSE_MAX dofs; beyond that the CG gets
             # the node-block Jacobi preconditioner of the same matrix (its 6 x 6 diagonal blocks, inverted: same solution,
             # more iterations - a quarter fewer than with the diagonal alone).
+            # Round 5: above the dense limit the node blocks get a dense level on top (precond = 4: 12 rigid / strain modes
+            # per aggregate of boundary nodes, Galerkin operator from the cell matrices) - the iteration count then stops
+            # growing with the lattice (32^3 BCC cells: 2.2 x fewer iterations than the node blocks alone).
             self._ddm_precond = 0
+            xyz = None
             if self.enable_preconditioner:
-                self._ddm_precond = 2 if 6 * n_nodes <= DDM_DENSE_MAX else 3
+                self._ddm_precond = 2 if 6 * n_nodes <= DDM_DENSE_MAX else DDM_LARGE_PRECOND
+                if self._ddm_precond == 4:
+                    xyz = self.lattice.node_xyz[self._boundary_nodes_by_index()]
             # CG parameters of the reference's solve_DDM (lattice_sim.py:1156-1159): alpha clamp 100, direction-norm
             # stop 1e-12, restart every 500 000 iterations
             self._ddm_device = HipLattice.ddm(n_nodes, self.index_boundary[cb], self.schur_complements,
                                               self.cell_schur_index, precond=self._ddm_precond, alpha_max=100.0,
-                                              mintol=1e-12, restart_every=500000)
+                                              mintol=1e-12, restart_every=500000, node_xyz=xyz,
+                                              coarse_max_dofs=DDM_COARSE_MAX_DOFS)
             if self._ddm_precond == 2:
                 self.define_preconditioner()
         return self._ddm_device
@@ -804,10 +813,11 @@ class LatticeSim(LatticeViews):
         if not self.domain_decomposition_solver:
             raise ValueError("LatticeSim was not created with enable_domain_decomposition_solver=True")
         dev = self.ddm_model()
-        if self._ddm_precond in (1, 3) and not getattr(self, "_precond_note_done", False):
+        if self._ddm_precond in (1, 3, 4) and not getattr(self, "_precond_note_done", False):
             print(f"solve_DDM: {6 * (self.max_index_boundary + 1)} boundary dofs exceed the {DDM_DENSE_MAX} the device "
-                  "factorises densely for the assembled-Schur preconditioner; running CG preconditioned by its node blocks "
-                  "to the same tolerance (max_iterations of the preset then only applies if larger than 20000)")
+                  "factorises densely for the assembled-Schur preconditioner; running CG preconditioned by its node blocks"
+                  + (" and a dense level on aggregates of nodes" if self._ddm_precond == 4 else "") +
+                  " to the same tolerance (max_iterations of the preset then only applies if larger than 20000)")
             self._precond_note_done = True
         bn = self._boundary_nodes_by_index()
         fixed = self.fixed_DOF[bn]
@@ -818,11 +828,12 @@ class LatticeSim(LatticeViews):
         dev.set_bc(fixed, ubar, f)
         dev.assemble()
         b = np.where(fixed, 0.0, f - dev.spmv(ubar))
-        if np.linalg.norm(b) == 0:
+        if not b.any():       # (not np.linalg.norm: a threaded BLAS dot whose spinning worker threads starve the HIP runtime's
+                              #  helper threads - measured at 32^3 cells: 12 ms in the norm and +70 ms in every other solve)
             print("No external forces or imposed displacements in the lattice. Process aborted.")
             return None, None, None, None
         maxit = self.number_iteration_max or 1000
-        if self._ddm_precond in (1, 3):
+        if self._ddm_precond in (1, 3, 4):
             # presets written for the LU-preconditioned CG cap it at a handful of iterations; the block-Jacobi CG that
             # replaces it above the dense limit needs O(sqrt(cond)) of them to reach the same 1e-6
             maxit = max(maxit, 20000)

@@ -152,9 +152,10 @@ def test_mean_preconditioner_and_the_jacobi_fallback(golden_dir, capsys, monkeyp
     L3 = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
     xsol3, info3, _, _ = L3.solve_DDM()
     L3.solve_DDM()
-    assert L3._ddm_precond == 3 and info3 == 0 and L3.iteration > 10 and _rel(xsol3, g["xsol"]) < 1e-5
-    assert int(L3.ddm_model().last_stats["precond_used"]) == 3
-    assert L3.iteration < int(g["iterations"])            # the node blocks of the assembled matrix beat the plain CG count
+    # (round 5: above the dense limit the node blocks carry a dense level - here one aggregate of 45 nodes, 12 global modes)
+    assert L3._ddm_precond == 4 and info3 == 0 and L3.iteration > 10 and _rel(xsol3, g["xsol"]) < 1e-5
+    assert int(L3.ddm_model().last_stats["precond_used"]) == 4
+    assert L3.iteration < int(g["iterations"])            # ... and beat the plain CG count
     assert capsys.readouterr().out.count("exceed") == 1
     ddm.pop("preconditioner_type")
     with pytest.raises(ValueError):
@@ -262,3 +263,84 @@ def test_cell_product_on_the_matrix_pipe_for_every_cell_size(nb, monkeypatch):
             assert int(dev.time_kernel(0, 2) > 0)
     assert _rel(ys["1"], y_ref) < 1e-13
     assert _rel(ys["0"], y_ref) < 1e-13
+
+
+@pytest.mark.parametrize("cells", [(12, 6, 6), (8, 8, 8)])
+def test_two_level_preconditioner_of_the_ddm_operator(golden_dir, cells):
+    """opts.precond = 4 on a DDM handle (round 5): the node blocks of precond = 3 plus a dense level of 12 modes (rigid +
+    uniform strain) per aggregate of boundary nodes, A_c = Z^T P G P Z assembled from the cell matrices on the device.  Same
+    solution as plain CG and as the node blocks alone, clearly fewer iterations than the node blocks, pl_stats_t.precond_used
+    says 4; the level follows a changed Dirichlet set; a handle without node positions refuses to assemble."""
+    g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    preset["geometry"]["number_of_cells"] = dict(x=cells[0], y=cells[1], z=cells[2])
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+    L.set_cell_radii(0.034 + 0.03 * L.lattice.cell_pos[:, 0] / (cells[0] - 1.0))
+    L.ddm_model()
+    cb = L.cell_boundary_nodes()
+    n_nodes = L.max_index_boundary + 1
+    nodes = L.index_boundary[cb]
+    bn = L._boundary_nodes_by_index()
+    fixed = L.fixed_DOF[bn]
+    f = L.applied_force[bn]
+    xyz = L.lattice.node_xyz[bn]
+    out = {}
+    for pre in (0, 3, 4):
+        with _capi.HipLattice.ddm(n_nodes, nodes, L.schur_complements, L.cell_schur_index, precond=pre,
+                                  node_xyz=xyz if pre == 4 else None) as dev:
+            dev.set_bc(fixed, None, f)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-10, max_iter=20000)
+            assert st["converged"] == 1 and int(st["precond_used"]) == pre
+            r = np.where(fixed, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(np.where(fixed, 0.0, f))
+            out[pre] = (u, st["iterations"])
+            if pre == 4:
+                fixed2 = fixed.copy()
+                fixed2[np.argmax(f[:, 2] != 0)] = 1
+                dev.set_bc(fixed2, None, f)
+                dev.assemble()
+                u2, st2 = dev.solve(rtol=1e-10, max_iter=20000)
+                assert st2["converged"] == 1 and int(st2["precond_used"]) == 4 and np.all(u2[fixed2 != 0] == 0.0)
+                r2 = np.where(fixed2, 0.0, f - dev.spmv(u2))
+                assert np.linalg.norm(r2) <= 2e-10 * np.linalg.norm(np.where(fixed2, 0.0, f))
+                # a second solve on the same factorisation, other load
+                f3 = np.zeros_like(f)
+                f3[np.isclose(xyz[:, 0], xyz[:, 0].max()), 1] = 1e-3
+                dev.set_bc(fixed, None, f3)
+                dev.assemble()
+                u3, st3 = dev.solve(rtol=1e-10, max_iter=20000)
+                assert st3["converged"] == 1
+                r3 = np.where(fixed, 0.0, f3 - dev.spmv(u3))
+                assert np.linalg.norm(r3) <= 2e-10 * np.linalg.norm(np.where(fixed, 0.0, f3))
+    assert _rel(out[4][0], out[0][0]) < 1e-7 and _rel(out[3][0], out[0][0]) < 1e-7
+    assert out[4][1] < 0.8 * out[3][1], (out[4][1], out[3][1])
+    with pytest.raises(ValueError):
+        _capi.HipLattice.ddm(n_nodes, nodes, L.schur_complements, L.cell_schur_index, precond=4)
+    with pytest.raises(ValueError):
+        with _capi.HipLattice.ddm(n_nodes, nodes, L.schur_complements, L.cell_schur_index, precond=3) as dev:
+            dev.set_ddm_geometry(xyz[:-1])                  # one position per node
+
+
+def test_solve_ddm_above_the_dense_limit_uses_the_two_level_preconditioner(golden_dir, capsys):
+    """LatticeSim.solve_DDM with enable_preconditioner beyond PL_DDM_DENSE_MAX boundary dofs: the handle is created with
+    precond = 4 and the positions of the boundary nodes; the solution equals the one the node blocks alone give
+    (DDM_LARGE_PRECOND = 3) to the CG tolerance, in fewer iterations."""
+    import pylatticedso_amd.lattice_sim as LS
+    g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    preset["geometry"]["number_of_cells"] = dict(x=16, y=14, z=12)          # 17 * 15 * 13 * 6 = 19 890 boundary dofs
+    preset["simulation_parameters"]["DDM"].update(enable_preconditioner=True, preconditioner_type="exact")
+    res = {}
+    for pre in (4, 3):
+        LS.DDM_LARGE_PRECOND = pre
+        try:
+            L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+            xsol, info, idx, b = L.solve_DDM()
+        finally:
+            LS.DDM_LARGE_PRECOND = 4
+        assert info == 0 and L._ddm_precond == pre and int(L.ddm_model().last_stats["precond_used"]) == pre
+        res[pre] = (xsol, L.iteration)
+    assert "dense level on aggregates" in capsys.readouterr().out
+    assert _rel(res[4][0], res[3][0]) < 2e-5                  # (both stop at the reference's 1e-6)
+    assert res[4][1] < 0.8 * res[3][1], (res[4][1], res[3][1])

@@ -3,7 +3,7 @@ diagonal, by the 6 x 6 node blocks, and by either plus a rigid-body (6) or rigid
 agg^3 cells.  Usage: python tools/experiments/ddm_two_level_host.py [n = 12] [agg = 4]"""
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl, sys, time
 n=int(sys.argv[1]) if len(sys.argv)>1 else 12
-agg=int(sys.argv[2]) if len(sys.argv)>2 else 4
+agg=float(sys.argv[2]) if len(sys.argv)>2 else 4.0
 d=np.load('/root/repo/tests/golden/Schur_complement_BCC.npz')
 S=d['schur_matrices'][4]   # r=0.05
 S=0.5*(S+S.T)

@@ -12,6 +12,11 @@ sys.path.insert(0, ROOT)
 from pylatticedso_amd.lattice_sim import LatticeSim  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+if len(sys.argv) > 2:            # preconditioner above the dense limit: 4 (node blocks + dense level, default) or 3 (node blocks)
+    import pylatticedso_amd.lattice_sim as LS
+    LS.DDM_LARGE_PRECOND = int(sys.argv[2])
+    if len(sys.argv) > 3:
+        LS.DDM_COARSE_MAX_DOFS = int(sys.argv[3])
 preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": n, "y": n, "z": n},
                        "radii": [0.05], "geom_types": ["BCC"]},
           "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False,
@@ -31,7 +36,19 @@ dev = L.ddm_model()
 out = {"cells": L.lattice.n_cells, "boundary_nodes": int(L.max_index_boundary + 1), "free_dofs": len(xsol),
        "setup_s": t1 - t0, "solve_ddm_s": t2 - t1, "cg_iterations": L.iteration, "info": info,
        "operator_ms": dev.time_kernel(0, 50), "cg_iteration_ms": dev.time_kernel(3, 50),
-       "preconditioner": {0: "none", 1: "Jacobi (above the dense limit)", 2: "assembled Schur, dense Cholesky"}[L._ddm_precond]}
+       "preconditioner": {0: "none", 1: "Jacobi (above the dense limit)", 2: "assembled Schur, dense Cholesky",
+                          3: "node blocks (above the dense limit)",
+                          4: "node blocks + dense level on node aggregates (above the dense limit)"}[L._ddm_precond]}
+st = dev.last_stats
+out["device_solve_ms"], out["device_assembly_ms"] = st["ms_solve"], st["ms_assembly"]
+reps = []
+for _ in range(5):               # the same solve again: set_bc + assemble (preconditioner set-up) + solve, device times
+    t3 = time.perf_counter()
+    L.solve_DDM()
+    s2 = dev.last_stats
+    reps.append((time.perf_counter() - t3, s2["ms_assembly"], s2["ms_solve"], s2["iterations"]))
+out["repeat_solve_ddm"] = {"wall_ms": [round(1e3 * r[0], 2) for r in reps], "device_assembly_ms": [round(r[1], 3) for r in reps],
+                           "device_solve_ms": [round(r[2], 3) for r in reps], "iterations": [int(r[3]) for r in reps]}
 m = 48
 out["operator_algorithmic_MB"] = (L.lattice.n_cells * (8 * 4 + 4) + 2 * 6 * 8 * out["boundary_nodes"]) / 1e6
 out["operator_staging_MB"] = 2 * L.lattice.n_cells * m * 8 / 1e6
