@@ -1092,7 +1092,12 @@ int pl_assemble(pl_handle h) {
                            h->ddm_have_P ? h->ddm_Pt.p : h->ddm_St.p, h->dd2_agg.p, h->dd2_cen.p, h->dd2_xyz.p,
                            h->have_bc ? (const uint8_t *)h->fixed.p : (const uint8_t *)nullptr, n, cs.Ac);
         hipLaunchKernelGGL(pl::k_coarse_regularize, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cs.Ac);
-        pl::coarse_factor(cs, n, h->stream, nullptr, (unsigned *)nullptr);
+        pl::TrtriPhases ph;          // the inverse factor in row ranges on a second stream, behind the chain (as pl_assembly.h)
+        ph.rows = 3;
+        ph.stream = h->side2;
+        ph.ev_go = h->ev_t0;
+        ph.ev_done = h->ev_t1;
+        pl::coarse_factor(cs, n, h->stream, nullptr, (unsigned *)nullptr, ph);
         cs.ainv_ready = false;
         if (cs.Ainv) {
           const long tiles = (long)(n / 32) * (n / 32 + 1) / 2;

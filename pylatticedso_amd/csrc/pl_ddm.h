@@ -287,17 +287,31 @@ __global__ __launch_bounds__(kBlock) void k_ddm_cell_product_mfma(int64_t n_tile
   }
 }
 
+// (fixed != null: rows of constrained dofs come out as zero; dot_out != null: dot_out[slot] += x . y - what k_mask_dot did
+// in a launch of its own until round 5: 4.8 us of the 54-us iteration at 32^3 cells)
 __global__ __launch_bounds__(kBlock) void k_ddm_node_gather(int64_t N, const int64_t *__restrict__ node_ptr,
                                                             const int32_t *__restrict__ node_ent,
                                                             const double *__restrict__ stage,
-                                                            double *__restrict__ y) {
+                                                            double *__restrict__ y,
+                                                            const uint8_t *__restrict__ fixed = nullptr,
+                                                            const double *__restrict__ x = nullptr,
+                                                            double *__restrict__ dot_out = nullptr) {
+  __shared__ double red[kBlock / kWave];
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= 6 * N) return;
-  const int64_t n = t / 6;
-  const int k = (int)(t - 6 * n);
-  double acc = 0.0;
-  for (int64_t q = node_ptr[n]; q < node_ptr[n + 1]; ++q) acc += stage[6 * (int64_t)node_ent[q] + k];
-  y[t] = acc;
+  double part = 0.0;
+  if (t < 6 * N) {
+    const int64_t n = t / 6;
+    const int k = (int)(t - 6 * n);
+    double acc = 0.0;
+    for (int64_t q = node_ptr[n]; q < node_ptr[n + 1]; ++q) acc += stage[6 * (int64_t)node_ent[q] + k];
+    if (fixed && fixed[t]) acc = 0.0;
+    y[t] = acc;
+    if (dot_out) part = x[t] * acc;
+  }
+  if (dot_out) {                       // (uniform over the launch)
+    const double s = block_sum(part, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_out + (blockIdx.x & (kSlots - 1)), s);
+  }
 }
 
 // diag(sum_c B_c^T S_c B_c): the Jacobi preconditioner offered in place of the reference's SuperLU factorisation of
@@ -491,15 +505,21 @@ __global__ __launch_bounds__(kWave) void k_ddm_coarse_cells(int64_t C, int nb, c
   const int k = s_k;
   const double *S = St + (size_t)cell_S[c] * m * m;              // St[col][row]
   for (int s = 0; s < k; ++s) {
-    for (int e = lane; e < m * kDdmModes; e += kWave) {          // T_s[row][q], consecutive lanes = consecutive rows
-      const int q = e / m, row = e - q * m;
-      double acc = 0.0;
-      for (int j = 0; j < nb; ++j) {
+    for (int row = lane; row < m; row += kWave) {                // T_s[row][0..11]: a lane owns a row, so every entry of S is
+      double acc[kDdmModes];                                     // read ONCE per slot (coalesced over the rows) and meets the
+#pragma unroll                                                   // twelve mode values of its column, which all lanes read at
+      for (int q = 0; q < kDdmModes; ++q) acc[q] = 0.0;          // the same LDS address (first version: one lane per (row, mode),
+      for (int j = 0; j < nb; ++j) {                             // S read twelve times - 700 us at 32^3 cells)
         if (s_slot[j] != s) continue;
+        for (int d = 0; d < 6; ++d) {
+          const double sv = S[(size_t)(6 * j + d) * m + row];
+          const double *zr = Z + (6 * j + d) * kDdmModes;
 #pragma unroll
-        for (int d = 0; d < 6; ++d) acc += S[(size_t)(6 * j + d) * m + row] * Z[(6 * j + d) * kDdmModes + q];
+          for (int q = 0; q < kDdmModes; ++q) acc[q] += sv * zr[q];
+        }
       }
-      T[row * kDdmModes + q] = acc;
+#pragma unroll
+      for (int q = 0; q < kDdmModes; ++q) T[row * kDdmModes + q] = acc[q];
     }
     __syncthreads();
     for (int t = 0; t < k; ++t) {
@@ -569,6 +589,115 @@ __global__ __launch_bounds__(kBlock) void k_ddm_restrict(const int32_t *__restri
     rc[kDdmModes * a + threadIdx.x] = s;
   }
 }
+// The CG update of an iteration and the restriction of the NEW residual in one pass over the nodes, aggregate by aggregate:
+// x += alpha p, r -= alpha K p (alpha from the scalar set, clamped as k_pcg_update does), r.r (and, REF, x.x and the norm of
+// the vector the next direction is built on) into the scalar set, r_c += Z^T r.  kDdmSplit workgroups share an aggregate (a
+// launch of one workgroup per aggregate leaves half the chip idle), so r_c is summed atomically: the caller's previous
+// k_ddm_two_level_apply has cleared it.  What it replaces: k_pcg_update + k_ddm_restrict, 6.2 + 7.0 us at 32^3 cells.
+constexpr int kDdmSplit = 4;
+template <bool REF>
+__global__ __launch_bounds__(kBlock) void k_ddm_update_restrict(const int32_t *__restrict__ agg_ptr,
+                                                                const int32_t *__restrict__ agg_nodes,
+                                                                const double *__restrict__ cen,
+                                                                const double *__restrict__ xyz,
+                                                                const uint8_t *__restrict__ fixed /* may be null */,
+                                                                const double *__restrict__ p, const double *__restrict__ Ap,
+                                                                double *__restrict__ x, double *__restrict__ r,
+                                                                double *__restrict__ scal, double alpha_max,
+                                                                const double *__restrict__ pn /* REF: may be null */,
+                                                                const int *__restrict__ stop /* may be null */,
+                                                                double *__restrict__ rc) {
+  __shared__ double red[kDdmModes + 3][kBlock / kWave];
+  if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // the iterate is final
+  const double pap = scalar_read(scal, S_PAP);
+  double alpha = (pap != 0.0) ? scalar_read(scal, S_RZ_OLD) / pap : 0.0;
+  if (alpha_max > 0.0 && alpha > alpha_max) alpha = alpha_max;
+  if (REF && blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA * kSlots] = alpha;
+  const int a = blockIdx.x / kDdmSplit, part = blockIdx.x - a * kDdmSplit;
+  const double c0 = cen[3 * a], c1 = cen[3 * a + 1], c2 = cen[3 * a + 2];
+  double acc[kDdmModes];
+#pragma unroll
+  for (int q = 0; q < kDdmModes; ++q) acc[q] = 0.0;
+  double rr = 0.0, xx = 0.0, pp = 0.0;
+  // one lane per PAIR of a node's dofs (three lanes per node: 48 contiguous bytes of every vector), each adding its share of
+  // the twelve restriction sums (one lane per node left three quarters of a workgroup idle: 16.7 us against 9 us)
+  const int e0 = agg_ptr[a], cnt3 = 3 * (agg_ptr[a + 1] - e0);
+  for (int j = part * kBlock + (int)threadIdx.x; j < cnt3; j += kDdmSplit * kBlock) {
+    const int e = j / 3, h = j - 3 * e;
+    const int64_t n = agg_nodes[e0 + e], i2 = 3 * n + h;
+    const double2 pv = reinterpret_cast<const double2 *>(p)[i2], av = reinterpret_cast<const double2 *>(Ap)[i2];
+    double2 xv = reinterpret_cast<double2 *>(x)[i2], rv = reinterpret_cast<double2 *>(r)[i2];
+    xv.x += alpha * pv.x;
+    xv.y += alpha * pv.y;
+    rv.x -= alpha * av.x;
+    rv.y -= alpha * av.y;
+    reinterpret_cast<double2 *>(x)[i2] = xv;
+    reinterpret_cast<double2 *>(r)[i2] = rv;
+    rr += rv.x * rv.x + rv.y * rv.y;
+    if (REF) {
+      xx += xv.x * xv.x + xv.y * xv.y;
+      if (pn) {
+        const double2 q = reinterpret_cast<const double2 *>(pn)[i2];
+        pp += q.x * q.x + q.y * q.y;
+      }
+    }
+    const double v0 = (fixed && fixed[6 * n + 2 * h]) ? 0.0 : rv.x, v1 = (fixed && fixed[6 * n + 2 * h + 1]) ? 0.0 : rv.y;
+    const double rx = xyz[3 * n] - c0, ry = xyz[3 * n + 1] - c1, rz = xyz[3 * n + 2] - c2;
+    if (h == 0) {            // (u_x, u_y)
+      acc[0] += v0;
+      acc[1] += v1;
+      acc[3] -= rz * v1;
+      acc[4] += rz * v0;
+      acc[5] += rx * v1 - ry * v0;
+      acc[6] += rx * v0;
+      acc[7] += ry * v1;
+      acc[9] += 0.5 * (ry * v0 + rx * v1);
+      acc[10] += 0.5 * rz * v1;
+      acc[11] += 0.5 * rz * v0;
+    } else if (h == 1) {     // (u_z, theta_x)
+      acc[2] += v0;
+      acc[3] += v1 + ry * v0;
+      acc[4] -= rx * v0;
+      acc[8] += rz * v0;
+      acc[10] += 0.5 * ry * v0;
+      acc[11] += 0.5 * rx * v0;
+    } else {                 // (theta_y, theta_z)
+      acc[4] += v0;
+      acc[5] += v1;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < kDdmModes; ++q) {
+    const double s = wave_sum(acc[q]);
+    if (lane == 0) red[q][wv] = s;
+  }
+  {
+    const double s0 = wave_sum(rr), s1 = wave_sum(xx), s2 = wave_sum(pp);
+    if (lane == 0) {
+      red[kDdmModes][wv] = s0;
+      red[kDdmModes + 1][wv] = s1;
+      red[kDdmModes + 2][wv] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kDdmModes + 3) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) s += red[threadIdx.x][w];
+    const int q = threadIdx.x;
+    if (q < kDdmModes) {
+      if (s != 0.0) unsafeAtomicAdd(rc + kDdmModes * a + q, s);
+    } else if (q == kDdmModes) {
+      scalar_add(scal, S_RR, s);
+      if (REF && !pn) scalar_add(scal, S_PP, s);      // (no separate source vector: ||r_new||, as k_pcg_update)
+    } else if (REF && q == kDdmModes + 1) {
+      scalar_add(scal, S_XX, s);
+    } else if (REF && pn) {
+      scalar_add(scal, S_PP, s);
+    }
+  }
+}
 // z = B^-1 r + P Z y_c node by node; dot_out[slot] += r . B^-1 r (the dense level's share r_c . y_c comes from its GEMV)
 __global__ __launch_bounds__(kBlock) void k_ddm_two_level_apply(int64_t N, const double *__restrict__ B,
                                                                 const int32_t *__restrict__ agg_of_node,
@@ -577,8 +706,12 @@ __global__ __launch_bounds__(kBlock) void k_ddm_two_level_apply(int64_t N, const
                                                                 const uint8_t *__restrict__ fixed /* may be null */,
                                                                 const double *__restrict__ yc,
                                                                 const double *__restrict__ r, double *__restrict__ z,
-                                                                double *__restrict__ dot_out) {
+                                                                double *__restrict__ dot_out,
+                                                                double *__restrict__ rc_clear = nullptr, int n_rc = 0) {
   __shared__ double red[kBlock / kWave];
+  // (the dense solve has consumed r_c: cleared here for the atomic sums of the next k_ddm_update_restrict)
+  if (rc_clear && (blockIdx.x == 1 || gridDim.x == 1))
+    for (int e = threadIdx.x; e < n_rc; e += kBlock) rc_clear[e] = 0.0;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;     // one lane per row of a node block
   double acc = 0.0;
   if (t < 6 * N) {

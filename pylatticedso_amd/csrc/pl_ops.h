@@ -211,10 +211,8 @@ int launch_spmv(pl_context *c, const double *x, double *y, bool masked, double *
                          c->ddm_stage.p);
 #undef PL_DM
     hipLaunchKernelGGL(pl::k_ddm_node_gather, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
-                       c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y);
-    if (masked || dot_dev)
-      hipLaunchKernelGGL(pl::k_mask_dot, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, n6,
-                         masked ? c->fixed.p : (const uint8_t *)nullptr, x, y, dot_dev);
+                       c->ddm_node_ptr.p, c->ddm_node_ent.p, (const double *)c->ddm_stage.p, y,
+                       masked ? (const uint8_t *)c->fixed.p : (const uint8_t *)nullptr, x, dot_dev);
     PL_HIP(hipGetLastError());
     return PL_OK;
   }

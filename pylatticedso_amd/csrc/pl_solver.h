@@ -96,17 +96,19 @@ int pcg_tail_coarse(pl_context *c, double *cur, double *nxt, int hist_slot) {
 }
 
 // z = G^-1 r of a DDM handle (dense factor of the assembled matrix, or its inverted node blocks); dot[kSlots] += r.z
-inline void ddm_precondition(pl_context *c, double *dot) {
+// (restricted = true: r_c already holds Z^T r - the iteration's fused update has summed it, k_ddm_update_restrict)
+inline void ddm_precondition(pl_context *c, double *dot, bool restricted = false) {
   if (c->dd2_ready) {   // two-level: r_c = Z^T r, y_c = A_c^-1 r_c (dot += r_c . y_c), z = B^-1 r + P Z y_c (dot += r . B^-1 r)
     pl::Coarse &cs = c->dd2;
     const uint8_t *fx = c->have_bc ? (const uint8_t *)c->fixed.p : (const uint8_t *)nullptr;
-    hipLaunchKernelGGL(pl::k_ddm_restrict, dim3((unsigned)c->dd2_n_agg), dim3(pl::kBlock), 0, c->stream, c->dd2_ptr.p,
-                       c->dd2_nodes.p, (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx, (const double *)c->r.p,
-                       cs.rc);
+    if (!restricted)
+      hipLaunchKernelGGL(pl::k_ddm_restrict, dim3((unsigned)c->dd2_n_agg), dim3(pl::kBlock), 0, c->stream, c->dd2_ptr.p,
+                         c->dd2_nodes.p, (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx,
+                         (const double *)c->r.p, cs.rc);
     pl::coarse_apply(cs, cs.rc, cs.tv, cs.yc, dot, (const double *)nullptr, c->stream);
     hipLaunchKernelGGL(pl::k_ddm_two_level_apply, dim3(grid_for(c->N * 6)), dim3(pl::kBlock), 0, c->stream, c->N,
                        (const double *)c->dd_B.p, c->dd2_agg.p, (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx,
-                       (const double *)cs.yc, (const double *)c->r.p, c->z.p, dot);
+                       (const double *)cs.yc, (const double *)c->r.p, c->z.p, dot, cs.rc, cs.ncp);
     return;
   }
   if (c->dd_ready)
@@ -257,6 +259,24 @@ int pcg_iteration(pl_context *c, int k) {
   const int hcap = ref ? c->hist_cap : 0;
   int *stop = c->stop_use ? c->stop_flag.p : (int *)nullptr;     // (DDM handles: the device stops itself, k_pcg_direction)
   const double stop_mintol = ref ? c->opt.mintol : 0.0;
+  if (c->dd2_ready) {                  // two-level DDM preconditioner: update and restriction in one pass over the aggregates
+    const uint8_t *fx = c->have_bc ? (const uint8_t *)c->fixed.p : (const uint8_t *)nullptr;
+    const dim3 g((unsigned)(c->dd2_n_agg * pl::kDdmSplit));
+    if (ref)
+      hipLaunchKernelGGL(pl::k_ddm_update_restrict<true>, g, dim3(pl::kBlock), 0, c->stream, c->dd2_ptr.p, c->dd2_nodes.p,
+                         (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx, (const double *)c->p.p,
+                         (const double *)c->Ap.p, c->x.p, c->r.p, cur, c->opt.alpha_max, pn, (const int *)stop, c->dd2.rc);
+    else
+      hipLaunchKernelGGL(pl::k_ddm_update_restrict<false>, g, dim3(pl::kBlock), 0, c->stream, c->dd2_ptr.p, c->dd2_nodes.p,
+                         (const double *)c->dd2_cen.p, (const double *)c->dd2_xyz.p, fx, (const double *)c->p.p,
+                         (const double *)c->Ap.p, c->x.p, c->r.p, cur, c->opt.alpha_max, (const double *)nullptr,
+                         (const int *)stop, c->dd2.rc);
+    ddm_precondition(c, cur + pl::S_RZ_NEW * pl::kSlots, true);
+    hipLaunchKernelGGL(pl::k_pcg_direction, dim3(grid_stream(n6 / 2)), dim3(pl::kBlock), 0, c->stream, n6, c->z.p,
+                       c->p.p, cur, nxt, c->hist.p, k, psrc, hcap, stop, c->stop_thresh, stop_mintol);
+    PL_HIP(hipGetLastError());
+    return PL_OK;
+  }
   if (c->dd_ready || c->dd_blocks) {   // DDM with the factorised assembled matrix / its node blocks: update leaves z = 0,
                                        // r.z = 0; then z = G^-1 r
     if (ref)

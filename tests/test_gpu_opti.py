@@ -256,9 +256,10 @@ def test_ddm_objective_and_gradient_match_the_reference(golden_dir, case):
 
 
 def test_ddm_adjoint_with_node_block_preconditioner(golden_dir, monkeypatch):
-    """Displacement objective on a DDM lattice whose boundary dofs exceed DDM_DENSE_MAX (node-block Jacobi, precond = 3):
-    pl_set_bc drops the inverted node blocks, so the adjoint solve must re-assemble before it solves (round-4 advisor finding:
-    PL_ERR_STATE 'call pl_assemble first').  Same gradient as with the dense assembled-Schur preconditioner."""
+    """Displacement objective on a DDM lattice whose boundary dofs exceed DDM_DENSE_MAX (node-block Jacobi, precond = 3; with
+    its dense level on node aggregates, precond = 4, the default since round 5): pl_set_bc drops what depends on the Dirichlet
+    mask, so the adjoint solve must re-assemble before it solves (round-4 advisor finding: PL_ERR_STATE 'call pl_assemble
+    first').  Same gradient as with the dense assembled-Schur preconditioner."""
     import json
     import os
     from pylatticedso_amd import lattice_sim as LS
@@ -266,18 +267,21 @@ def test_ddm_adjoint_with_node_block_preconditioner(golden_dir, monkeypatch):
     case = "unit_cell_displacement"
     x = list(g[f"{case}_x"])
     grads = []
-    for dense_max in (LS.DDM_DENSE_MAX, 100):
+    for dense_max, large in ((LS.DDM_DENSE_MAX, 4), (100, 3), (100, 4)):
         monkeypatch.setattr(LS, "DDM_DENSE_MAX", dense_max)
+        monkeypatch.setattr(LS, "DDM_LARGE_PRECOND", large)
         L = LatticeOpti(json.loads(str(g[f"{case}_preset_json"])), data_roots=[golden_dir])
         L._initialize_optimization_solver()
         L.objective(x)
-        assert L._ddm_precond == (2 if dense_max > 100 else 3)
+        assert L._ddm_precond == (2 if dense_max > 100 else large)
         grads.append(np.asarray(L.gradient(x)))
         grads.append(np.asarray(L.gradient(x)))          # and again: the handle must survive the adjoint's pl_set_bc
         L.objective(x)
-    assert np.isfinite(grads[2]).all()
-    assert np.linalg.norm(grads[2] - grads[0]) < 1e-6 * np.linalg.norm(grads[0])
-    assert np.linalg.norm(grads[3] - grads[2]) < 1e-9 * np.linalg.norm(grads[2])
+        assert int(L.ddm_model().last_stats["precond_used"]) == L._ddm_precond
+    for k in (2, 4):
+        assert np.isfinite(grads[k]).all()
+        assert np.linalg.norm(grads[k] - grads[0]) < 1e-6 * np.linalg.norm(grads[0])
+        assert np.linalg.norm(grads[k + 1] - grads[k]) < 1e-9 * np.linalg.norm(grads[k])
 
 
 def test_ddm_optimisation_with_exact_schur_complements():
