@@ -394,17 +394,32 @@ def drop_in_optimisation():
     from pylatticedso_amd.lattice_sim import open_lattice_parameters
     from pylatticedso_amd.timing import timing
     out = {}
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
     cases = {"optimization/optimization_beam_flexion": {},
              "optimization_beam_flexion, unit_cell parameterisation (54 design variables)":
-                 {"base": "optimization/optimization_beam_flexion", "optimization_parameters": {"type": "unit_cell", "hybrid": False}}}
+                 {"base": "optimization/optimization_beam_flexion", "optimization_parameters": {"type": "unit_cell", "hybrid": False}},
+             # simulation_type "DDM" (what most of the reference's optimisation presets use): the reference's preset with BCC
+             # cells only - the RBF surrogate of its three-geometry cells is one of the reference's absent large files, the BCC
+             # one is a committed fixture - on the 5 x 1 x 1 cells of the preset and on a 12 x 4 x 4 lattice
+             "optimization/optimization_DDM_surrogate, BCC cells (5 design variables)":
+                 {"base": "optimization/optimization_DDM_surrogate", "geometry": {"geom_types": ["BCC"], "radii": [0.05]},
+                  "ddm": {"preconditioner_type": "exact"}, "data_roots": [golden]},
+             "optimization_DDM_surrogate, BCC cells, 12 x 4 x 4 (192 design variables)":
+                 {"base": "optimization/optimization_DDM_surrogate",
+                  "geometry": {"geom_types": ["BCC"], "radii": [0.05], "number_of_cells": {"x": 12, "y": 4, "z": 4}},
+                  "ddm": {"preconditioner_type": "exact"}, "data_roots": [golden]}}
     for name, over in cases.items():
         preset = copy.deepcopy(open_lattice_parameters(over.get("base", name)))
         for k, v in over.items():
-            if k != "base":
+            if k == "geometry":
+                preset["geometry"].update(v)
+            elif k == "ddm":
+                preset["simulation_parameters"]["DDM"].update(v)
+            elif k not in ("base", "data_roots"):
                 preset["optimization_informations"][k] = v
         timing.reset()
         t0 = time.perf_counter()
-        L = LatticeOpti(preset, verbose=0, convergence_plotting=False)
+        L = LatticeOpti(preset, verbose=0, convergence_plotting=False, **({"data_roots": over["data_roots"]} if "data_roots" in over else {}))
         t1 = time.perf_counter()
         sol = L.optimize_lattice()
         t2 = time.perf_counter()
@@ -415,6 +430,7 @@ def drop_in_optimisation():
                      "optimize_s": t2 - t1, "s_per_slsqp_iteration": (t2 - t1) / nit, "device_s": dev_s,
                      "device_s_per_slsqp_iteration": dev_s / nit, "host_s_per_slsqp_iteration": (t2 - t1 - dev_s) / nit,
                      "struts": int(L.lattice.n_beams), "design_variables": int(L.number_parameters),
+                     "simulation_type": "DDM" if getattr(L, "_ddm_mode", False) else "FEM",
                      "final_objective": float(L.denorm_objective), "success": bool(sol.success)}
     return out
 

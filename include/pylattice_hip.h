@@ -238,6 +238,12 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
 int pl_ddm_set_preconditioner(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/,
                               const int32_t *cell_S /*[n_cells]*/);
 
+/* New cell matrices on an existing DDM handle (round 5): a design loop changes every S_c between two solves
+ * (LatticeOpti.set_optimization_parameters -> reset_cell_with_new_radii, lattice_opti.py:467-560, lattice_sim.py:1421-1497) while
+ * the cells keep their nodes.  S / cell_S as in pl_create_ddm (same nb; n_S may differ).  The handle's preconditioner data is
+ * dropped: pl_assemble before the next pl_solve.  A palette installed by pl_ddm_set_preconditioner stays. */
+int pl_ddm_update_matrices(pl_handle h, int32_t n_S, const double *S /*[n_S][6nb][6nb]*/, const int32_t *cell_S /*[n_cells]*/);
+
 /* Beyond PL_DDM_DENSE_MAX dofs (round 5): opts->precond = 4 on a DDM handle = the node blocks of precond = 3 plus a dense
  * level, M^-1 = B^-1 + Z A_c^-1 Z^T with A_c = Z^T P G P Z - twelve modes (six rigid-body motions, six uniform strains) per
  * aggregate of boundary nodes, aggregates = boxes of a regular grid over the nodes' bounding box, as many as

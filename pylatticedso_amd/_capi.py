@@ -19,7 +19,7 @@ PL_OK, PL_ERR_ARG, PL_ERR_HIP, PL_ERR_STATE, PL_ERR_NOCONV, PL_ERR_NAN, PL_ERR_N
 
 # every symbol include/pylattice_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = ["pl_default_opts", "pl_opts_size", "pl_stats_size", "pl_abi_version", "pl_last_error", "pl_version", "pl_lzone", "pl_create", "pl_create_ddm",
-           "pl_ddm_set_preconditioner", "pl_ddm_set_geometry", "pl_destroy", "pl_set_bc", "pl_set_periodic",
+           "pl_ddm_set_preconditioner", "pl_ddm_set_geometry", "pl_ddm_update_matrices", "pl_destroy", "pl_set_bc", "pl_set_periodic",
            "pl_update_radii", "pl_set_multiplicity", "pl_update_segments", "pl_assemble", "pl_assemble_bsr", "pl_get_bsr", "pl_spmv",
            "pl_spmv_free", "pl_spmv_bsr", "pl_solve", "pl_reactions", "pl_sens", "pl_energy", "pl_node_mod", "pl_schur",
            "pl_get_records", "pl_time_kernel", "pl_algorithmic_bytes", "pl_forget_history", "pl_debug_spd_solve", "pl_dist_unique_id_bytes",
@@ -85,7 +85,7 @@ def load_library(path: str | None = None):
     lib.pl_lattice_free.restype = None
     V, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {"pl_default_opts": [V, C.c_uint32], "pl_opts_size": [], "pl_stats_size": [], "pl_abi_version": [], "pl_lzone": [I32, I64, I64, V, V, V, V], "pl_create": [V, V, V], "pl_create_ddm": [I64, I64, I32, V, I32, V, V, V, V],
-           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_ddm_set_geometry": [V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V], "pl_set_periodic": [V, V],
+           "pl_ddm_set_preconditioner": [V, I32, V, V], "pl_ddm_set_geometry": [V, V], "pl_ddm_update_matrices": [V, I32, V, V], "pl_destroy": [V], "pl_set_bc": [V, V, V, V], "pl_set_periodic": [V, V],
            "pl_update_radii": [V, V], "pl_set_multiplicity": [V, V], "pl_update_segments": [V, V, V], "pl_assemble": [V],
            "pl_assemble_bsr": [V, I32, V, V], "pl_get_bsr": [V, V, V, V], "pl_spmv": [V, V, V],
            "pl_spmv_free": [V, V, V], "pl_spmv_bsr": [V, V, V], "pl_solve": [V, D, I32, V, V],
@@ -305,6 +305,19 @@ class HipLattice:
         if node_xyz is not None:
             self.set_ddm_geometry(node_xyz)
         return self
+
+    def update_ddm_matrices(self, S, cell_S):
+        """New cell matrices on this DDM handle (pl_ddm_update_matrices): same cells and nodes, other S_c; assemble() again
+        before the next solve."""
+        Sm = np.ascontiguousarray(S, dtype=np.float64)
+        if Sm.ndim == 2:
+            Sm = Sm[None]
+        if Sm.shape[1:] != (self._m, self._m):
+            raise ValueError(f"cell matrices must be {self._m} x {self._m}, got {Sm.shape[1:]}")
+        cs = np.ascontiguousarray(cell_S, dtype=np.int32)
+        if cs.shape != (self._n_cells,):
+            raise ValueError("one matrix index per cell expected")
+        _check(self._lib, self._lib.pl_ddm_update_matrices(self._h, Sm.shape[0], _ptr(Sm), _ptr(cs)))
 
     def set_ddm_geometry(self, node_xyz):
         """Node positions of a DDM handle (pl_ddm_set_geometry): aggregates and modes of the dense level of precond = 4."""

@@ -471,6 +471,88 @@ int pl_create(const pl_mesh_t *m, const pl_opts_t *o, pl_handle *out) {
   return PL_OK;
 }
 
+// Everything of a DDM handle that depends on WHICH matrix a cell uses (not on the matrix values): the cells sorted by matrix
+// id (k_ddm_cell_product_lds), and the tiles of 16 cells of one class with their gather positions (k_ddm_cell_product_mfma).
+static int ddm_build_classes(pl_context *c) {
+  const int64_t n_cells = c->ddm_cells;
+  const int nb = c->ddm_nb, m = 6 * nb;
+  const int32_t *cell_S = c->h_ddm_cell_S.data(), *cell_nodes = c->h_ddm_cell_nodes.data();
+  std::vector<int32_t> order((size_t)n_cells);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t l, int32_t r) { return cell_S[l] < cell_S[r]; });
+  PL_HIP(c->ddm_order.alloc(order.size()));
+  PL_HIP(hipMemcpy(c->ddm_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  // tiles of 16 cells of one matrix class for the matrix-pipe product (k_ddm_cell_product_mfma)
+  std::vector<int32_t> tiles, tile_S;
+  for (size_t q = 0; q < order.size();) {
+    const int32_t id = cell_S[order[q]];
+    size_t e = q;
+    while (e < order.size() && cell_S[order[e]] == id) ++e;
+    for (size_t a = q; a < e; a += 16) {
+      for (size_t k = 0; k < 16; ++k) tiles.push_back(a + k < e ? order[a + k] : -1);
+      tile_S.push_back(id);
+    }
+    q = e;
+  }
+  c->ddm_n_tiles = (int64_t)tile_S.size();
+  if (m <= 192) {
+    const int KS = pl::ddm_mfma_ks(m);
+    std::vector<int32_t> gidx((size_t)c->ddm_n_tiles * KS * 64, -1);
+    for (int64_t t = 0; t < c->ddm_n_tiles; ++t)
+      for (int kk = 0; kk < KS; ++kk)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int32_t cell = tiles[16 * t + (lane & 15)];
+          const int k = 4 * kk + (lane >> 4);
+          if (cell >= 0 && k < m)
+            gidx[((size_t)t * KS + kk) * 64 + lane] = 6 * cell_nodes[(int64_t)cell * nb + k / 6] + k % 6;
+        }
+    PL_HIP(c->ddm_tile_gidx.alloc(std::max<size_t>(1, gidx.size())));
+    if (!gidx.empty())
+      PL_HIP(hipMemcpy(c->ddm_tile_gidx.p, gidx.data(), gidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  PL_HIP(c->ddm_tiles.alloc(std::max<size_t>(1, tiles.size())));
+  PL_HIP(c->ddm_tile_S.alloc(std::max<size_t>(1, tile_S.size())));
+  if (!tiles.empty()) {
+    PL_HIP(hipMemcpy(c->ddm_tiles.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    PL_HIP(hipMemcpy(c->ddm_tile_S.p, tile_S.data(), tile_S.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return PL_OK;
+}
+
+// New cell matrices on an existing DDM handle (a design loop changes the radii, hence every S_c, between two solves; the
+// topology - which nodes a cell couples - stays): uploads the palette again and, only when the cells' matrix ids changed,
+// re-cuts the class tiles.  What it saves is pl_destroy + pl_create_ddm per design iteration (streams, events, a dozen
+// allocations, the node -> cell incidence).  The preconditioner data of the handle is dropped: pl_assemble before pl_solve.
+int pl_ddm_update_matrices(pl_handle h, int32_t n_S, const double *S, const int32_t *cell_S) {
+  if (!valid(h) || !S || !cell_S || n_S <= 0) return fail(PL_ERR_ARG, "pl_ddm_update_matrices: bad argument");
+  if (h->opkind != 1) return fail(PL_ERR_STATE, "pl_ddm_update_matrices: not a DDM handle");
+  for (int64_t c = 0; c < h->ddm_cells; ++c)
+    if (cell_S[c] < 0 || cell_S[c] >= n_S) return fail(PL_ERR_ARG, "pl_ddm_update_matrices: matrix id out of range");
+  PL_HIP(hipSetDevice(h->opt.device));
+  PL_HIP(hipStreamSynchronize(h->stream));
+  const int m = 6 * h->ddm_nb;
+  std::vector<double> St((size_t)n_S * m * m);
+  pl::parallel_for(n_S, [&](int64_t s0, int64_t s1, unsigned) {
+    for (int64_t s = s0; s < s1; ++s)
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) St[((size_t)s * m + j) * m + i] = S[((size_t)s * m + i) * m + j];
+  }, 8);
+  if (h->ddm_St.n != St.size()) PL_HIP(h->ddm_St.alloc(St.size()));
+  PL_HIP(hipMemcpy(h->ddm_St.p, St.data(), St.size() * sizeof(double), hipMemcpyHostToDevice));
+  h->ddm_n_S = n_S;
+  if (!std::equal(h->h_ddm_cell_S.begin(), h->h_ddm_cell_S.end(), cell_S)) {
+    h->h_ddm_cell_S.assign(cell_S, cell_S + h->ddm_cells);
+    PL_HIP(hipMemcpy(h->ddm_cell_S.p, cell_S, h->ddm_cells * sizeof(int32_t), hipMemcpyHostToDevice));
+    int rc = ddm_build_classes(h);
+    if (rc) return rc;
+  }
+  h->assembled = false;
+  h->dd_ready = false;
+  h->dd_blocks = false;
+  h->dd2_ready = false;
+  return PL_OK;
+}
+
 int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *cell_nodes, int32_t n_S,
                   const double *S, const int32_t *cell_S, const pl_opts_t *o, pl_handle *out) {
   if (!cell_nodes || !S || !cell_S || !o || !out) return fail(PL_ERR_ARG, "pl_create_ddm: null argument");
@@ -561,44 +643,12 @@ int pl_create_ddm(int64_t n_nodes, int64_t n_cells, int32_t nb, const int32_t *c
     PL_HIPC(c->ddm_stage.alloc((size_t)n_cells * m));
     PL_HIPC(hipMemcpy(c->ddm_node_ptr.p, nptr.data(), nptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     PL_HIPC(hipMemcpy(c->ddm_node_ent.p, nent.data(), nent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    std::vector<int32_t> order((size_t)n_cells);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t l, int32_t r) { return cell_S[l] < cell_S[r]; });
-    PL_HIPC(c->ddm_order.alloc(order.size()));
-    PL_HIPC(hipMemcpy(c->ddm_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    // tiles of 16 cells of one matrix class for the matrix-pipe product (k_ddm_cell_product_mfma)
-    std::vector<int32_t> tiles, tile_S;
-    for (size_t q = 0; q < order.size();) {
-      const int32_t id = cell_S[order[q]];
-      size_t e = q;
-      while (e < order.size() && cell_S[order[e]] == id) ++e;
-      for (size_t a = q; a < e; a += 16) {
-        for (size_t k = 0; k < 16; ++k) tiles.push_back(a + k < e ? order[a + k] : -1);
-        tile_S.push_back(id);
-      }
-      q = e;
-    }
-    c->ddm_n_tiles = (int64_t)tile_S.size();
-    if (m <= 192) {
-      const int KS = pl::ddm_mfma_ks(m);
-      std::vector<int32_t> gidx((size_t)c->ddm_n_tiles * KS * 64, -1);
-      for (int64_t t = 0; t < c->ddm_n_tiles; ++t)
-        for (int kk = 0; kk < KS; ++kk)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int32_t cell = tiles[16 * t + (lane & 15)];
-            const int k = 4 * kk + (lane >> 4);
-            if (cell >= 0 && k < m)
-              gidx[((size_t)t * KS + kk) * 64 + lane] = 6 * cell_nodes[(int64_t)cell * nb + k / 6] + k % 6;
-          }
-      PL_HIPC(c->ddm_tile_gidx.alloc(std::max<size_t>(1, gidx.size())));
-      if (!gidx.empty())
-        PL_HIPC(hipMemcpy(c->ddm_tile_gidx.p, gidx.data(), gidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    PL_HIPC(c->ddm_tiles.alloc(std::max<size_t>(1, tiles.size())));
-    PL_HIPC(c->ddm_tile_S.alloc(std::max<size_t>(1, tile_S.size())));
-    if (!tiles.empty()) {
-      PL_HIPC(hipMemcpy(c->ddm_tiles.p, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      PL_HIPC(hipMemcpy(c->ddm_tile_S.p, tile_S.data(), tile_S.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->h_ddm_cell_nodes.assign(cell_nodes, cell_nodes + n_cells * nb);
+    c->h_ddm_cell_S.assign(cell_S, cell_S + n_cells);
+    c->ddm_n_S = n_S;
+    {
+      int rcc = ddm_build_classes(c);
+      if (rcc) return bail(rcc);
     }
   }
   const size_t n6 = (size_t)n_nodes * 6;

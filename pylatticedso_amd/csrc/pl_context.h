@@ -132,6 +132,8 @@ struct pl_context {
   int opkind = 0;
   int64_t ddm_cells = 0;
   int ddm_nb = 0;
+  int ddm_n_S = 0;                       // matrices of the palette
+  std::vector<int32_t> h_ddm_cell_nodes, h_ddm_cell_S;   // host copies (pl_ddm_update_matrices re-cuts the class tiles)
   DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
   DevBuf<double> ddm_St;
   DevBuf<int64_t> ddm_node_ptr;       // node -> (cell * nb + slot) entries: the atomic-free scatter of k_ddm_node_gather

@@ -184,15 +184,20 @@ class LatticeOpti(LatticeSim):
 
     def set_optimization_parameters(self, optimization_parameters_actual):
         """lattice_opti.py:467-560: map the optimiser's vector to strut radii (device update, topology untouched)."""
-        theta = [float(v) for v in optimization_parameters_actual]
-        if len(theta) != self.number_parameters:
+        # (this runs once per design variable and SLSQP iteration - the finite-difference density constraint - so it stays in
+        #  numpy: the list conversions and np.allclose of the first version were 10 ms per iteration at 192 variables)
+        th = np.array(optimization_parameters_actual, dtype=float).ravel()
+        if len(th) != self.number_parameters:
             raise ValueError("Invalid number of optimization parameters.")
-        if (self.actual_optimization_parameters is not None
-                and len(self.actual_optimization_parameters) == len(theta)
-                and np.allclose(theta, self.actual_optimization_parameters, rtol=1e-10, atol=1e-10)):
+        prev = getattr(self, "_theta_arr", None)
+        if (self.actual_optimization_parameters is not None and prev is not None
+                and len(self.actual_optimization_parameters) == len(th) == len(prev)
+                and bool(np.all(np.abs(th - prev) <= 1e-10 + 1e-10 * np.abs(prev)))):      # (np.allclose, rtol = atol = 1e-10)
             return
         self._sim_is_current = False
-        self.actual_optimization_parameters = list(theta)
+        theta = th.tolist()
+        self._theta_arr = th
+        self.actual_optimization_parameters = theta
         self.cell_radii = self._cell_radii_from_parameters(theta)
         lat = self.lattice
         lat.beam_radius = (self.cell_radii[self._beam_cell, lat.beam_type] * self._cell_gfac[self._beam_cell])
@@ -200,13 +205,26 @@ class LatticeOpti(LatticeSim):
             # reset_cell_with_new_radii (lattice_sim.py:1421-1497): new cell radii -> new Schur complements (+ dS/dr)
             lat.cell_radii = self.cell_radii * self._cell_gfac[:, None]
             # exact: one device condensation per distinct radius set (+ central differences for dS/dr when gradients
-            # are on, as lattice_sim.py:1020-1054 does with dolfinx solves); surrogates: one batched evaluation
-            self.calculate_schur_complement_cells()
+            # are on, as lattice_sim.py:1020-1054 does with dolfinx solves); surrogates: one batched evaluation - made when
+            # the matrices are next asked for (_flush_schur): SLSQP's finite-difference density constraint sets one vector per
+            # design variable and iteration that is never simulated (round 5, 12 x 4 x 4 cells: 197 evaluations of all cell
+            # matrices per SLSQP iteration, 146 of its 186 ms)
+            self._schur_stale = True
             return
         # the device gets the new radii when it is next asked for (device_model): SLSQP differentiates the density constraint by
         # finite differences - 54 parameter vectors per iteration on the reference's 6x3x3 preset, none of which is simulated
         # (round 5: 1 174 of 1 253 calls of this method in a 20-iteration run uploaded radii nobody used)
         self._device_radii_stale = True
+
+    def _flush_schur(self):
+        """Cell matrices (and dS/dr) for the radii set last: evaluated here, not in set_optimization_parameters."""
+        if getattr(self, "_schur_stale", False):
+            self._schur_stale = False
+            self.calculate_schur_complement_cells()
+
+    def ddm_model(self):
+        self._flush_schur()
+        return super().ddm_model()
 
     def device_model(self, **kw):
         """As LatticeSim.device_model; a compliance loop solves ONE slowly changing system over and over, so its handle
@@ -359,6 +377,7 @@ class LatticeOpti(LatticeSim):
     def _ddm_cell_sensitivities(self):
         """(C, G):  lam_c^T (dS_c/dr_j) u_c per cell and geometry, u_c / lam_c on the cell's boundary nodes in
         Cell.define_node_order_to_simulate order (lattice_opti.py:746-760, 866-890)."""
+        self._flush_schur()
         if self.schur_gradients is None:
             raise RuntimeError("Schur complement gradients are not available: enable_gradient_computing must be true")
         cb = self.cell_boundary_nodes()
@@ -463,9 +482,13 @@ class LatticeOpti(LatticeSim):
     # -- density constraint (direct strut-volume formula) ---------------------------------------------------------
     def relative_density(self):
         lat = self.lattice
-        d = lat.node_xyz[lat.beam_conn[:, 1]] - lat.node_xyz[lat.beam_conn[:, 0]]
-        vol = np.pi * lat.beam_radius ** 2 * np.linalg.norm(d, axis=1)
-        return float(vol.sum() / lat.cell_size.prod(axis=1).sum())
+        geo = getattr(self, "_density_geometry", None)
+        if geo is None or geo[0] is not lat.beam_conn:          # strut lengths and the cells' volume: fixed by the topology
+            d = lat.node_xyz[lat.beam_conn[:, 1]] - lat.node_xyz[lat.beam_conn[:, 0]]
+            geo = self._density_geometry = (lat.beam_conn, np.pi * np.linalg.norm(d, axis=1),
+                                            float(lat.cell_size.prod(axis=1).sum()))
+        r = lat.beam_radius
+        return float((geo[1] * r * r).sum() / geo[2])
 
     def density_constraint(self, r):
         self.set_optimization_parameters(r)

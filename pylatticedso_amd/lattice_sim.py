@@ -614,9 +614,17 @@ class LatticeSim(LatticeViews):
         self.schur_complements = S
         self.cell_schur_index = (np.zeros(self.lattice.n_cells, np.int32) if cell_index is None
                                  else np.asarray(cell_index, np.int32))
-        if self._ddm_device is not None:
-            self._ddm_device.close()
-            self._ddm_device = None
+        dev = self._ddm_device
+        if dev is not None:
+            if S.shape[1] == dev._m and len(self.cell_schur_index) == dev._n_cells:
+                # same cells, other matrices (every iteration of a design loop): the handle takes them (round 5; it used to be
+                # destroyed and created again - 10 ms per solve_DDM on a 12 x 4 x 4 lattice against 2 ms of device work)
+                dev.update_ddm_matrices(S, self.cell_schur_index)
+                if getattr(self, "_ddm_precond", 0) == 2:
+                    self.define_preconditioner()
+            else:
+                dev.close()
+                self._ddm_device = None
 
     @timing.category("simulation")
     @timing.timeit
