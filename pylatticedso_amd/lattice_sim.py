@@ -479,20 +479,22 @@ class LatticeSim(LatticeViews):
         names = surface_cells if surface_cells is not None else surfaceNames
         ptr, idx = self.cell_points()
         node_xyz = self.node_coordinates()
-        out = []
-        for c in cells:
-            nodes = idx[ptr[c]:ptr[c + 1]]
-            xyz = node_xyz[nodes]
+        # every (surface cell, point of that cell) pair at once (a Python loop over the cells cost 0.1 s at 50^3 cells)
+        cells = np.asarray(cells, dtype=np.int64)
+        if len(cells):
+            cnt = (ptr[cells + 1] - ptr[cells]).astype(np.int64)
+            owner = np.repeat(np.arange(len(cells)), cnt)
+            first = np.repeat(np.asarray(ptr)[cells].astype(np.int64) - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt)
+            nodes = np.asarray(idx)[first + np.arange(int(cnt.sum()))]
             keep = np.ones(len(nodes), bool)
             for s in names:
                 ax = "XYZ".index(s[0])
-                if s.endswith("max"):
-                    val = lat.cell_coord[c, ax] + lat.cell_size[c, ax]
-                else:   # min and mid both refer to the cell's lower corner (cell.py:451-462)
-                    val = lat.cell_coord[c, ax]
-                keep &= xyz[:, ax] == val
-            out.append(nodes[keep])
-        pts = np.unique(np.concatenate(out)) if out else np.zeros(0, np.int64)
+                val = lat.cell_coord[cells, ax] + (lat.cell_size[cells, ax] if s.endswith("max") else 0.0)
+                # (min and mid both refer to the cell's lower corner, cell.py:451-462)
+                keep &= node_xyz[nodes, ax] == val[owner]
+            pts = np.unique(nodes[keep])
+        else:
+            pts = np.zeros(0, np.int64)
         if len(pts) == 0:
             raise ValueError("No points found on the specified surfaces.")
         cache[ckey] = pts
