@@ -553,7 +553,12 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   // A design loop solves a slowly changing system over and over: the iteration count of the previous converged solve on
   // this handle (identical on every rank) is where the first look at the history is worth taking - three iterations
   // before it - instead of every 32 iterations on the way there (each look drains the stream: 30-50 us).
-  const int first = (adaptive && !ref && c->last_iterations > 40) ? std::min(c->last_iterations - 3, max_iter) : chunk;
+  // ... and a handle preconditioned by a dense FACTOR of its own matrix (precond = 5; the assembled Schur matrix of a DDM handle,
+  // precond = 2) converges in one or two steps: look after two (32 queued iterations of a 9-node cell were 0.5 ms of the 0.57 ms
+  // a column of pl_schur took)
+  const bool direct = adaptive && c->dd_ready;
+  const int first = direct ? std::min(2, max_iter)
+                           : ((adaptive && !ref && c->last_iterations > 40) ? std::min(c->last_iterations - 3, max_iter) : chunk);
   const int hbuf = std::max(chunk, first);
   std::vector<double> h_hist(hbuf), h_pp(ref ? hbuf : 0), h_xx(ref ? hbuf : 0), h_al(ref ? hbuf : 0);
   st->info = 1.0;
@@ -600,7 +605,7 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     if (st->converged) break;
     if (adaptive) {
       const double rr_end = h_hist[todo - 1];
-      next = chunk;
+      next = direct && k < 16 ? 2 : chunk;
       if (rr_end < rr_prev && rr_end > thresh) {
         const double per_it = std::log(rr_end / rr_prev) / (double)(k - k_prev);      // < 0
         const double need = std::log(thresh / rr_end) / per_it;

@@ -662,7 +662,8 @@ class LatticeSim(LatticeViews):
                 remap[nodes] = np.arange(len(nodes))
                 with HipLattice(lat.node_xyz[nodes], remap[lat.beam_conn[beams]], lat.beam_radius[beams],
                                 pen.seg_len[beams], pen.seg_nsub[beams], self.young_modulus, self.poisson_ratio,
-                                pen_coef=self.penalization_coefficient, reorder=0) as dev:
+                                pen_coef=self.penalization_coefficient, reorder=0,
+                                **({"precond": 5} if 6 * len(nodes) <= DDM_DENSE_MAX else {})) as dev:   # (see cell_device)
                     dev.assemble()
                     mats.append(dev.schur(remap[cb[c]], rtol=1e-13, max_iter=200000))
                     if self.enable_gradient_computing:

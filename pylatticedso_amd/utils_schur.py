@@ -88,8 +88,11 @@ def cell_device(lattice, cell_index):
                                       lat.beam_conn[struts].ravel()]))
     local = np.full(lat.n_nodes, -1, np.int64)
     local[nodes] = np.arange(len(nodes))
+    # one cell: a few hundred dofs - the dense factor of P K P as the preconditioner (precond = 5), so that each of the 6 n_b
+    # condensation solves of pl_schur is one or two PCG steps instead of hundreds of Jacobi iterations
     dev = HipLattice(lat.node_xyz[nodes], local[lat.beam_conn[struts]], lat.beam_radius[struts], pen.seg_len[struts],
-                     pen.seg_nsub[struts], lattice.young_modulus, lattice.poisson_ratio)
+                     pen.seg_nsub[struts], lattice.young_modulus, lattice.poisson_ratio,
+                     **({"precond": 5} if 6 * len(nodes) <= 16384 else {}))
     return dev, local[node_order_to_simulate(lattice, cell_index)]
 
 
