@@ -380,7 +380,51 @@ def other_configs(args, local_rank):
     except Exception as e:
         out["drop_in_optimisation"] = {"error": f"{type(e).__name__}: {e}"}
     out["drop_in_optimisation"]["wall_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    try:
+        out["solve_DDM"] = drop_in_ddm()
+    except Exception as e:
+        out["solve_DDM"] = {"error": f"{type(e).__name__}: {e}"}
+    out["solve_DDM"]["wall_s"] = time.perf_counter() - t0
     return out
+
+
+def drop_in_ddm(n=32):
+    """SURVEY 8(f) row 1 through the drop-in call site: LatticeSim.solve_DDM() (lattice_sim.py:1111-1252) on an n^3 BCC cantilever
+    with the reference's RBF surrogate of the cell Schur complements (the committed fixture tests/golden/reduced_basis_BCC...)
+    and enable_preconditioner - beyond PL_DDM_DENSE_MAX boundary dofs, so the device CG is preconditioned by the node blocks +
+    the dense level on aggregates of boundary nodes (precond = 4).  Device times are HIP-event times of pl_assemble + pl_solve;
+    the reference's own operator costs 3.6 - 17 ms per APPLICATION at 54 - 250 cells (Python loops)."""
+    from pylatticedso_amd.lattice_sim import LatticeSim
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    preset = {"geometry": {"cell_size": {"x": 1, "y": 1, "z": 1}, "number_of_cells": {"x": n, "y": n, "z": n},
+                           "radii": [0.05], "geom_types": ["BCC"]},
+              "simulation_parameters": {"enable": True, "material": "VeroClear", "periodicity": False,
+                                        "DDM": {"enable_preconditioner": True, "preconditioner_type": "exact",
+                                                "max_iterations": 20000,
+                                                "schur_complement_computation": {"type": "RBF", "precision_greedy": 1e-6}}},
+              "boundary_conditions": {
+                  "Displacement": {"Fixed": {"Surface": ["Xmin"], "DOF": ["X", "Y", "Z", "RX", "RY", "RZ"], "Value": [0] * 6}},
+                  "Force": {"Load": {"Surface": ["Xmax"], "DOF": ["Z"], "Value": [-0.1]}}}}
+    t0 = time.perf_counter()
+    L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden], verbose=-1)
+    t1 = time.perf_counter()
+    xsol, info, _, _ = L.solve_DDM()
+    t2 = time.perf_counter()
+    dev = L.ddm_model()
+    walls, devs = [], []
+    for _ in range(5):
+        t = time.perf_counter()
+        L.solve_DDM()
+        walls.append(time.perf_counter() - t)
+        devs.append(dev.last_stats["ms_assembly"] + dev.last_stats["ms_solve"])
+    st = dev.last_stats
+    return {"workload": f"{n}^3 BCC cells r = 0.05 cantilever, RBF surrogate of the cell Schur complements, CG to 1e-6 as the reference",
+            "cells": int(L.lattice.n_cells), "boundary_dofs": int(6 * (L.max_index_boundary + 1)), "free_dofs": int(len(xsol)),
+            "cg_iterations": int(L.iteration), "info": int(info), "precond_used": int(st["precond_used"]),
+            "construct_s": t1 - t0, "first_solve_ddm_s": t2 - t1, "solve_ddm_ms": 1e3 * min(walls),
+            "device_ms": min(devs), "device_assembly_ms": st["ms_assembly"], "device_solve_ms": st["ms_solve"],
+            "operator_us": 1e3 * dev.time_kernel(0, 50), "cg_iteration_us": 1e3 * dev.time_kernel(3, 50)}
 
 
 def drop_in_optimisation():
