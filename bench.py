@@ -494,7 +494,7 @@ def design_loop(args, local_rank):
     fixed, f, _ = cantilever_bc(lat.node_xyz, float(n))
     cell_of = lat.beam_cell0
     with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU,
-                          device=local_rank, precond=3, palette=1, warm_start=1, tile_nodes=args.tile_nodes,
+                          device=local_rank, precond=3, palette=1, warm_start=args.warm_start, tile_nodes=args.tile_nodes,
                           coarse_modes=args.coarse_modes, coarse_max_dofs=args.coarse_max_dofs,
                           tile_modes=max(args.tile_modes, 0), condense=args.condense, cg_form=args.cg_form,
                           short_iteration=args.short_iteration) as dev:
@@ -544,9 +544,14 @@ def design_loop(args, local_rank):
                                    f"sensitivity pl_sens + projected-gradient step) (BASELINE.json configs[3])",
                        "struts": lat.n_beams, "pcg_iterations_first_last": [its[args.warmup], its[-1]],
                        "compliance_first_last": [C0, C], "rtol": args.rtol,
-                       "warm_start": "every solve starts from the previous design iteration's solution (pl_opts_t.warm_start: "
-                                     "the system changes by one projected-gradient step; the stopping test is the same "
-                                     "||r|| <= rtol ||b||)"}}
+                       "warm_start": {0: "every solve starts from zero",
+                                      1: "every solve starts from the previous design iteration's solution (pl_opts_t.warm_start = 1)",
+                                      2: "every solve starts from the linear extrapolation 2 x_prev - x_prev2 of the last two design "
+                                         "iterations' solutions (pl_opts_t.warm_start = 2)",
+                                      3: "every solve starts from the quadratic extrapolation of the last three solutions "
+                                         "(pl_opts_t.warm_start = 3)"}.get(args.warm_start, str(args.warm_start)) +
+                                     ": the system changes by one projected-gradient step; the stopping test is the same "
+                                     "||r|| <= rtol ||b|| of the current right-hand side"}}
 
 
 def main():
@@ -586,6 +591,8 @@ def main():
     ap.add_argument("--cg-form", type=int, default=0,
                     help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
                          "vectors); 0 = ordinary form")
+    ap.add_argument("--warm-start", type=int, default=2,
+                    help="configs[3]: 1 = every solve starts from the previous solution, 2 = from the linear extrapolation of the last two, 0 = from zero")
     ap.add_argument("--short-iteration", type=int, default=0,
                     help="small lattices: 0 = automatic, 1 = short form of the iteration (pl_small.h), -1 = ordinary form")
     ap.add_argument("--precision", type=int, default=-1,

@@ -145,7 +145,10 @@ typedef struct {
                           * handle instead of from zero (one extra K*x; the stopping test is unchanged: ||r|| <= rtol ||b|| of the
                           * current right-hand side).  Multi-level PCG in fp64, ordinary form, single-GPU handles; ignored
                           * elsewhere.  0 = every solve starts from zero (what bench.py times on configs[1] / [2] / [4]: a loop of
-                          * IDENTICAL solves must not start from its own answer) */
+                          * IDENTICAL solves must not start from its own answer).  2 (round 5) = start from 2 x_prev - x_prev2,
+                          * the linear extrapolation of the handle's last two solutions - a design loop moves along a smooth path
+                          * (configs[3]: 249 -> 208 iterations per solve on average); 3 = quadratic extrapolation of the last three
+                          * (193; amplifies a jagged path threefold - opt-in).  With the fp32 inner solver (precision = 1) 2 and 3 act as 1. */
   int32_t short_iteration; /* small lattices (few K*p tiles: the dense level's explicit inverse can be read once per tile and
                           * iteration): 1 = the SHORT form of the multi-level PCG iteration (pl_small.h) - the dense level's
                           * solve and the prolongation fused into one launch that writes z = M^-1 r and r.z, the search

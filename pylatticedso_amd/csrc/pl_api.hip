@@ -1598,6 +1598,7 @@ int pl_forget_history(pl_handle h) {
   if (!valid(h)) return fail(PL_ERR_ARG, "pl_forget_history: null handle");
   h->last_iterations = 0;       // the next solve looks at the residual history every 32 iterations again
   h->xprev_valid = false;       // and starts from zero even with opts.warm_start
+  h->xprev2_valid = false;
   return PL_OK;
 }
 

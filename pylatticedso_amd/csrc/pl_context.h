@@ -124,6 +124,10 @@ struct pl_context {
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
   DevBuf<double> xprev;               // previous converged solution (opts.warm_start)
   bool xprev_valid = false;
+  DevBuf<double> xprev2;              // the one before (opts.warm_start = 2: linear extrapolation of the design path)
+  bool xprev2_valid = false;
+  DevBuf<double> xprev3;              // (warm_start = 3, experiment: quadratic extrapolation)
+  bool xprev3_valid = false;
   DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
   int hist_cap = 0;
   // LDS-tile operator

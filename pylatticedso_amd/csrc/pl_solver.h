@@ -12,6 +12,17 @@ __global__ __launch_bounds__(pl::kBlock) void k_warm_mask(int64_t N, const uint8
   const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
   if (t < 6 * N && ((cflag && cflag[t / 6]) || fixed[t])) p[t] = 0.0;     // (the Dirichlet set may have changed since)
 }
+// opts.warm_start = 2: p <- 2 x_prev - x_prev2, the linear extrapolation of the last two solutions of a design loop
+__global__ __launch_bounds__(pl::kBlock) void k_warm_extrapolate(int64_t n6, const double *__restrict__ a /* x_prev */,
+                                                                 const double *__restrict__ b /* x_prev2 */, double *__restrict__ p) {
+  const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (t < n6) p[t] = 2.0 * a[t] - b[t];
+}
+__global__ __launch_bounds__(pl::kBlock) void k_warm_extrapolate2(int64_t n6, const double *__restrict__ a, const double *__restrict__ b,
+                                                                  const double *__restrict__ c3, double *__restrict__ p) {
+  const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (t < n6) p[t] = 3.0 * (a[t] - b[t]) + c3[t];
+}
 __global__ __launch_bounds__(pl::kBlock) void k_warm_apply(int64_t N, const uint8_t *__restrict__ cflag /* may be null */,
                                                           const double *__restrict__ Ap, const double *__restrict__ p,
                                                           double *__restrict__ r, double *__restrict__ x) {
@@ -467,11 +478,18 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
                        (const double *)c->tmp2.p, c->r.p);
     PL_HIP(hipGetLastError());
   }
-  const bool warm = c->opt.warm_start == 1 && c->coarse.ready && !c->dist.active;
+  const bool warm = c->opt.warm_start >= 1 && c->coarse.ready && !c->dist.active;
   if (warm && c->xprev.p && c->xprev_valid) {
     // x0 = the previous solution: r0 = b - S x0 through the same operator the iterations apply (with node elimination: first
     // pass fills the eliminated rows of p, second pass takes the others); the tail below then builds z0, p0 from r0
-    PL_HIP(hipMemcpyAsync(c->p.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (c->opt.warm_start == 3 && c->xprev2_valid && c->xprev3_valid)
+      hipLaunchKernelGGL(k_warm_extrapolate2, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, n6, (const double *)c->xprev.p,
+                         (const double *)c->xprev2.p, (const double *)c->xprev3.p, c->p.p);
+    else if (c->opt.warm_start >= 2 && c->xprev2.p && c->xprev2_valid)
+      hipLaunchKernelGGL(k_warm_extrapolate, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, n6, (const double *)c->xprev.p,
+                         (const double *)c->xprev2.p, c->p.p);
+    else
+      PL_HIP(hipMemcpyAsync(c->p.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_warm_mask, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N,
                        c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr, (const uint8_t *)c->fixed.p, c->p.p);
     if (c->cond_use) {
@@ -630,6 +648,16 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     PL_HIP(hipGetLastError());
   }
   if (warm && st->converged) {      // keep the solution for the next solve (before the caller's download adds ubar)
+    if (c->opt.warm_start >= 2 && c->xprev.p && c->xprev_valid) {     // ... and the one before it
+      if (c->opt.warm_start == 3 && c->xprev2_valid) {
+        std::swap(c->xprev2.p, c->xprev3.p);
+        std::swap(c->xprev2.n, c->xprev3.n);
+        c->xprev3_valid = true;
+      }
+      std::swap(c->xprev.p, c->xprev2.p);
+      std::swap(c->xprev.n, c->xprev2.n);
+      c->xprev2_valid = true;
+    }
     if (!c->xprev.p) PL_HIP(c->xprev.alloc(n6));
     PL_HIP(hipMemcpyAsync(c->xprev.p, c->x.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     c->xprev_valid = true;
@@ -899,7 +927,7 @@ int pcg_solve_mp_t(pl_context *c, const double *f_dev, const double *Kubar_dev, 
   double rr_true = bb;
   // warm start (mode 1, as pcg_solve): the refinement begins at the previous solution of this handle, masked with the
   // CURRENT Dirichlet set - the first inner solve then works on its true residual like every later one
-  const bool warm = kAll32 && c->opt.warm_start == 1 && !c->dist.active;
+  const bool warm = kAll32 && c->opt.warm_start >= 1 && !c->dist.active;     // (2 / 3: the previous solution here, no extrapolation)
   if (warm && c->xprev.p && c->xprev_valid) {
     PL_HIP(hipMemcpyAsync(c->x.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_warm_mask, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, (const uint8_t *)nullptr,

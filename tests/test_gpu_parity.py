@@ -1426,3 +1426,41 @@ def test_float_lever_arms_of_the_vector_kernels_change_nothing(cell, geom, conde
             out.append((u, st["iterations"]))
     assert abs(out[0][1] - out[1][1]) <= 3, (out[0][1], out[1][1])
     assert _rel(out[0][0].ravel(), out[1][0].ravel()) < 1e-8
+
+
+@pytest.mark.parametrize("condense", [0, 1])
+def test_extrapolated_warm_start_on_a_smooth_design_path(condense):
+    """opts.warm_start = 2 / 3 (round 5): the solve starts from the linear / quadratic extrapolation of the handle's last two /
+    three solutions.  Along a smooth path of radii (a design loop) every solve reaches the displacements of a cold start (1e-7)
+    and the path as a whole takes fewer iterations than with warm_start = 1, which takes fewer than cold starts."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 12
+    lat = LA.generate((1, 1, 1), (n, n, n), ["BCC"], [0.05])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == float(n), 2] = -1e-3
+    mid = 0.5 * (lat.node_xyz[lat.beam_conn[:, 0]] + lat.node_xyz[lat.beam_conn[:, 1]])
+    shape = np.sin(2 * np.pi * mid[:, 0] / n) * np.cos(2 * np.pi * mid[:, 1] / n)
+    path = [lat.beam_radius * (1.0 + 0.012 * k * shape) for k in range(7)]
+    total, sols = {}, {}
+    for warm in (0, 1, 2, 3):
+        with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                              palette=1, tile_nodes=64, coarse_max_dofs=600, condense=condense, warm_start=warm) as dev:
+            dev.set_bc(fixed, None, f)
+            its, us = [], []
+            for r in path:
+                dev.update_radii(r)
+                dev.assemble()
+                u, st = dev.solve(rtol=1e-9, max_iter=20000)
+                assert st["converged"] == 1
+                its.append(int(st["iterations"]))
+                us.append(u)
+            total[warm], sols[warm] = its, us
+    for warm in (1, 2, 3):
+        for k in range(len(path)):
+            assert _rel(sols[warm][k], sols[0][k]) < 1e-7, (warm, k)
+    tail = {w: sum(v[3:]) for w, v in total.items()}          # (from the fourth solve on all three have their history)
+    assert tail[2] < tail[1] < tail[0], total
+    assert tail[3] < tail[1], total
