@@ -549,7 +549,11 @@ def design_loop(args, local_rank):
                                       2: "every solve starts from the linear extrapolation 2 x_prev - x_prev2 of the last two design "
                                          "iterations' solutions (pl_opts_t.warm_start = 2)",
                                       3: "every solve starts from the quadratic extrapolation of the last three solutions "
-                                         "(pl_opts_t.warm_start = 3)"}.get(args.warm_start, str(args.warm_start)) +
+                                         "(pl_opts_t.warm_start = 3)",
+                                      4: "every solve starts from the combination of the last six design iterations' solutions that is "
+                                         "nearest to the new solution in the energy norm of the new system (Galerkin start, "
+                                         "pl_opts_t.warm_start = 4: six operator applications and a 6 x 6 solve per design iteration, "
+                                         "inside the timed step)"}.get(args.warm_start, str(args.warm_start)) +
                                      ": the system changes by one projected-gradient step; the stopping test is the same "
                                      "||r|| <= rtol ||b|| of the current right-hand side"}}
 
@@ -591,8 +595,9 @@ def main():
     ap.add_argument("--cg-form", type=int, default=0,
                     help="1 = single-reduction PCG (one all-reduce per iteration on several GPUs, three more stored "
                          "vectors); 0 = ordinary form")
-    ap.add_argument("--warm-start", type=int, default=2,
-                    help="configs[3]: 1 = every solve starts from the previous solution, 2 = from the linear extrapolation of the last two, 0 = from zero")
+    ap.add_argument("--warm-start", type=int, default=4,
+                    help="configs[3]: 0 = every solve starts from zero, 1 = from the previous solution, 2 / 3 = from the linear / quadratic "
+                         "extrapolation of the last two / three, 4 = from their best combination for the current system (Galerkin start)")
     ap.add_argument("--short-iteration", type=int, default=0,
                     help="small lattices: 0 = automatic, 1 = short form of the iteration (pl_small.h), -1 = ordinary form")
     ap.add_argument("--precision", type=int, default=-1,

@@ -28,7 +28,7 @@ preset = {
         "enable_gradient_computing": True, "simulation_type": "FEM"}}
 t0 = time.perf_counter()
 L = LatticeOpti(preset)
-L._device = L.device_model(precond=3, palette=1, warm_start=2)      # (a smooth design path: start from 2 x_prev - x_prev2)
+L._device = L.device_model(precond=3, palette=1)      # (LatticeOpti asks for warm_start = 4: the Galerkin start)
 c = L._cell_center
 r = np.clip(0.05 + 0.03 * (np.sin(2 * np.pi * c[:, 0] / 8) * np.cos(2 * np.pi * c[:, 1] / 8)
                            + np.sin(2 * np.pi * c[:, 1] / 8) * np.cos(2 * np.pi * c[:, 2] / 8)

@@ -148,7 +148,12 @@ typedef struct {
                           * IDENTICAL solves must not start from its own answer).  2 (round 5) = start from 2 x_prev - x_prev2,
                           * the linear extrapolation of the handle's last two solutions - a design loop moves along a smooth path
                           * (configs[3]: 249 -> 208 iterations per solve on average); 3 = quadratic extrapolation of the last three
-                          * (193; amplifies a jagged path threefold - opt-in).  With the fp32 inner solver (precision = 1) 2 and 3 act as 1. */
+                          * (193; amplifies a jagged path threefold - opt-in); 4 = the GALERKIN start: x0 = the combination of the
+                          * handle's last six solutions (environment PL_WARM_VECTORS, 2 ... 8) that is nearest to the solution of the
+                          * CURRENT system in its energy norm, (V^T K V) c = V^T b - one operator application and a handful of dot
+                          * products per stored vector, one 6 x 6 solve on the host.  A projection: it contains the candidates of 1, 2
+                          * and 3 and can do no worse than any of them (configs[3]: 160 iterations per solve).  With the fp32 inner
+                          * solver (precision = 1) 2, 3 and 4 act as 1. */
   int32_t short_iteration; /* small lattices (few K*p tiles: the dense level's explicit inverse can be read once per tile and
                           * iteration): 1 = the SHORT form of the multi-level PCG iteration (pl_small.h) - the dense level's
                           * solve and the prolongation fused into one launch that writes z = M^-1 r and r.z, the search

@@ -1599,6 +1599,8 @@ int pl_forget_history(pl_handle h) {
   h->last_iterations = 0;       // the next solve looks at the residual history every 32 iterations again
   h->xprev_valid = false;       // and starts from zero even with opts.warm_start
   h->xprev2_valid = false;
+  h->xprev3_valid = false;
+  h->gh_count = 0;
   return PL_OK;
 }
 

@@ -128,6 +128,12 @@ struct pl_context {
   bool xprev2_valid = false;
   DevBuf<double> xprev3;              // (warm_start = 3, experiment: quadratic extrapolation)
   bool xprev3_valid = false;
+  // warm_start = 4: the Galerkin start takes the best combination of the last kWarmMax solutions - xprev and a ring of older ones
+  static constexpr int kWarmMax = 8;
+  DevBuf<double> gh[kWarmMax - 1];    // ring of the solutions before xprev (gh_head = the newest of them)
+  int gh_head = 0, gh_count = 0;
+  DevBuf<double> gw[kWarmMax];        // masked copies (operands of the operator)
+  DevBuf<double> gw_dots;             // [kWarmMax][kWarmMax + 1]: v_i . S v_j, then v_j . r
   DevBuf<double> cg1;   // single-reduction PCG: two reduction blocks, r_c.y_c slots, (gamma, alpha) pairs, Z^T s
   int hist_cap = 0;
   // LDS-tile operator

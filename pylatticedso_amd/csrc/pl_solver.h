@@ -23,6 +23,55 @@ __global__ __launch_bounds__(pl::kBlock) void k_warm_extrapolate2(int64_t n6, co
   const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
   if (t < n6) p[t] = 3.0 * (a[t] - b[t]) + c3[t];
 }
+// opts.warm_start = 4 (Galerkin start): out[i] += v_i . Ap for the m stored vectors, out[m] += vj . r - rows that are unknowns
+// of the CG only (not eliminated, not constrained: v is masked, Ap is masked)
+constexpr int kWarmMax = pl_context::kWarmMax;
+struct WarmVecs {
+  const double *v[kWarmMax];
+};
+struct WarmCoef {
+  double c[kWarmMax];
+};
+__global__ __launch_bounds__(pl::kBlock) void k_warm_dots(int64_t N, int m, WarmVecs V, int j, const uint8_t *__restrict__ cflag,
+                                                          const double *__restrict__ Ap, const double *__restrict__ r,
+                                                          double *__restrict__ out /* [m + 1] */) {
+  __shared__ double red[kWarmMax + 1][pl::kBlock / pl::kWave];
+  double acc[kWarmMax + 1];
+#pragma unroll
+  for (int i = 0; i <= kWarmMax; ++i) acc[i] = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x; t < 6 * N; t += (int64_t)gridDim.x * pl::kBlock) {
+    if (cflag && cflag[t / 6]) continue;
+    const double a = Ap[t];
+#pragma unroll
+    for (int i = 0; i < kWarmMax; ++i)
+      if (i < m) acc[i] += V.v[i][t] * a;
+    acc[kWarmMax] += V.v[j][t] * r[t];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i <= kWarmMax; ++i) {
+    const double s = pl::wave_sum(acc[i]);
+    if (lane == 0) red[i][wv] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x <= kWarmMax) {
+    double s = 0.0;
+    for (int w = 0; w < pl::kBlock / pl::kWave; ++w) s += red[threadIdx.x][w];
+    const int i = threadIdx.x;
+    if (i < m) unsafeAtomicAdd(out + i, s);
+    else if (i == kWarmMax) unsafeAtomicAdd(out + m, s);
+  }
+}
+// p = sum_i c_i v_i
+__global__ __launch_bounds__(pl::kBlock) void k_warm_combine(int64_t n6, int m, WarmVecs V, WarmCoef C, double *__restrict__ p) {
+  const int64_t t = (int64_t)blockIdx.x * pl::kBlock + threadIdx.x;
+  if (t >= n6) return;
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < kWarmMax; ++i)
+    if (i < m) s += C.c[i] * V.v[i][t];
+  p[t] = s;
+}
 __global__ __launch_bounds__(pl::kBlock) void k_warm_apply(int64_t N, const uint8_t *__restrict__ cflag /* may be null */,
                                                           const double *__restrict__ Ap, const double *__restrict__ p,
                                                           double *__restrict__ r, double *__restrict__ x) {
@@ -482,10 +531,101 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
   if (warm && c->xprev.p && c->xprev_valid) {
     // x0 = the previous solution: r0 = b - S x0 through the same operator the iterations apply (with node elimination: first
     // pass fills the eliminated rows of p, second pass takes the others); the tail below then builds z0, p0 from r0
-    if (c->opt.warm_start == 3 && c->xprev2_valid && c->xprev3_valid)
+    bool combined = false;
+    if (c->opt.warm_start == 4 && c->gh_count >= 1) {
+      // Galerkin start: the combination x0 = sum c_i v_i of the handle's last m solutions that is nearest to the solution
+      // of the CURRENT system in its energy norm, (V^T S V) c = V^T b.  It contains the previous solution and both
+      // extrapolations as candidates, and - a projection - can do no worse than any of them.  m applications of the operator,
+      // m + 1 dot products each, one look at m^2 + m numbers on the host.
+      static const int want = [] { const char *e = std::getenv("PL_WARM_VECTORS"); const int v = e ? std::atoi(e) : 6;       // (configs[3]: 183 / 170 / 160 / 155 iterations per solve with 3 / 4 / 6 / 8)
+                                   return std::max(2, std::min(kWarmMax, v)); }();
+      const int m = std::min(want, 1 + c->gh_count);
+      const uint8_t *cf = c->cond_use ? (const uint8_t *)c->cflag.p : (const uint8_t *)nullptr;
+      WarmVecs V;
+      for (int i = 0; i < kWarmMax; ++i) V.v[i] = nullptr;
+      for (int i = 0; i < m; ++i) {
+        const double *src = i == 0 ? c->xprev.p
+                                   : c->gh[(c->gh_head - (i - 1) + 2 * (kWarmMax - 1)) % (kWarmMax - 1)].p;
+        if (!c->gw[i].p || c->gw[i].n < (size_t)n6) PL_HIP(c->gw[i].alloc(n6));
+        PL_HIP(hipMemcpyAsync(c->gw[i].p, src, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_warm_mask, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, c->N, cf, (const uint8_t *)c->fixed.p,
+                           c->gw[i].p);
+        V.v[i] = c->gw[i].p;
+      }
+      constexpr int kRow = kWarmMax + 1;
+      if (!c->gw_dots.p) PL_HIP(c->gw_dots.alloc(kWarmMax * kRow));
+      PL_HIP(hipMemsetAsync(c->gw_dots.p, 0, kWarmMax * kRow * sizeof(double), c->stream));
+      for (int j = 0; j < m; ++j) {
+        // (with node elimination the first pass writes the eliminated rows of its operand: on a copy, the dots skip those rows)
+        PL_HIP(hipMemcpyAsync(c->p.p, c->gw[j].p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (c->cond_use) {
+          rc = launch_spmv(c, c->p.p, c->p.p, false, nullptr, nullptr, pl::kEndsCondensedSolve);
+          if (rc) return rc;
+          rc = launch_spmv(c, c->p.p, c->Ap.p, true, nullptr, c->maskC.p, pl::kEndsOthers);
+        } else {
+          rc = launch_spmv(c, c->p.p, c->Ap.p, true, nullptr);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_warm_dots, dim3(grid_stream(n6)), dim3(pl::kBlock), 0, c->stream, c->N, m, V, j, cf,
+                           (const double *)c->Ap.p, (const double *)c->r.p, c->gw_dots.p + kRow * j);
+      }
+      double hd[kWarmMax * kRow];
+      PL_HIP(hipMemcpyAsync(hd, c->gw_dots.p, sizeof(hd), hipMemcpyDeviceToHost, c->stream));
+      PL_HIP(hipStreamSynchronize(c->stream));
+      // G[i][j] = hd[kRow j + i] (symmetrised), g[j] = hd[kRow j + m]; Cholesky with a relative pivot floor: vectors that add
+      // nothing new (a stalled design path) are dropped
+      double G[kWarmMax][kWarmMax], g[kWarmMax], L[kWarmMax][kWarmMax] = {}, y[kWarmMax] = {};
+      WarmCoef cc;
+      for (int i = 0; i < kWarmMax; ++i) cc.c[i] = 0.0;
+      bool ok = true, used[kWarmMax] = {};
+      for (int i = 0; i < m; ++i) {
+        g[i] = hd[kRow * i + m];
+        for (int j = 0; j < m; ++j) G[i][j] = 0.5 * (hd[kRow * j + i] + hd[kRow * i + j]);
+        if (!(G[i][i] > 0.0) || !std::isfinite(G[i][i]) || !std::isfinite(g[i])) ok = false;
+      }
+      if (ok) {
+        for (int j = 0; j < m; ++j) {            // (in the order newest first: the newest vector is always kept)
+          double d = G[j][j];
+          for (int k = 0; k < j; ++k)
+            if (used[k]) d -= L[j][k] * L[j][k];
+          if (!(d > 1e-10 * G[j][j])) continue;
+          used[j] = true;
+          L[j][j] = std::sqrt(d);
+          for (int i = j + 1; i < m; ++i) {
+            double v = G[i][j];
+            for (int k = 0; k < j; ++k)
+              if (used[k]) v -= L[i][k] * L[j][k];
+            L[i][j] = v / L[j][j];
+          }
+        }
+        for (int i = 0; i < m; ++i) {
+          if (!used[i]) continue;
+          double v = g[i];
+          for (int k = 0; k < i; ++k)
+            if (used[k]) v -= L[i][k] * y[k];
+          y[i] = v / L[i][i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+          if (!used[i]) continue;
+          double v = y[i];
+          for (int k = i + 1; k < m; ++k)
+            if (used[k]) v -= L[k][i] * cc.c[k];
+          cc.c[i] = v / L[i][i];
+        }
+        for (int i = 0; i < m; ++i)
+          if (!std::isfinite(cc.c[i])) ok = false;
+      }
+      if (ok) {
+        hipLaunchKernelGGL(k_warm_combine, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, n6, m, V, cc, c->p.p);
+        combined = true;
+      }
+    }
+    if (combined) {
+      // (p holds the combination of masked vectors)
+    } else if (c->opt.warm_start == 3 && c->xprev2_valid && c->xprev3_valid)
       hipLaunchKernelGGL(k_warm_extrapolate2, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, n6, (const double *)c->xprev.p,
                          (const double *)c->xprev2.p, (const double *)c->xprev3.p, c->p.p);
-    else if (c->opt.warm_start >= 2 && c->xprev2.p && c->xprev2_valid)
+    else if ((c->opt.warm_start == 2 || c->opt.warm_start == 3) && c->xprev2.p && c->xprev2_valid)
       hipLaunchKernelGGL(k_warm_extrapolate, dim3(grid_for(n6)), dim3(pl::kBlock), 0, c->stream, n6, (const double *)c->xprev.p,
                          (const double *)c->xprev2.p, c->p.p);
     else
@@ -648,8 +788,14 @@ int pcg_solve(pl_context *c, const double *f_dev, const double *Kubar_dev, doubl
     PL_HIP(hipGetLastError());
   }
   if (warm && st->converged) {      // keep the solution for the next solve (before the caller's download adds ubar)
-    if (c->opt.warm_start >= 2 && c->xprev.p && c->xprev_valid) {     // ... and the one before it
-      if (c->opt.warm_start == 3 && c->xprev2_valid) {
+    if (c->opt.warm_start == 4 && c->xprev.p && c->xprev_valid) {     // the Galerkin start's ring takes the solution before
+      c->gh_head = (c->gh_head + 1) % (pl_context::kWarmMax - 1);
+      DevBuf<double> &slot = c->gh[c->gh_head];
+      if (!slot.p || slot.n < (size_t)n6) PL_HIP(slot.alloc(n6));
+      PL_HIP(hipMemcpyAsync(slot.p, c->xprev.p, n6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      c->gh_count = std::min(c->gh_count + 1, pl_context::kWarmMax - 1);
+    } else if (c->opt.warm_start >= 2 && c->xprev.p && c->xprev_valid) {     // ... and the one(s) before it
+      if (c->opt.warm_start >= 3 && c->xprev2_valid) {
         std::swap(c->xprev2.p, c->xprev3.p);
         std::swap(c->xprev2.n, c->xprev3.n);
         c->xprev3_valid = true;

@@ -227,11 +227,13 @@ class LatticeOpti(LatticeSim):
         return super().ddm_model()
 
     def device_model(self, **kw):
-        """As LatticeSim.device_model; a compliance loop solves ONE slowly changing system over and over, so its handle
-        starts every solve from the previous solution (pl_opts_t.warm_start; objectives with adjoint solves alternate two
-        right-hand sides on the handle and keep the cold start).  Radii set since the last call are uploaded here."""
-        if self._device is None and getattr(self, "objective_type", None) == "compliance":
-            kw.setdefault("warm_start", 1)
+        """As LatticeSim.device_model; a design loop solves ONE slowly changing system over and over, so its handle starts every
+        solve from the best combination of its last six solutions for the system at hand (pl_opts_t.warm_start = 4, the Galerkin
+        start; round 5 - until then the previous solution, and for compliance only: an objective with an adjoint solve alternates
+        two right-hand sides on the handle, which a projection does not mind - the states and the adjoints of the last design
+        iterations are all candidates).  Radii set since the last call are uploaded here."""
+        if self._device is None:
+            kw.setdefault("warm_start", 4)
         fresh = self._device is None
         dev = super().device_model(**kw)
         if getattr(self, "_device_radii_stale", False) and not self._ddm_mode:

@@ -1445,7 +1445,7 @@ def test_extrapolated_warm_start_on_a_smooth_design_path(condense):
     shape = np.sin(2 * np.pi * mid[:, 0] / n) * np.cos(2 * np.pi * mid[:, 1] / n)
     path = [lat.beam_radius * (1.0 + 0.012 * k * shape) for k in range(7)]
     total, sols = {}, {}
-    for warm in (0, 1, 2, 3):
+    for warm in (0, 1, 2, 3, 4):
         with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
                               palette=1, tile_nodes=64, coarse_max_dofs=600, condense=condense, warm_start=warm) as dev:
             dev.set_bc(fixed, None, f)
@@ -1458,9 +1458,12 @@ def test_extrapolated_warm_start_on_a_smooth_design_path(condense):
                 its.append(int(st["iterations"]))
                 us.append(u)
             total[warm], sols[warm] = its, us
-    for warm in (1, 2, 3):
+    for warm in (1, 2, 3, 4):
         for k in range(len(path)):
             assert _rel(sols[warm][k], sols[0][k]) < 1e-7, (warm, k)
-    tail = {w: sum(v[3:]) for w, v in total.items()}          # (from the fourth solve on all three have their history)
+    tail = {w: sum(v[3:]) for w, v in total.items()}          # (from the fourth solve on all of them have their history)
     assert tail[2] < tail[1] < tail[0], total
     assert tail[3] < tail[1], total
+    # 4 = the Galerkin start: the best combination of the last (up to) four solutions for the current system - it contains
+    # the candidates of 1, 2 and 3
+    assert tail[4] <= tail[2], total
