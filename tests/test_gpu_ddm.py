@@ -344,3 +344,29 @@ def test_solve_ddm_above_the_dense_limit_uses_the_two_level_preconditioner(golde
     assert "dense level on aggregates" in capsys.readouterr().out
     assert _rel(res[4][0], res[3][0]) < 2e-5                  # (both stop at the reference's 1e-6)
     assert res[4][1] < 0.8 * res[3][1], (res[4][1], res[3][1])
+
+
+@pytest.mark.parametrize("geoms,radii", [(["Hybrid1"], [0.04]), (["BCC", "Hybrid1"], [0.05, 0.03])])
+def test_two_level_preconditioner_on_cells_with_edge_and_face_nodes(golden_dir, geoms, radii, monkeypatch):
+    """precond = 4 on cells whose boundary is more than the eight corners (Hybrid1: 12 boundary nodes, m = 72; BCC + Hybrid1
+    hybrids: 20): exact (device-condensed) Schur complements, the coarse operator assembled from them cell by cell, the node
+    aggregates cut from the positions of corner, edge and face nodes alike.  solve_DDM reaches what the node blocks alone reach
+    (DDM_LARGE_PRECOND = 3), in fewer iterations."""
+    import pylatticedso_amd.lattice_sim as LS
+    g = np.load(os.path.join(golden_dir, "ddm_bcc_4x2x2.npz"))
+    preset = json.loads(str(g["preset_json"]))
+    preset["geometry"].update(geom_types=geoms, radii=radii, number_of_cells=dict(x=8, y=4, z=4))
+    preset["simulation_parameters"]["DDM"].update(enable_preconditioner=True, preconditioner_type="exact", max_iterations=20000,
+                                                  schur_complement_computation={"type": "exact"})
+    monkeypatch.setattr(LS, "DDM_DENSE_MAX", 100)
+    res = {}
+    for pre in (4, 3):
+        monkeypatch.setattr(LS, "DDM_LARGE_PRECOND", pre)
+        L = LatticeSim(preset, enable_domain_decomposition_solver=True, data_roots=[golden_dir])
+        xsol, info, _, _ = L.solve_DDM()
+        st = L.ddm_model().last_stats
+        assert info == 0 and int(st["precond_used"]) == pre, (info, st["precond_used"])
+        res[pre] = (xsol, L.iteration, L.cell_boundary_nodes().shape[1])
+    assert res[4][2] == (12 if geoms == ["Hybrid1"] else 20)
+    assert _rel(res[4][0], res[3][0]) < 2e-5
+    assert res[4][1] < 0.8 * res[3][1], (res[4][1], res[3][1])
