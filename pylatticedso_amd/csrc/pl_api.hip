@@ -531,14 +531,14 @@ int pl_ddm_update_matrices(pl_handle h, int32_t n_S, const double *S, const int3
   PL_HIP(hipSetDevice(h->opt.device));
   PL_HIP(hipStreamSynchronize(h->stream));
   const int m = 6 * h->ddm_nb;
-  std::vector<double> St((size_t)n_S * m * m);
-  pl::parallel_for(n_S, [&](int64_t s0, int64_t s1, unsigned) {
-    for (int64_t s = s0; s < s1; ++s)
-      for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j) St[((size_t)s * m + j) * m + i] = S[((size_t)s * m + i) * m + j];
-  }, 8);
-  if (h->ddm_St.n != St.size()) PL_HIP(h->ddm_St.alloc(St.size()));
-  PL_HIP(hipMemcpy(h->ddm_St.p, St.data(), St.size() * sizeof(double), hipMemcpyHostToDevice));
+  const size_t cnt = (size_t)n_S * m * m;
+  if (h->ddm_St.n != cnt) PL_HIP(h->ddm_St.alloc(cnt));
+  if (h->ddm_Sraw.n < cnt) PL_HIP(h->ddm_Sraw.alloc(cnt));
+  PL_HIP(hipMemcpyAsync(h->ddm_Sraw.p, S, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(pl::k_ddm_transpose_palette, dim3(grid_for((int64_t)cnt)), dim3(pl::kBlock), 0, h->stream, (int64_t)n_S, m,
+                     (const double *)h->ddm_Sraw.p, h->ddm_St.p);
+  PL_HIP(hipStreamSynchronize(h->stream));
+  PL_HIP(hipGetLastError());
   h->ddm_n_S = n_S;
   if (!std::equal(h->h_ddm_cell_S.begin(), h->h_ddm_cell_S.end(), cell_S)) {
     h->h_ddm_cell_S.assign(cell_S, cell_S + h->ddm_cells);

@@ -146,6 +146,7 @@ struct pl_context {
   std::vector<int32_t> h_ddm_cell_nodes, h_ddm_cell_S;   // host copies (pl_ddm_update_matrices re-cuts the class tiles)
   DevBuf<int32_t> ddm_cell_nodes, ddm_cell_S;
   DevBuf<double> ddm_St;
+  DevBuf<double> ddm_Sraw;            // upload buffer of pl_ddm_update_matrices (transposed on the device)
   DevBuf<int64_t> ddm_node_ptr;       // node -> (cell * nb + slot) entries: the atomic-free scatter of k_ddm_node_gather
   DevBuf<int32_t> ddm_node_ent;
   DevBuf<double> ddm_stage;           // [cells][6 nb] local products

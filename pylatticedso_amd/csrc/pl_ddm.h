@@ -332,6 +332,17 @@ __global__ __launch_bounds__(kBlock) void k_ddm_diag(int64_t C, int nb, const in
 // the assembled matrix is not factorised): the 6 x 6 diagonal blocks of G = sum_c B_c^T Shat_c B_c, inverted per node.
 // Constrained dofs are taken out of the block before the inversion and get zero rows / columns in the inverse.  Measured on the
 // host (BCC cantilevers, r = 0.05, 1e-8): 20^3 cells 296 iterations against 384 with the diagonal alone, 12^3 175 against 254.
+// St[s][j][i] = S[s][i][j] for a whole palette (pl_ddm_update_matrices uploads the caller's matrices as they are and
+// transposes here: a host transposition needs the caller's threads, which a numpy BLAS call may have left spinning)
+__global__ __launch_bounds__(kBlock) void k_ddm_transpose_palette(int64_t n_S, int m, const double *__restrict__ S,
+                                                                  double *__restrict__ St) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n_S * m * m) return;
+  const int64_t s = e / ((int64_t)m * m);
+  const int r = (int)(e - s * m * m), j = r / m, i = r - j * m;       // writes coalesced
+  St[e] = S[(size_t)s * m * m + (size_t)i * m + j];
+}
+
 __global__ __launch_bounds__(kBlock) void k_ddm_node_blocks(int64_t C, int nb, const int32_t *__restrict__ cell_nodes,
                                                             const int32_t *__restrict__ cell_S,
                                                             const double *__restrict__ St, double *__restrict__ B) {

@@ -399,6 +399,14 @@ class LatticeOpti(LatticeSim):
         else:
             raise NotImplementedError(f"Gradient for objective '{self.objective_type}' not implemented yet.")
         G = len(self.geom_types)
+        GA = getattr(self, "_schur_gradients_array", None)
+        if GA is not None and GA.shape[1] == G:
+            # every cell at once: t = dS[idx[c], j] u_c (batched matrix-vector products), then lam_c . t  (a design with one
+            # radius set per cell has as many distinct matrices as cells: the loop below made 4 096 einsum calls at 16^3 cells)
+            idx = self.cell_schur_index
+            T = np.matmul(GA[idx], U[:, None, :, None])[..., 0]          # (C, G, n)
+            s_cell = np.einsum("cgn,cn->cg", T, Lam)
+            return s_cell * self._cell_gfac[:, None]
         s_cell = np.zeros((len(cb), G))
         for k, dS_list in enumerate(self.schur_gradients):            # one batched contraction per distinct matrix
             sel = np.flatnonzero(self.cell_schur_index == k)

@@ -687,6 +687,7 @@ class LatticeSim(LatticeViews):
                 groups[k] = len(mats) - 1
             idx[c] = groups[k]
         self.schur_gradients = grads if self.enable_gradient_computing else None
+        self._schur_gradients_array = None
         self.set_schur_complements(np.stack(mats), idx)
 
     def _surrogate_schur_complement_cells(self):
@@ -704,8 +705,14 @@ class LatticeSim(LatticeViews):
             idx[c] = uniq.setdefault(k, len(uniq))
         radii_batch = [list(k) for k in uniq]
         S = self.schur_surrogate.schur_batch(radii_batch)
-        self.schur_gradients = ([self.schur_surrogate.schur_gradients(r) for r in radii_batch]
-                                if self.enable_gradient_computing else None)
+        self.schur_gradients, self._schur_gradients_array = None, None
+        if self.enable_gradient_computing:
+            G = self.schur_surrogate.schur_gradients_batch(radii_batch)          # (n_q, d, n, n) in one go, or None
+            if G is not None:
+                self._schur_gradients_array = G
+                self.schur_gradients = [list(g) for g in G]                      # (views)
+            else:
+                self.schur_gradients = [self.schur_surrogate.schur_gradients(r) for r in radii_batch]
         if self._verbose > 1:
             print("Number of unique Schur complements computed:", len(radii_batch))
         self.set_schur_complements(S, idx)

@@ -19,6 +19,18 @@ import re
 
 import numpy as np
 
+
+def _single_threaded_blas():
+    """Context in which numpy's BLAS runs on the calling thread only.  The worker threads of a threaded BLAS keep spinning for a
+    while after a GEMM; a device solve that follows within milliseconds then shares the job's CPUs with them and its launch
+    loop crawls (measured: 4.3 -> 32 ms per solve_DDM at 16^3 cells on a 16-CPU share).  These GEMMs are small: one thread does."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1, user_api="blas")
+    except Exception:                     # (no threadpoolctl: as before)
+        import contextlib
+        return contextlib.nullcontext()
+
 KINDS = ("nearest_neighbor", "linear", "RBF")
 
 
@@ -81,7 +93,8 @@ class ThinPlateSpline:
     def evaluate(self, xq):
         """(M, d) -> (M, m)."""
         Xq = np.atleast_2d(np.asarray(xq, dtype=float))
-        return self._phi(self._dist(Xq, self.x)) @ self.w + np.hstack([np.ones((len(Xq), 1)), Xq]) @ self.c
+        with _single_threaded_blas():
+            return self._phi(self._dist(Xq, self.x)) @ self.w + np.hstack([np.ones((len(Xq), 1)), Xq]) @ self.c
 
     def gradient(self, xq):
         """(M, d) -> (M, d, m):  sum_i w_i (2 log r_i + 1)(x - x_i) + c."""
@@ -146,12 +159,32 @@ class SchurSurrogate:
 
     # ---- S(r), dS/dr -----------------------------------------------------------------------------------------
     def _matrices(self, coeffs):
-        flat = self.basis @ np.atleast_2d(coeffs).T                       # (n_S^2, n_q): one GEMM
-        return np.ascontiguousarray(flat.T.reshape(-1, self.n, self.n).transpose(0, 2, 1))   # column-major reshape
+        # the basis vectors are column-major images of (n, n) matrices (lattice_sim.py:919-977 reshapes with order "F"): with
+        # the rows of the basis permuted to row-major ONCE, one GEMM writes the (n_q, n, n) stack as it is wanted (the
+        # transposing copy of the first version was 40 ms per 4 096 matrices, twice per design iteration)
+        bt = self.__dict__.get("_basis_rowmajor_T")
+        if bt is None:
+            n, m = self.n, self.basis.shape[1]
+            bt = self._basis_rowmajor_T = np.ascontiguousarray(self.basis.reshape(n, n, m).transpose(1, 0, 2).reshape(n * n, m).T)
+        with _single_threaded_blas():
+            return (np.atleast_2d(np.asarray(coeffs, dtype=float)) @ bt).reshape(-1, self.n, self.n)
 
     def schur_batch(self, radii_batch):
         """(n_q, d) -> (n_q, n, n)  (lattice_sim.py:919-977)."""
         return self._matrices(self.alphas(radii_batch))
+
+    def schur_gradients_batch(self, radii_batch):
+        """(n_q, d) -> (n_q, d, n, n): dS/dr_j of every radius set in ONE spline evaluation and ONE GEMM (RBF surrogate; the
+        per-set calls of schur_gradients were 0.2 ms each - 4 096 distinct cells: 0.8 s per design iteration).  None for the
+        surrogates whose gradient is a finite difference."""
+        if self.kind != "RBF":
+            return None
+        Xq = np.atleast_2d(np.asarray(radii_batch, dtype=float))
+        if self._tps is None:
+            self._tps = ThinPlateSpline(self.points, self.alpha_train)
+        g = self._tps.gradient(Xq)                                           # (n_q, d, m)
+        nq, d, m = g.shape
+        return self._matrices(g.reshape(nq * d, m)).reshape(nq, d, self.n, self.n)
 
     def schur_gradients(self, radii, eps_rel=1e-6):
         """[dS/dr_j for every radius j].  RBF: analytic through the spline (lattice_sim.py:1056-1082); the other
