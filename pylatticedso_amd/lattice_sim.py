@@ -696,14 +696,12 @@ class LatticeSim(LatticeViews):
         enable_gradient_computing is set."""
         if self.schur_surrogate is None:
             raise NotImplementedError("Not implemented schur complement computation method.")
-        lat = self.lattice
-        par = self._cell_parameter_radii()
-        keys = [tuple(round(float(r), 8) for r in par[c]) for c in range(lat.n_cells)]
-        uniq = {}
-        idx = np.zeros(lat.n_cells, np.int32)
-        for c, k in enumerate(keys):
-            idx[c] = uniq.setdefault(k, len(uniq))
-        radii_batch = [list(k) for k in uniq]
+        par = np.asarray(self._cell_parameter_radii(), dtype=float)
+        # distinct radius sets, rounded to 8 decimals like the reference's cache keys (one numpy pass; the per-cell tuples and the
+        # dictionary of the first version were 10 ms at 4 096 cells)
+        uniq, idx = np.unique(np.round(par.reshape(len(par), -1), 8), axis=0, return_inverse=True)
+        idx = np.asarray(idx, dtype=np.int32).ravel()
+        radii_batch = uniq.tolist()
         S = self.schur_surrogate.schur_batch(radii_batch)
         self.schur_gradients, self._schur_gradients_array = None, None
         if self.enable_gradient_computing:
