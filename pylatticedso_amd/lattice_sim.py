@@ -254,6 +254,8 @@ class LatticeSim(LatticeViews):
             self._cell_radii_override = LA.random_cell_radii(geo.extras["node_creator"], geo.n_cells,
                                                              len(self._base_radii), self.range_radius,
                                                              self.randomness_hybrid)
+        self.__dict__.pop("_surface_points_cache", None)      # (tables derived from the old topology)
+        self.__dict__.pop("_gdi_cache", None)
         self.lattice = LA.generate((self.cell_size_x, self.cell_size_y, self.cell_size_z),
                                    (self.num_cells_x, self.num_cells_y, self.num_cells_z), self.geom_types,
                                    self._base_radii, grad_radius=self.grad_radius, grad_dim=self.grad_dim,
