@@ -900,7 +900,7 @@ def main():
                                    "distinct_radii": int(len(np.unique(glat.beam_radius))),
                                    "beams_per_s": glat.n_beams / dtg, "ms_per_step": dtg * 1e3,
                                    "pcg_iterations": gst["iterations"],
-                                   "step": "records + palette attempt + Jacobi diag + coarse levels + PCG (no BSR)"}
+                                   "step": "records + palette attempt (backed off after failures) + Jacobi diag + coarse levels + PCG (no BSR)"}
         s_traffic, s_src = committed_pmc("pmc_spmv_streaming_latest.json",
                                         spmv_kernel=dev_kernel_name(args.kernel, args.reorder, 0, True))
         streaming.update({"bound": "hbm", "kernel": "K*p: " + dev_kernel_name(args.kernel, args.reorder, 0, True) + " (40-byte records streamed)", "peak": HBM_PEAK_GBS,

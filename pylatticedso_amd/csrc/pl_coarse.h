@@ -891,50 +891,49 @@ __global__ __launch_bounds__(kBlock) void k_tile_blocks_strain(const int32_t *__
 // in place by twelve symmetric sweeps (Gauss-Jordan on an SPD matrix needs no pivoting); a mode whose pivot has lost ten
 // digits against its own diagonal entry has no stiffness of its own (all its dofs fixed, or it repeats earlier modes) and
 // is dropped - zero row and column, as in spd6_inverse.
-constexpr int kInv12Block = 64;
+// (Round 5: one workgroup per tile, one lane per ENTRY of the 12 x 12 block - every pivot step updates all 144 entries at
+// once from the values of the step before.  The first version swept the block serially, one lane per tile: 101 us for the
+// few hundred tiles of configs[3], a quarter of its assembly.  Same arithmetic per entry, same dropping rule.)
+constexpr int kInv12Block = 192;
 __global__ __launch_bounds__(kInv12Block) void k_tile_invert12(int64_t T, const double *__restrict__ raw,
                                                               double *__restrict__ Bt_inv) {
-  __shared__ double As[144][kInv12Block];
-  const int64_t t = (int64_t)blockIdx.x * kInv12Block + threadIdx.x;
-  if (t >= T) return;
   constexpr int n = 12;
-  const int me = threadIdx.x;
-  double diag0[n];
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) As[i * n + j][me] = 0.5 * (raw[t * 144 + i * n + j] + raw[t * 144 + j * n + i]);
-#pragma unroll
-  for (int i = 0; i < n; ++i) diag0[i] = As[i * n + i][me];
+  __shared__ double A[n][n + 1];
+  __shared__ double diag0[n];
+  const int64_t t = blockIdx.x;
+  if (t >= T) return;
+  const int e = threadIdx.x, i = e / n, j = e - n * i;
+  const bool act = e < n * n;
+  if (act) A[i][j] = 0.5 * (raw[t * 144 + i * n + j] + raw[t * 144 + j * n + i]);
+  __syncthreads();
+  if (e < n) diag0[e] = A[e][e];
+  __syncthreads();
   unsigned dropped = 0u;
   for (int k = 0; k < n; ++k) {
-    const double d = As[k * n + k][me];
-    if (!(d > 1e-10 * diag0[k]) || !(diag0[k] > 0.0)) {
+    const double d = A[k][k];
+    if (!(d > 1e-10 * diag0[k]) || !(diag0[k] > 0.0)) {      // (the same decision in every lane)
       dropped |= 1u << k;
       continue;
     }
     const double inv = 1.0 / d;
-    // sweep on pivot k (rows / columns of dropped modes stay out of it)
-    for (int i = 0; i < n; ++i) {
-      if (i == k || ((dropped >> i) & 1u)) continue;
-      const double f = As[i * n + k][me] * inv;
-      for (int j = 0; j < n; ++j) {
-        if (j == k || ((dropped >> j) & 1u)) continue;
-        As[i * n + j][me] -= f * As[k * n + j][me];
-      }
+    double v = 0.0;
+    if (act) {
+      const bool di = (dropped >> i) & 1u, dj = (dropped >> j) & 1u;
+      if (i == k && j == k) v = -inv;
+      else if (i == k) v = A[k][j] * inv;                    // row k, scaled
+      else if (j == k) v = A[k][i] * inv;                    // ... and its mirror image
+      else if (di || dj) v = A[i][j];                        // rows / columns of dropped modes stay out of the sweep
+      else v = A[i][j] - (A[i][k] * inv) * A[k][j];
     }
-    for (int j = 0; j < n; ++j) {
-      if (j == k) continue;
-      const double v = As[k * n + j][me] * inv;
-      As[k * n + j][me] = v;
-      As[j * n + k][me] = v;
-    }
-    As[k * n + k][me] = -inv;
+    __syncthreads();
+    if (act) A[i][j] = v;
+    __syncthreads();
   }
-  // after sweeping every kept pivot the kept block holds -B^-1 (off-diagonal signs flipped back below)
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      const bool out = ((dropped >> i) & 1u) || ((dropped >> j) & 1u);
-      Bt_inv[t * 144 + i * n + j] = out ? 0.0 : -As[i * n + j][me];
-    }
+  // after sweeping every kept pivot the kept block holds -B^-1
+  if (act) {
+    const bool out = ((dropped >> i) & 1u) || ((dropped >> j) & 1u);
+    Bt_inv[t * 144 + i * n + j] = out ? 0.0 : -A[i][j];
+  }
 }
 // The dense level's factorisation and solve in whichever storage type the level uses.
 inline void coarse_factor(Coarse &cs, int n, hipStream_t s, const std::function<void(int)> &after_chol, unsigned *bar,

@@ -124,6 +124,9 @@ struct pl_context {
   DevBuf<double> diag, dinv, x, r, z, p, Ap, tmp, tmp2, scal, hist;
   DevBuf<double> xprev;               // previous converged solution (opts.warm_start)
   bool xprev_valid = false;
+  // record palette: an attempt that fails (a graded lattice: too many distinct records) is not repeated at once
+  int pal_fail_streak = 0, pal_skip_left = 0;
+  bool pal_skipped = false;
   DevBuf<double> xprev2;              // the one before (opts.warm_start = 2: linear extrapolation of the design path)
   bool xprev2_valid = false;
   DevBuf<double> xprev3;              // (warm_start = 3, experiment: quadratic extrapolation)
