@@ -1467,3 +1467,45 @@ def test_extrapolated_warm_start_on_a_smooth_design_path(condense):
     # 4 = the Galerkin start: the best combination of the last (up to) four solutions for the current system - it contains
     # the candidates of 1, 2 and 3
     assert tail[4] <= tail[2], total
+
+
+def test_failed_palette_attempts_back_off_and_a_success_brings_the_palette_back():
+    """Round 5: on a graded lattice every strut has its own record, so the record-palette attempt of pl_assemble fails; after a
+    failure the next 1, 3, 7, 15 assemblies go without an attempt (the streaming form of K*p meanwhile: the same operator), and
+    when the radii become uniform again an attempt at the end of the current pause succeeds and the palette form returns.  Every
+    solve on the way reaches its residual."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 10
+    lat = LA.generate((1, 1, 1), (n, n, n), ["Octet"], [0.03])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == float(n), 2] = -1e-3
+    rng = np.random.default_rng(4)
+    graded = lat.beam_radius * (1.0 + 0.2 * rng.random(lat.n_beams))
+    forms = []
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                          palette=1) as dev:
+        dev.set_bc(fixed, None, f)
+
+        def step(r):
+            dev.update_radii(r)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-9, max_iter=20000)
+            assert st["converged"] == 1
+            res = np.where(fixed, 0.0, f - dev.spmv(u))
+            assert np.linalg.norm(res) <= 2e-9 * np.linalg.norm(f)
+            forms.append(int(st["kp_form"]))
+        step(lat.beam_radius)                      # uniform: palette form
+        assert forms[-1] == 1
+        for _ in range(4):                         # graded: attempt fails, pause, attempt fails, pause ...
+            step(graded)
+        assert all(k != 1 for k in forms[1:])
+        for _ in range(20):                        # uniform again: the palette returns once the pause is over
+            step(lat.beam_radius)
+            if forms[-1] == 1:
+                break
+        assert forms[-1] == 1, forms
+        step(lat.beam_radius)                      # ... and stays
+        assert forms[-1] == 1
