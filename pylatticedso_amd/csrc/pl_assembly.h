@@ -120,12 +120,6 @@ void finish_palette(pl_context *c) {
   }
   c->pal_entries = c->pal_host_flags[1];
   c->pal_ready = (c->pal_host_flags[0] == 0);
-  if (c->pal_ready) {
-    c->pal_fail_streak = 0;
-  } else {
-    c->pal_fail_streak = std::min(c->pal_fail_streak + 1, 4);
-    c->pal_skip_left = (1 << c->pal_fail_streak) - 1;
-  }
   // the LDS-resident K*p (pl_tile.h) when the whole palette fits its LDS table; PL_TILE_LDS=0 keeps the gather kernel (A/B)
   static const bool lds_off = [] { const char *e = std::getenv("PL_TILE_LDS"); return e && e[0] == '0'; }();
   c->pal_lds = c->pal_ready && c->vword.p && c->pal_entries > 0 && c->pal_entries <= pl::kPalDenseMax && !lds_off;
@@ -135,6 +129,12 @@ void finish_palette(pl_context *c) {
   if (c->pal_ready && !c->pal_lds && !lds_off && small_wanted(c) && c->rec5.p && c->vword_dir.p && c->tile.n_dir > 0 &&
       c->tile.n_dir <= pl::kPalDenseMax)
     c->pal_ready = false;
+  if (c->pal_ready) {            // (an attempt whose palette is not USED counts as failed too)
+    c->pal_fail_streak = 0;
+  } else {
+    c->pal_fail_streak = std::min(c->pal_fail_streak + 1, 4);
+    c->pal_skip_left = (1 << c->pal_fail_streak) - 1;
+  }
   // the row kernel (pl_rows.h): opt-in with PL_ROWS=1 (read at every assembly, so that one process can compare both) -
   // measured slower than the tile kernel at 50^3 Octet (51 against 36 us: see the header of pl_rows.h)
   const char *re = std::getenv("PL_ROWS");
