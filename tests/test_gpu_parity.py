@@ -1509,3 +1509,34 @@ def test_failed_palette_attempts_back_off_and_a_success_brings_the_palette_back(
         assert forms[-1] == 1, forms
         step(lat.beam_radius)                      # ... and stays
         assert forms[-1] == 1
+
+
+@pytest.mark.parametrize("condense", [0, 1])
+def test_galerkin_start_with_repeated_scaled_and_unrelated_right_hand_sides(condense):
+    """opts.warm_start = 4 is a projection onto the handle's stored solutions: the identical system again and a scaled load are
+    answered (almost) at once - the stored vectors are dependent then, which the pivot floor of the small Cholesky absorbs -,
+    an unrelated load costs what a cold start costs (never more), and every answer reaches its residual."""
+    from pylatticedso_amd import lattice_arrays as LA
+    n = 12
+    lat = LA.generate((1, 1, 1), (n, n, n), ["BCC"], [0.05])
+    pen = LA.penalize(lat, LA.compute_lzone(lat))
+    fixed = np.zeros((lat.n_nodes, 6), np.uint8)
+    fixed[lat.node_xyz[:, 0] == 0.0] = 1
+    f = np.zeros((lat.n_nodes, 6))
+    f[lat.node_xyz[:, 0] == float(n), 2] = -1e-3
+    g = np.zeros_like(f)
+    g[lat.node_xyz[:, 0] == float(n), 1] = 1e-3
+    with _capi.HipLattice(lat.node_xyz, lat.beam_conn, lat.beam_radius, pen.seg_len, pen.seg_nsub, E, NU, precond=3,
+                          palette=1, warm_start=4, condense=condense, tile_nodes=64, coarse_max_dofs=600) as dev:
+        its = []
+        for load in (f, f, f, 2.0 * f, 2.0 * f, g, g):
+            dev.set_bc(fixed, None, load)
+            dev.assemble()
+            u, st = dev.solve(rtol=1e-9, max_iter=20000)
+            assert st["converged"] == 1 and np.isfinite(u).all()
+            r = np.where(fixed, 0.0, load - dev.spmv(u))
+            assert np.linalg.norm(r) <= 2e-9 * np.linalg.norm(load)
+            its.append(int(st["iterations"]))
+    cold = its[0]
+    assert cold > 100 and max(its[1:5]) <= 3, its           # the same system, the same load scaled
+    assert its[5] <= cold + 3 and its[6] <= 3, its          # an unrelated load: a cold start's count, then known
